@@ -1,0 +1,9 @@
+"""datafusion-bio-formats_amd -- MI355X-native BGZF -> Arrow scan engine (BAM path).
+
+Python side = a thin ctypes consumer of the C ABI in include/bioscan.h, shaped like the
+reference's `BamTableProvider` / `BamExec` (bio-format-bam/src/table_provider.rs,
+physical_exec.rs) so the parity tests read like the reference's own tests.  All decoding
+happens in libbioscan.so on the GPU; importing this package without the built library (or
+opening a file without a HIP device) raises -- there is no CPU fallback.
+"""
+from .table_provider import BamTableProvider, BamExec, BioscanError, load_library, bgzf_inflate, device_check  # noqa: F401

@@ -1,0 +1,104 @@
+// common.h -- shared host-side definitions (Arrow C Data Interface structs, HIP RAII, errors).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdexcept>
+#include <string>
+
+// ---- Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html) ----
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+extern "C" {
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+}
+#endif
+
+namespace bioscan {
+
+struct Error : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+  if (e != hipSuccess) {
+    throw Error(std::string("HIP error in ") + what + " (" + file + ":" + std::to_string(line) + "): " + hipGetErrorString(e));
+  }
+}
+#define HIP_CHECK(x) ::bioscan::hip_check((x), #x, __FILE__, __LINE__)
+
+// device buffer with value semantics off (move only)
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { reset(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { reset(); }
+  void alloc(size_t count) {
+    reset();
+    n = count;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_CHECK(hipMalloc((void**)&p, bytes));
+  }
+  void reset() {
+    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// pinned host buffer
+struct HostBuf {
+  uint8_t* p = nullptr;
+  size_t n = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf&) = delete;
+  HostBuf& operator=(const HostBuf&) = delete;
+  HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  HostBuf& operator=(HostBuf&& o) noexcept {
+    if (this != &o) { reset(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~HostBuf() { reset(); }
+  void alloc(size_t bytes) {
+    reset();
+    n = bytes;
+    HIP_CHECK(hipHostMalloc((void**)&p, bytes ? bytes : 1, hipHostMallocDefault));
+  }
+  void reset() {
+    if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+  }
+};
+
+}  // namespace bioscan

@@ -1,0 +1,134 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (device code lives in kernels.hip).
+// Internal header: the public boundary is include/bioscan.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bioscan {
+
+constexpr uint64_t SEG_NONE = ~0ull;       // segment has no record start
+constexpr uint64_t SEG_BAD = ~0ull - 1;    // walk ran into an impossible block_size
+constexpr uint32_t SEG_BYTES = 65536;      // record-chain segment size (bytes of inflated stream)
+
+// per-block inflate status codes (0 = ok)
+enum InflateStatus : uint32_t {
+  INF_OK = 0, INF_BAD_HEADER = 1, INF_BAD_BTYPE = 2, INF_BAD_CODE = 3, INF_BAD_DIST = 4,
+  INF_OVERRUN = 5, INF_SIZE_MISMATCH = 6, INF_BAD_STORED = 7, INF_CRC_MISMATCH = 8
+};
+
+// ---- K1: BGZF inflate -------------------------------------------------------------------------
+// comp: compressed file bytes (padded by >= 1 KiB readable slack), blk_coff[i] = byte offset of
+// BGZF member i, blk_uoff[i] = offset of its payload in `out`; blk_uoff[n] = total.
+void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
+                         uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
+// K2: CRC32 of each inflated block vs the BGZF trailer (validation mode).
+void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
+                       const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
+
+// ---- scans ------------------------------------------------------------------------------------
+// out[0..n] exclusive prefix sums of in[0..n) (out has n+1 entries); tmp must hold
+// scan_tmp_elems(n) uint64.
+size_t scan_tmp_elems(uint64_t n);
+void launch_exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st);
+
+// ---- K3: record boundary scan -----------------------------------------------------------------
+struct ChainBuffers {
+  uint64_t* entry;   // [nseg]
+  uint64_t* exit_;   // [nseg]
+  uint32_t* count;   // [nseg]
+  uint32_t* dirty;   // [nseg]
+  uint32_t* nfix;    // [1] device counter
+  uint32_t* err;     // [1] device error flag
+};
+void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref,
+                      ChainBuffers cb, hipStream_t st);
+void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, hipStream_t st);
+void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st);
+void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, const uint64_t* base,
+                     uint64_t* rec_off, hipStream_t st);
+
+// ---- record key table (refid,pos,end,flag,mapq per record) ------------------------------------
+struct RecKeys {
+  int32_t* refid;
+  int32_t* pos;      // 0-based, -1 = none
+  int32_t* end1;     // 1-based inclusive end, 0 = None
+  uint32_t* flag_mapq;  // flag | mapq << 16
+};
+void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, hipStream_t st);
+
+// ---- row selection ----------------------------------------------------------------------------
+// Residual filter program: conjunction of terms on numeric fields / chrom index.
+struct FilterTerm {
+  int32_t field;     // 0 chrom(refid), 1 start, 2 end, 3 mapping_quality, 4 flags
+  int32_t op;        // bioscan_filter_op
+  int32_t n_vals;    // number of literal values (<= 8)
+  int32_t has_null;  // in-list contained NULL / non-numeric literal
+  double vals[8];    // numeric literals, or ref index for chrom (-1 = name not in header)
+};
+struct RowSelect {
+  int32_t mode;          // 0 all records, 1 mapped region, 2 unmapped tail of ref, 3 no-coor
+  int32_t ref;           // region reference index
+  int64_t start1, end1;  // region bounds 1-based inclusive, <=0 / INT64_MAX = unbounded
+  int64_t q_start1;      // noodles interval start used by intersects()
+  uint64_t i_lo, i_hi;   // record index range considered (mode 2: run bounds)
+  int32_t zero_based;
+  int32_t n_terms;
+};
+void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, hipStream_t st);
+void launch_compact_rows(const uint64_t* rec_off, const uint32_t* keep, const uint64_t* keep_scan, uint64_t n,
+                         uint64_t* rows, uint64_t row_base, hipStream_t st);
+// tail run finder: first index >= i0 with refid==ref  /  first index > a with refid != ref
+void launch_find_first(const int32_t* refid, uint64_t n, uint64_t from, int32_t ref, int want_equal,
+                       unsigned long long* result, hipStream_t st);
+void launch_lower_bound_u64(const uint64_t* arr, uint64_t n, uint64_t key, unsigned long long* result, hipStream_t st);
+
+// ---- K4-K7: field extract + Arrow scatter -----------------------------------------------------
+struct CoreCols {   // device pointers; nullptr = not projected
+  uint32_t* start; uint32_t* end; uint32_t* flags; uint32_t* mapq; uint32_t* mate_start; int32_t* tlen;
+  uint64_t* v_chrom; uint64_t* v_start; uint64_t* v_end; uint64_t* v_mate_chrom; uint64_t* v_mate_start;  // validity words
+  uint32_t* len_name; uint32_t* len_chrom; uint32_t* len_cigar; uint32_t* len_mate_chrom; uint32_t* len_seq; uint32_t* len_qual;
+};
+struct RowOverride {  // indexed-path overrides (physical_exec.rs:1078-1080, 1206-1208)
+  int32_t force_null_coords;   // start/end NULL
+  int32_t chrom_mode;          // 0 from record, 1 NULL, 2 fixed ref index
+  int32_t chrom_ref;
+};
+void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, CoreCols c,
+                          const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
+                          RowOverride ov, uint32_t* err, hipStream_t st);
+void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, int32_t* off32, hipStream_t st);
+void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n,
+                          const uint64_t* off_name, uint8_t* d_name,
+                          const uint64_t* off_chrom, uint8_t* d_chrom,
+                          const uint64_t* off_cigar, uint8_t* d_cigar,
+                          const uint64_t* off_mate, uint8_t* d_mate,
+                          const uint8_t* ref_names, const uint32_t* ref_name_off, int32_t n_ref, int32_t binary_cigar,
+                          RowOverride ov, hipStream_t st);
+// which: 0 = sequence (4-bit -> ASCII), 1 = quality (+33).  qual_wide: set to 1 when a quality byte
+// maps to a 2-byte UTF-8 char (q+33 >= 128): caller re-runs the exact wide path.
+void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst,
+                            int which, uint32_t* qual_wide, hipStream_t st);
+void launch_qual_wide_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, uint32_t* len_qual, hipStream_t st);
+void launch_qual_wide_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
+
+// ---- tags ---------------------------------------------------------------------------------------
+// loc[t*n + i] = byte offset (from record start) of the aux VALUE of requested tag t in row i,
+// typ[t*n + i] = its BAM type char (0 = absent).  tags[t] = two tag bytes little-endian.
+void launch_tag_locate(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint16_t* tags_dev, int32_t n_tags,
+                       uint32_t* loc, uint8_t* typ, uint32_t* err, hipStream_t st);
+enum TagColKind : int32_t { TAG_INT32 = 0, TAG_UINT32 = 1, TAG_FLOAT32 = 2, TAG_UTF8 = 3, TAG_LIST = 4 };
+// fixed-width tag column (Int32/UInt32/Float32): values + validity words (row0 = global row index of rows[0])
+void launch_tag_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                      int32_t kind, uint32_t* values, uint64_t* valid, uint32_t* err, hipStream_t st);
+// utf8 tag column: pass 1 lengths (+validity), pass 2 scatter
+void launch_tag_utf8_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                         uint32_t* len, uint64_t* valid, uint32_t* err, hipStream_t st);
+void launch_tag_utf8_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                             const uint64_t* off64, const uint64_t* valid, uint64_t row0, uint8_t* dst, hipStream_t st);
+// list tag column: elem: 0 i8,1 u8,2 i16,3 u16,4 i32,5 u32,6 f32
+void launch_tag_list_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                         int32_t elem, uint32_t* len, uint64_t* valid, uint32_t* err, hipStream_t st);
+void launch_tag_list_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                             int32_t elem, const uint64_t* off64, uint8_t* dst, uint32_t* err, hipStream_t st);
+
+}  // namespace bioscan

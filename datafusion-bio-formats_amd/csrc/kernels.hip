@@ -1,0 +1,969 @@
+// kernels.hip -- record-boundary scan, row selection, field extract -> Arrow scatter, tags (gfx950).
+//
+// These kernels replace the per-record loop of the reference's BamExec
+// (bio-format-bam/src/physical_exec.rs:408-573 sequential, :1269-1356 indexed) and the Arrow
+// builders it drives (bio-format-core/src/alignment_utils.rs:383-644, sam_tag_io.rs:154-204,
+// 658-1036).  All integer / byte work: no MFMA.  Layout rule: row i of a launch is lane
+// (i & 63) of wave (i >> 6), so fixed-width columns and validity words are written fully
+// coalesced and one wave owns exactly one 64-bit validity word per nullable column.
+#include "kernels.h"
+#include "../../include/bioscan.h"
+
+namespace bioscan {
+
+#define WAVE 64
+
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+__device__ __forceinline__ int32_t ld_i32(const uint8_t* p) { return (int32_t)ld_u32(p); }
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// =================================================================================================
+// exclusive scan u32 -> u64 (three-kernel, 2048 elements per block)
+// =================================================================================================
+constexpr int SCAN_T = 256;
+constexpr int SCAN_PER = 8;
+constexpr int SCAN_BLOCK = SCAN_T * SCAN_PER;
+
+size_t scan_tmp_elems(uint64_t n) { return (size_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK) + 2; }
+
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t lo = __shfl_up((uint32_t)v, d, WAVE);
+    uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, WAVE);
+    uint64_t o = ((uint64_t)hi << 32) | lo;
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of per-thread totals; returns exclusive prefix, *total = block sum
+__device__ uint64_t block_excl_scan(uint64_t v, uint64_t* total) {
+  __shared__ uint64_t s_w[SCAN_T / WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t inc = wave_incl_scan(v, lane);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  for (int i = 0; i < SCAN_T / WAVE; i++) {
+    if (i < w) base += s_w[i];
+    tot += s_w[i];
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_local(const uint32_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                        uint64_t n, uint64_t* __restrict__ block_sums) {
+  const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BLOCK;
+  const uint64_t t0 = b0 + (uint64_t)threadIdx.x * SCAN_PER;
+  uint32_t v[SCAN_PER];
+  uint64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    uint64_t i = t0 + k;
+    v[k] = i < n ? in[i] : 0u;
+    s += v[k];
+  }
+  uint64_t tot;
+  uint64_t ex = block_excl_scan(s, &tot);
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; k++) {
+    uint64_t i = t0 + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block sums in place; block_sums[nb] = grand total
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(uint64_t* block_sums, uint64_t nb) {
+  __shared__ uint64_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < nb; base += SCAN_T) {
+    uint64_t i = base + threadIdx.x;
+    uint64_t v = i < nb ? block_sums[i] : 0;
+    uint64_t tot;
+    uint64_t ex = block_excl_scan(v, &tot);
+    uint64_t c = carry_s;
+    if (i < nb) block_sums[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = c + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_sums[nb] = carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(uint64_t* __restrict__ out, uint64_t n,
+                                                      const uint64_t* __restrict__ block_sums, uint64_t nb) {
+  const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_BLOCK;
+  const uint64_t add = block_sums[blockIdx.x];
+  for (int k = 0; k < SCAN_PER; k++) {
+    uint64_t i = b0 + (uint64_t)k * SCAN_T + threadIdx.x;
+    if (i < n) out[i] += add;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
+}
+
+void launch_exclusive_scan_u32_to_u64(const uint32_t* in, uint64_t* out, uint64_t n, uint64_t* tmp, hipStream_t st) {
+  if (n == 0) {
+    hipMemsetAsync(out, 0, sizeof(uint64_t), st);
+    return;
+  }
+  uint64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  hipLaunchKernelGGL(k_scan_local, dim3((uint32_t)nb), dim3(SCAN_T), 0, st, in, out, n, tmp);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, tmp, nb);
+  hipLaunchKernelGGL(k_scan_add, dim3((uint32_t)nb), dim3(SCAN_T), 0, st, out, n, tmp, nb);
+}
+
+// =================================================================================================
+// K3: record boundary scan.  The record chain (block_size prefixes) is a linked list through the
+// whole inflated stream.  It is cut into SEG_BYTES segments; each segment's entry (first record
+// start >= segment begin) is GUESSED with a plausibility test, every segment is walked in
+// parallel from its guess, and the guesses are VERIFIED exactly: entry[s] must equal the exit of
+// the nearest preceding non-empty segment.  Segment 0's entry is exact (end of the BAM header),
+// so by induction a verified chain is the true chain.  Mismatches are corrected and re-walked
+// until none remain (normally zero iterations).
+// =================================================================================================
+__device__ __forceinline__ bool plausible_rec(const uint8_t* u, uint64_t ulen, uint64_t p, int32_t n_ref, uint64_t* next) {
+  if (p + 36 > ulen) return false;
+  const uint8_t* r = u + p;
+  int32_t bs = ld_i32(r);
+  if (bs < 32) return false;
+  if (p + 4 + (uint64_t)bs > ulen) return false;
+  int32_t refid = ld_i32(r + 4), pos = ld_i32(r + 8);
+  uint32_t lrn = r[12];
+  uint32_t ncig = ld_u16(r + 16);
+  int32_t lseq = ld_i32(r + 20);
+  int32_t nref = ld_i32(r + 24), npos = ld_i32(r + 28);
+  if (refid < -1 || refid >= n_ref || nref < -1 || nref >= n_ref) return false;
+  if (pos < -1 || npos < -1 || lseq < 0 || lrn == 0) return false;
+  uint64_t need = 32ull + lrn + 4ull * ncig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
+  if (need > (uint64_t)bs) return false;
+  if (r[36 + lrn - 1] != 0) return false;
+  *next = p + 4 + (uint64_t)bs;
+  return true;
+}
+
+__global__ __launch_bounds__(WAVE) void k_seg_guess(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t first_rec,
+                                                     uint64_t nseg, int32_t n_ref, uint64_t* __restrict__ entry) {
+  const uint64_t s = blockIdx.x;
+  if (s >= nseg) return;
+  const int lane = threadIdx.x;
+  const uint64_t B = s * SEG_BYTES;
+  uint64_t E = B + SEG_BYTES;
+  if (E > ulen) E = ulen;
+  uint64_t res = SEG_NONE;
+  if (first_rec >= E) {
+    res = SEG_NONE;  // still inside the BAM header
+  } else if (first_rec >= B) {
+    res = first_rec;  // exact anchor
+  } else {
+    for (uint64_t p0 = B; p0 < E; p0 += WAVE) {
+      uint64_t p = p0 + lane;
+      uint64_t nx = 0, nx2 = 0;
+      bool ok = p < E && plausible_rec(u, ulen, p, n_ref, &nx);
+      if (ok) ok = (nx == ulen) || plausible_rec(u, ulen, nx, n_ref, &nx2);
+      unsigned long long m = __ballot(ok);
+      if (m) {
+        res = p0 + (uint64_t)__builtin_ctzll(m);
+        break;
+      }
+    }
+  }
+  if (lane == 0) entry[s] = res;
+}
+
+__global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  if (only_dirty && !cb.dirty[s]) return;
+  uint64_t E = (s + 1) * (uint64_t)SEG_BYTES;
+  if (E > ulen) E = ulen;
+  uint64_t p = cb.entry[s];
+  uint32_t cnt = 0;
+  uint64_t ex = SEG_NONE;
+  if (p != SEG_NONE) {
+    ex = p;
+    while (ex < E) {
+      if (ex + 4 > ulen) { ex = SEG_BAD; break; }
+      int32_t bs = ld_i32(u + ex);
+      if (bs < 32 || ex + 4 + (uint64_t)bs > ulen) { ex = SEG_BAD; break; }
+      ex += 4 + (uint64_t)bs;
+      cnt++;
+    }
+  }
+  cb.exit_[s] = ex;
+  cb.count[s] = cnt;
+  cb.dirty[s] = 0;
+}
+
+__global__ void k_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const uint64_t first_seg = first_rec / SEG_BYTES;
+  if (s <= first_seg) return;  // exact anchor / header segments
+  const uint64_t B = s * (uint64_t)SEG_BYTES;
+  uint64_t E = B + SEG_BYTES;
+  if (E > ulen) E = ulen;
+  uint64_t t = s - 1;
+  while (t > first_seg && cb.exit_[t] == SEG_NONE) t--;
+  const uint64_t e = cb.exit_[t];
+  uint64_t expect;
+  if (e == SEG_BAD || e == SEG_NONE) expect = SEG_NONE;      // upstream is broken / empty: nothing starts here yet
+  else if (e >= B && e < E) expect = e;
+  else expect = SEG_NONE;                                      // a long record covers this segment (or stream ended)
+  if (cb.entry[s] != expect) {
+    cb.entry[s] = expect;
+    cb.dirty[s] = 1;
+    atomicAdd(cb.nfix, 1u);
+  }
+}
+
+__global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t nseg, ChainBuffers cb,
+                           const uint64_t* __restrict__ base, uint64_t* __restrict__ rec_off) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  uint64_t E = (s + 1) * (uint64_t)SEG_BYTES;
+  if (E > ulen) E = ulen;
+  uint64_t p = cb.entry[s];
+  if (p == SEG_NONE) return;
+  if (cb.exit_[s] == SEG_BAD) {
+    atomicExch(cb.err, 1u);
+    return;
+  }
+  uint64_t o = base[s];
+  while (p < E) {
+    rec_off[o++] = p;
+    p += 4 + (uint64_t)ld_u32(u + p);
+  }
+}
+
+void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref, ChainBuffers cb, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_guess, dim3((uint32_t)nseg), dim3(WAVE), 0, st, u, ulen, first_rec, nseg, n_ref, cb.entry);
+}
+void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_walk, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, only_dirty);
+}
+void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_verify, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, ulen, first_rec, nseg, cb);
+}
+void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, const uint64_t* base, uint64_t* rec_off, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_emit, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, base, rec_off);
+}
+
+// =================================================================================================
+// record key table + row selection
+// =================================================================================================
+__device__ __forceinline__ uint32_t cigar_ref_span(const uint8_t* cig, uint32_t n) {
+  uint32_t span = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t v = ld_u32(cig + 4 * k);
+    uint32_t op = v & 15u;
+    // M(0) D(2) N(3) =(7) X(8) consume the reference
+    if ((0x18Du >> op) & 1u) span += v >> 4;
+  }
+  return span;
+}
+
+// 1-based inclusive end; 0 encodes None.  noodles: end = start + span - 1, Position::new(0) = None.
+__device__ __forceinline__ uint32_t rec_end1(const uint8_t* r) {
+  int32_t pos = ld_i32(r + 8);
+  if (pos < 0) return 0;
+  uint32_t lrn = r[12];
+  uint32_t ncig = ld_u16(r + 16);
+  uint32_t span = cigar_ref_span(r + 36 + lrn, ncig);
+  return (uint32_t)pos + span;  // (pos+1) + span - 1
+}
+
+__global__ void k_rec_keys(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n, RecKeys k) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = u + rec_off[i];
+  k.refid[i] = ld_i32(r + 4);
+  k.pos[i] = ld_i32(r + 8);
+  k.end1[i] = (int32_t)rec_end1(r);
+  k.flag_mapq[i] = ld_u16(r + 18) | ((uint32_t)r[13] << 16);
+}
+void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_rec_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, k);
+}
+
+// residual filter evaluation (bio-format-core/src/record_filter.rs:57-283 with BamRecordFields,
+// bio-format-bam/src/storage.rs:456-494): numeric compares in f64, NULL fields pass through.
+__device__ bool eval_terms(const FilterTerm* t, int n, bool has_chrom, int32_t chrom_ref, bool has_start, uint32_t start,
+                           bool has_end, uint32_t end, uint32_t mapq, uint32_t flags) {
+  for (int k = 0; k < n; k++) {
+    const FilterTerm& f = t[k];
+    bool have;
+    double v;
+    switch (f.field) {
+      case 0: have = has_chrom; v = (double)chrom_ref; break;
+      case 1: have = has_start; v = (double)start; break;
+      case 2: have = has_end; v = (double)end; break;
+      case 3: have = true; v = (double)mapq; break;
+      default: have = true; v = (double)flags; break;
+    }
+    if (!have) continue;  // field not found on record -> pass through
+    bool ok = true;
+    switch (f.op) {
+      case BIOSCAN_OP_EQ: ok = v == f.vals[0]; break;
+      case BIOSCAN_OP_NE: ok = v != f.vals[0]; break;
+      case BIOSCAN_OP_LT: ok = v < f.vals[0]; break;
+      case BIOSCAN_OP_LE: ok = v <= f.vals[0]; break;
+      case BIOSCAN_OP_GT: ok = v > f.vals[0]; break;
+      case BIOSCAN_OP_GE: ok = v >= f.vals[0]; break;
+      case BIOSCAN_OP_BETWEEN: ok = v >= f.vals[0] && v <= f.vals[1]; break;
+      case BIOSCAN_OP_NOT_BETWEEN: ok = !(v >= f.vals[0] && v <= f.vals[1]); break;
+      case BIOSCAN_OP_IN:
+      case BIOSCAN_OP_NOT_IN: {
+        bool hit = false;
+        for (int j = 0; j < f.n_vals; j++) hit = hit || (v == f.vals[j]);
+        const bool neg = f.op == BIOSCAN_OP_NOT_IN;
+        ok = hit ? !neg : (!f.has_null && neg);
+      } break;
+    }
+    if (!ok) return false;
+  }
+  return true;
+}
+
+__global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t refid = k.refid[i], pos = k.pos[i];
+  const uint32_t end1 = (uint32_t)k.end1[i];
+  const uint32_t fm = k.flag_mapq[i];
+  bool kp = false;
+  bool has_chrom = false, has_start = false, has_end = false;
+  int32_t chrom_ref = -1;
+  uint32_t start_out = 0;
+  if (sel.mode == 0) {
+    kp = true;
+  } else if (sel.mode == 1) {
+    // noodles query intersects() then the reference's sub-region dedup (physical_exec.rs:1280-1314)
+    if (refid == sel.ref && pos >= 0 && end1 != 0) {
+      const int64_t s1 = (int64_t)pos + 1;
+      const bool inter = sel.q_start1 <= (int64_t)end1 && s1 <= sel.end1;
+      const bool dedup = s1 >= sel.start1 && s1 <= sel.end1;
+      kp = inter && dedup;
+      has_chrom = true; chrom_ref = refid;
+      has_start = true; start_out = sel.zero_based ? (uint32_t)pos : (uint32_t)pos + 1u;
+      has_end = true;
+    } else if (refid == sel.ref && pos >= 0 && end1 == 0) {
+      kp = false;  // alignment_end() == None -> intersects() false
+    }
+  } else if (sel.mode == 2) {
+    kp = i >= sel.i_lo && i < sel.i_hi && refid == sel.ref && pos < 0;
+    has_chrom = true; chrom_ref = sel.ref;
+  } else {
+    kp = refid < 0 && pos < 0;
+  }
+  if (kp && sel.n_terms)
+    kp = eval_terms(terms, sel.n_terms, has_chrom, chrom_ref, has_start, start_out, has_end, end1, fm >> 16, fm & 0xFFFFu);
+  keep[i] = kp ? 1u : 0u;
+}
+void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_row_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, k, n, sel, terms_dev, keep);
+}
+
+__global__ void k_compact_rows(const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ keep,
+                               const uint64_t* __restrict__ keep_scan, uint64_t n, uint64_t* __restrict__ rows, uint64_t row_base) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i]) rows[row_base + keep_scan[i]] = rec_off[i];
+}
+void launch_compact_rows(const uint64_t* rec_off, const uint32_t* keep, const uint64_t* keep_scan, uint64_t n, uint64_t* rows,
+                         uint64_t row_base, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_compact_rows, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, rec_off, keep, keep_scan, n, rows, row_base);
+}
+
+__global__ void k_find_first(const int32_t* __restrict__ refid, uint64_t n, uint64_t from, int32_t ref, int want_equal,
+                             unsigned long long* result) {
+  const uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool eq = refid[i] == ref;
+  if (eq == (want_equal != 0)) atomicMin(result, (unsigned long long)i);
+}
+void launch_find_first(const int32_t* refid, uint64_t n, uint64_t from, int32_t ref, int want_equal, unsigned long long* result, hipStream_t st) {
+  if (from >= n) return;
+  uint64_t m = n - from;
+  hipLaunchKernelGGL(k_find_first, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, st, refid, n, from, ref, want_equal, result);
+}
+__global__ void k_lower_bound(const uint64_t* __restrict__ arr, uint64_t n, uint64_t key, unsigned long long* result) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    if (arr[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  *result = lo;
+}
+void launch_lower_bound_u64(const uint64_t* arr, uint64_t n, uint64_t key, unsigned long long* result, hipStream_t st) {
+  hipLaunchKernelGGL(k_lower_bound, dim3(1), dim3(1), 0, st, arr, n, key, result);
+}
+
+// =================================================================================================
+// K4/K6: fixed-width columns, validity words, var-len lengths
+// =================================================================================================
+__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
+  uint32_t d = 1;
+  while (v >= 10) { v /= 10; d++; }
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_extract_fixed(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
+                                                        uint64_t row0, uint64_t n, CoreCols c,
+                                                        const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
+                                                        int32_t zero_based, int32_t binary_cigar, RowOverride ov,
+                                                        uint32_t* err) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // local row
+  const bool act = li < n;
+  const uint64_t i = row0 + li;  // global row index (row0 is a multiple of 64)
+  int32_t refid = -1, pos = -1, nref = -1, npos = -1, tlen = 0, lseq = 0;
+  uint32_t lrn = 1, mapq = 0, ncig = 0, flag = 0, end1 = 0;
+  const uint8_t* r = nullptr;
+  if (act) {
+    r = u + rows[li];
+    refid = ld_i32(r + 4); pos = ld_i32(r + 8);
+    lrn = r[12]; mapq = r[13]; ncig = ld_u16(r + 16); flag = ld_u16(r + 18);
+    lseq = ld_i32(r + 20); nref = ld_i32(r + 24); npos = ld_i32(r + 28); tlen = ld_i32(r + 32);
+    if (refid >= n_ref || nref >= n_ref) { atomicExch(err, 2u); refid = -1; nref = -1; }
+  }
+  bool v_start = act && pos >= 0 && !ov.force_null_coords;
+  bool v_end = false;
+  if (act && (c.end || c.v_end) && !ov.force_null_coords) {
+    end1 = rec_end1(r);
+    v_end = end1 != 0;
+  }
+  int32_t chrom_ref = ov.chrom_mode == 0 ? refid : (ov.chrom_mode == 2 ? ov.chrom_ref : -1);
+  bool v_chrom = act && chrom_ref >= 0;
+  bool v_mchrom = act && nref >= 0;
+  bool v_mstart = act && npos >= 0;
+  if (act) {
+    if (c.start) c.start[i] = v_start ? (zero_based ? (uint32_t)pos : (uint32_t)pos + 1u) : 0u;
+    if (c.end) c.end[i] = v_end ? end1 : 0u;
+    if (c.flags) c.flags[i] = flag;
+    if (c.mapq) c.mapq[i] = mapq;
+    if (c.mate_start) c.mate_start[i] = v_mstart ? (zero_based ? (uint32_t)npos : (uint32_t)npos + 1u) : 0u;
+    if (c.tlen) c.tlen[i] = tlen;
+    if (c.len_name) {
+      // noodles strips the trailing NUL; a missing name ("*\0") is rendered "*" by the reference
+      uint32_t l = lrn ? lrn - 1 : 0;
+      c.len_name[i] = l;
+    }
+    if (c.len_chrom) c.len_chrom[i] = v_chrom ? ref_name_len[chrom_ref] : 0u;
+    if (c.len_mate_chrom) c.len_mate_chrom[i] = v_mchrom ? ref_name_len[nref] : 0u;
+    if (c.len_seq) c.len_seq[i] = (uint32_t)lseq;
+    if (c.len_qual) c.len_qual[i] = (uint32_t)lseq;
+    if (c.len_cigar) {
+      uint32_t l = 0;
+      if (binary_cigar) l = 4 * ncig;
+      else {
+        const uint8_t* cg = r + 36 + lrn;
+        for (uint32_t k = 0; k < ncig; k++) {
+          uint32_t v = ld_u32(cg + 4 * k);
+          if ((v & 15u) > 8u) atomicExch(err, 3u);
+          l += dec_digits(v >> 4) + 1;
+        }
+      }
+      c.len_cigar[i] = l;
+    }
+  }
+  // validity words: one 64-bit word per wave (rows are wave-aligned)
+  const int lane = threadIdx.x & 63;
+  const uint64_t word = i >> 6;
+  unsigned long long m;
+  if (c.v_chrom) { m = __ballot(v_chrom); if (lane == 0 && act) c.v_chrom[word] = m; }
+  if (c.v_start) { m = __ballot(v_start); if (lane == 0 && act) c.v_start[word] = m; }
+  if (c.v_end) { m = __ballot(v_end); if (lane == 0 && act) c.v_end[word] = m; }
+  if (c.v_mate_chrom) { m = __ballot(v_mchrom); if (lane == 0 && act) c.v_mate_chrom[word] = m; }
+  if (c.v_mate_start) { m = __ballot(v_mstart); if (lane == 0 && act) c.v_mate_start[word] = m; }
+}
+void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, CoreCols c,
+                          const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
+                          RowOverride ov, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_extract_fixed, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, c, ref_name_len,
+                     n_ref, zero_based, binary_cigar, ov, err);
+}
+
+// per-batch int32 offsets: off32[b*(bs+1) + r] = off64[b*bs + r] - off64[b*bs]
+__global__ void k_batch_offsets(const uint64_t* __restrict__ off64, uint64_t n_rows, uint32_t bs, int32_t* __restrict__ off32) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t nb = (n_rows + bs - 1) / bs;
+  const uint64_t per = (uint64_t)bs + 1;
+  if (t >= nb * per) return;
+  const uint64_t b = t / per, r = t % per;
+  uint64_t row = b * bs + r;
+  if (row > n_rows) row = n_rows;
+  off32[t] = (int32_t)(off64[row] - off64[b * bs]);
+}
+void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, int32_t* off32, hipStream_t st) {
+  if (!n_rows) return;
+  uint64_t nb = (n_rows + batch_size - 1) / batch_size;
+  uint64_t tot = nb * ((uint64_t)batch_size + 1);
+  hipLaunchKernelGGL(k_batch_offsets, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, off64, n_rows, batch_size, off32);
+}
+
+// =================================================================================================
+// K7a: short var-len columns, one record per lane (name, chrom, cigar, mate_chrom)
+// =================================================================================================
+__device__ __forceinline__ uint32_t write_dec(uint8_t* d, uint32_t v) {
+  uint32_t nd = dec_digits(v);
+  for (int k = (int)nd - 1; k >= 0; k--) { d[k] = (uint8_t)('0' + v % 10); v /= 10; }
+  return nd;
+}
+
+__global__ __launch_bounds__(256) void k_scatter_small(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
+                                                        uint64_t row0, uint64_t n,
+                                                        const uint64_t* __restrict__ off_name, uint8_t* __restrict__ d_name,
+                                                        const uint64_t* __restrict__ off_chrom, uint8_t* __restrict__ d_chrom,
+                                                        const uint64_t* __restrict__ off_cigar, uint8_t* __restrict__ d_cigar,
+                                                        const uint64_t* __restrict__ off_mate, uint8_t* __restrict__ d_mate,
+                                                        const uint8_t* __restrict__ ref_names, const uint32_t* __restrict__ ref_name_off,
+                                                        int32_t n_ref, int32_t binary_cigar, RowOverride ov) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  const uint64_t i = row0 + li;
+  const uint8_t* r = u + rows[li];
+  const uint32_t lrn = r[12];
+  if (d_name) {
+    uint8_t* d = d_name + off_name[i];
+    const uint32_t l = lrn ? lrn - 1 : 0;
+    for (uint32_t k = 0; k < l; k++) d[k] = r[36 + k];
+  }
+  if (d_chrom) {
+    int32_t refid = ld_i32(r + 4);
+    int32_t cr = ov.chrom_mode == 0 ? refid : (ov.chrom_mode == 2 ? ov.chrom_ref : -1);
+    if (cr >= 0 && cr < n_ref) {
+      uint8_t* d = d_chrom + off_chrom[i];
+      const uint32_t a = ref_name_off[cr], b = ref_name_off[cr + 1];
+      for (uint32_t k = a; k < b; k++) d[k - a] = ref_names[k];
+    }
+  }
+  if (d_mate) {
+    int32_t nref = ld_i32(r + 24);
+    if (nref >= 0 && nref < n_ref) {
+      uint8_t* d = d_mate + off_mate[i];
+      const uint32_t a = ref_name_off[nref], b = ref_name_off[nref + 1];
+      for (uint32_t k = a; k < b; k++) d[k - a] = ref_names[k];
+    }
+  }
+  if (d_cigar) {
+    const uint32_t ncig = ld_u16(r + 16);
+    const uint8_t* cg = r + 36 + lrn;
+    uint8_t* d = d_cigar + off_cigar[i];
+    if (binary_cigar) {
+      for (uint32_t k = 0; k < 4 * ncig; k++) d[k] = cg[k];
+    } else {
+      const char ops[] = "MIDNSHP=X???????";
+      for (uint32_t k = 0; k < ncig; k++) {
+        uint32_t v = ld_u32(cg + 4 * k);
+        d += write_dec(d, v >> 4);
+        *d++ = (uint8_t)ops[v & 15u];
+      }
+    }
+  }
+}
+void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint64_t* off_name,
+                          uint8_t* d_name, const uint64_t* off_chrom, uint8_t* d_chrom, const uint64_t* off_cigar,
+                          uint8_t* d_cigar, const uint64_t* off_mate, uint8_t* d_mate, const uint8_t* ref_names,
+                          const uint32_t* ref_name_off, int32_t n_ref, int32_t binary_cigar, RowOverride ov, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scatter_small, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, off_name, d_name,
+                     off_chrom, d_chrom, off_cigar, d_cigar, off_mate, d_mate, ref_names, ref_name_off, n_ref, binary_cigar, ov);
+}
+
+// =================================================================================================
+// K7b: sequence / quality, output-centric: a workgroup owns 256 consecutive rows, stages their
+// output offsets in LDS, and its threads sweep the rows' OUTPUT bytes so stores are coalesced
+// (consecutive lanes -> consecutive bytes of the Arrow values buffer).
+// =================================================================================================
+constexpr int SQ_ROWS = 256;
+__global__ __launch_bounds__(256) void k_scatter_seqqual(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
+                                                          uint64_t n, const uint64_t* __restrict__ off64,
+                                                          uint8_t* __restrict__ dst, int which, uint32_t* qual_wide) {
+  __shared__ uint64_t s_off[SQ_ROWS + 1];
+  __shared__ uint64_t s_src[SQ_ROWS];
+  const uint64_t r0 = (uint64_t)blockIdx.x * SQ_ROWS;
+  const uint32_t nr = (uint32_t)((n - r0) < SQ_ROWS ? (n - r0) : SQ_ROWS);
+  for (uint32_t k = threadIdx.x; k <= nr; k += 256) s_off[k] = off64[r0 + k];
+  for (uint32_t k = threadIdx.x; k < nr; k += 256) {
+    const uint8_t* r = u + rows[r0 + k];
+    const uint32_t lrn = r[12];
+    const uint32_t ncig = ld_u16(r + 16);
+    const int32_t lseq = ld_i32(r + 20);
+    uint64_t src = rows[r0 + k] + 36 + lrn + 4ull * ncig;
+    if (which == 1) src += (uint64_t)((lseq + 1) / 2);
+    s_src[k] = src;
+  }
+  __syncthreads();
+  const uint64_t b0 = s_off[0], b1 = s_off[nr];
+  bool wide = false;
+  for (uint64_t j = b0 + threadIdx.x; j < b1; j += 256) {
+    // upper_bound - 1 over s_off[0..nr]
+    uint32_t lo = 0, hi = nr;
+    while (lo + 1 < hi) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= j) lo = mid; else hi = mid;
+    }
+    // skip empty rows: lo is the last row with off <= j (rows with zero length share offsets)
+    const uint32_t k = (uint32_t)(j - s_off[lo]);
+    const uint8_t* sp = u + s_src[lo];
+    uint8_t o;
+    if (which == 0) {
+      const uint8_t b = sp[k >> 1];
+      const uint32_t nib = (k & 1u) ? (b & 15u) : (b >> 4);
+      o = (uint8_t)"=ACMGRSVTWYHKDBN"[nib];
+    } else {
+      const uint32_t q = ((uint32_t)sp[k] + 33u) & 0xFFu;
+      wide = wide || q >= 128u;
+      o = (uint8_t)q;
+    }
+    dst[j] = o;
+  }
+  if (which == 1 && wide) atomicExch(qual_wide, 1u);
+}
+void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, int which,
+                            uint32_t* qual_wide, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scatter_seqqual, dim3((uint32_t)((n + SQ_ROWS - 1) / SQ_ROWS)), dim3(256), 0, st, u, rows, n, off64, dst,
+                     which, qual_wide);
+}
+
+// exact wide-quality path: `char::from(q + 33)` pushed into a String -> chars >= U+0080 take two UTF-8 bytes
+__global__ void k_qual_wide_len(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
+                                uint32_t* __restrict__ len_qual) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  const uint8_t* r = u + rows[li];
+  const uint32_t lrn = r[12], ncig = ld_u16(r + 16);
+  const int32_t lseq = ld_i32(r + 20);
+  const uint8_t* q = r + 36 + lrn + 4 * ncig + (lseq + 1) / 2;
+  uint32_t l = 0;
+  for (int32_t k = 0; k < lseq; k++) l += ((((uint32_t)q[k] + 33u) & 0xFFu) >= 128u) ? 2u : 1u;
+  len_qual[row0 + li] = l;
+}
+void launch_qual_wide_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, uint32_t* len_qual, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_qual_wide_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, len_qual);
+}
+__global__ void k_qual_wide_scatter(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                    const uint64_t* __restrict__ off64, uint8_t* __restrict__ dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = u + rows[i];
+  const uint32_t lrn = r[12], ncig = ld_u16(r + 16);
+  const int32_t lseq = ld_i32(r + 20);
+  const uint8_t* q = r + 36 + lrn + 4 * ncig + (lseq + 1) / 2;
+  uint8_t* d = dst + off64[i];
+  for (int32_t k = 0; k < lseq; k++) {
+    uint32_t c = ((uint32_t)q[k] + 33u) & 0xFFu;
+    if (c < 128u) *d++ = (uint8_t)c;
+    else { *d++ = (uint8_t)(0xC0u | (c >> 6)); *d++ = (uint8_t)(0x80u | (c & 0x3Fu)); }
+  }
+}
+void launch_qual_wide_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_qual_wide_scatter, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, n, off64, dst);
+}
+
+// =================================================================================================
+// K8: tags.  One record per lane walks the aux fields once and records where each requested tag's
+// value lives; typed column kernels then read straight from those locations.
+// =================================================================================================
+__device__ __forceinline__ uint32_t aux_elem_size(uint8_t t) {
+  switch (t) {
+    case 'c': case 'C': case 'A': return 1;
+    case 's': case 'S': return 2;
+    case 'i': case 'I': case 'f': return 4;
+    default: return 0;
+  }
+}
+
+__global__ void k_tag_locate(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                             const uint16_t* __restrict__ tags, int32_t n_tags, uint32_t* __restrict__ loc,
+                             uint8_t* __restrict__ typ, uint32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = u + rows[i];
+  const uint32_t bs = ld_u32(r);
+  const uint32_t lrn = r[12], ncig = ld_u16(r + 16);
+  const int32_t lseq = ld_i32(r + 20);
+  uint32_t o = 36 + lrn + 4 * ncig + (uint32_t)((lseq + 1) / 2) + (uint32_t)lseq;
+  const uint32_t end = 4 + bs;
+  for (int t = 0; t < n_tags; t++) typ[(uint64_t)t * n + i] = 0;
+  while (o + 3 <= end) {
+    const uint32_t tag = ld_u16(r + o);
+    const uint8_t ty = r[o + 2];
+    const uint32_t vo = o + 3;
+    uint32_t sz;
+    if (ty == 'Z' || ty == 'H') {
+      uint32_t k = vo;
+      while (k < end && r[k] != 0) k++;
+      if (k >= end) { atomicExch(err, 4u); return; }
+      sz = k - vo + 1;
+    } else if (ty == 'B') {
+      if (vo + 5 > end) { atomicExch(err, 4u); return; }
+      uint32_t es = aux_elem_size(r[vo]);
+      uint32_t cnt = ld_u32(r + vo + 1);
+      if (es == 0 || r[vo] == 'A') { atomicExch(err, 4u); return; }
+      sz = 5 + es * cnt;
+    } else {
+      sz = aux_elem_size(ty);
+      if (sz == 0) { atomicExch(err, 4u); return; }
+    }
+    if (vo + sz > end) { atomicExch(err, 4u); return; }
+    for (int t = 0; t < n_tags; t++) {
+      if (tags[t] == tag) {
+        const uint64_t x = (uint64_t)t * n + i;
+        if (typ[x] != 0) atomicExch(err, 5u);  // duplicate tag: the reference appends twice (row misalignment)
+        loc[x] = vo;
+        typ[x] = ty;
+      }
+    }
+    o = vo + sz;
+  }
+}
+void launch_tag_locate(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint16_t* tags_dev, int32_t n_tags, uint32_t* loc,
+                       uint8_t* typ, uint32_t* err, hipStream_t st) {
+  if (!n || !n_tags) return;
+  hipLaunchKernelGGL(k_tag_locate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, n, tags_dev, n_tags, loc, typ, err);
+}
+
+// integer value of an aux scalar as i64 (c,C,s,S,i,I,A)
+__device__ __forceinline__ int64_t aux_int(const uint8_t* p, uint8_t ty) {
+  switch (ty) {
+    case 'c': return (int8_t)p[0];
+    case 'C': case 'A': return p[0];
+    case 's': return (int16_t)ld_u16(p);
+    case 'S': return ld_u16(p);
+    case 'i': return ld_i32(p);
+    default: return (int64_t)ld_u32(p);  // 'I'
+  }
+}
+
+// sam_tag_io.rs:658-742: Int32 / UInt32 / Float32 builders
+__global__ void k_tag_fixed(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
+                            const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ, int32_t kind,
+                            uint32_t* __restrict__ values, uint64_t* __restrict__ valid, uint32_t* err) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = li < n;
+  const uint64_t i = row0 + li;
+  bool v = false;
+  uint32_t out = 0;
+  if (act) {
+    const uint8_t ty = typ[li];
+    if (ty) {
+      const uint8_t* p = u + rows[li] + loc[li];
+      if (ty == 'f') {
+        if (kind == TAG_FLOAT32) { out = ld_u32(p); v = true; }
+        else atomicExch(err, 6u);  // append_float on an integer builder: type mismatch
+      } else if (ty == 'Z' || ty == 'H' || ty == 'B') {
+        atomicExch(err, 6u);
+      } else {
+        const int64_t x = aux_int(p, ty);
+        if (kind == TAG_UINT32) {
+          if (x < 0 || x > 0xFFFFFFFFll) atomicExch(err, 7u); else { out = (uint32_t)x; v = true; }
+        } else if (kind == TAG_INT32) {
+          if (x < -2147483648ll || x > 2147483647ll) atomicExch(err, 7u); else { out = (uint32_t)(int32_t)x; v = true; }
+        } else {
+          atomicExch(err, 6u);  // integer into a Float32 builder
+        }
+      }
+    }
+    values[i] = out;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && act) valid[i >> 6] = m;
+}
+void launch_tag_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                      int32_t kind, uint32_t* values, uint64_t* valid, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_tag_fixed, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, loc, typ, kind, values, valid, err);
+}
+
+// UTF-8 helpers
+__device__ __forceinline__ uint32_t utf8_len_cp(uint32_t cp) { return cp < 0x80 ? 1 : cp < 0x800 ? 2 : cp < 0x10000 ? 3 : 4; }
+__device__ __forceinline__ uint32_t utf8_write_cp(uint8_t* d, uint32_t cp) {
+  if (cp < 0x80) { d[0] = (uint8_t)cp; return 1; }
+  if (cp < 0x800) { d[0] = (uint8_t)(0xC0 | (cp >> 6)); d[1] = (uint8_t)(0x80 | (cp & 0x3F)); return 2; }
+  if (cp < 0x10000) { d[0] = (uint8_t)(0xE0 | (cp >> 12)); d[1] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F)); d[2] = (uint8_t)(0x80 | (cp & 0x3F)); return 3; }
+  d[0] = (uint8_t)(0xF0 | (cp >> 18)); d[1] = (uint8_t)(0x80 | ((cp >> 12) & 0x3F)); d[2] = (uint8_t)(0x80 | ((cp >> 6) & 0x3F)); d[3] = (uint8_t)(0x80 | (cp & 0x3F));
+  return 4;
+}
+__device__ bool utf8_valid(const uint8_t* s, uint32_t n) {
+  uint32_t i = 0;
+  while (i < n) {
+    uint8_t c = s[i];
+    if (c < 0x80) { i++; continue; }
+    uint32_t need; uint32_t cp;
+    if ((c & 0xE0) == 0xC0) { need = 1; cp = c & 0x1F; if (cp < 2) return false; }
+    else if ((c & 0xF0) == 0xE0) { need = 2; cp = c & 0x0F; }
+    else if ((c & 0xF8) == 0xF0) { need = 3; cp = c & 0x07; if (cp > 4) return false; }
+    else return false;
+    if (i + need >= n) return false;
+    for (uint32_t k = 1; k <= need; k++) {
+      uint8_t d = s[i + k];
+      if ((d & 0xC0) != 0x80) return false;
+      cp = (cp << 6) | (d & 0x3F);
+    }
+    if (need == 2 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) return false;
+    if (need == 3 && (cp < 0x10000 || cp > 0x10FFFF)) return false;
+    i += need + 1;
+  }
+  return true;
+}
+__device__ __forceinline__ bool valid_scalar_cp(int64_t x) { return x >= 0 && x <= 0x10FFFF && !(x >= 0xD800 && x <= 0xDFFF); }
+__device__ __forceinline__ uint32_t dec_len_i64(int64_t x) {
+  uint32_t l = 0;
+  uint64_t a;
+  if (x < 0) { l = 1; a = (uint64_t)(-(x + 1)) + 1; } else a = (uint64_t)x;
+  do { l++; a /= 10; } while (a);
+  return l;
+}
+__device__ __forceinline__ uint32_t dec_write_i64(uint8_t* d, int64_t x) {
+  uint32_t l = dec_len_i64(x);
+  uint64_t a;
+  if (x < 0) { d[0] = '-'; a = (uint64_t)(-(x + 1)) + 1; } else a = (uint64_t)x;
+  for (int k = (int)l - 1; k >= (x < 0 ? 1 : 0); k--) { d[k] = (uint8_t)('0' + a % 10); a /= 10; }
+  return l;
+}
+
+// Utf8 tag builder (sam_tag_io.rs:658-732): Z/H -> string (invalid UTF-8 -> NULL), A -> 1 char,
+// ints -> the Unicode char of that code point if valid else decimal; f -> not supported on device yet.
+__global__ void k_tag_utf8_len(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
+                               const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ, uint32_t* __restrict__ len,
+                               uint64_t* __restrict__ valid, uint32_t* err) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = li < n;
+  const uint64_t i = row0 + li;
+  bool v = false;
+  uint32_t l = 0;
+  if (act) {
+    const uint8_t ty = typ[li];
+    if (ty) {
+      const uint8_t* p = u + rows[li] + loc[li];
+      if (ty == 'Z' || ty == 'H') {
+        uint32_t k = 0;
+        while (p[k]) k++;
+        if (utf8_valid(p, k)) { v = true; l = k; }
+      } else if (ty == 'A') {
+        v = true; l = utf8_len_cp(p[0]);
+      } else if (ty == 'f') {
+        atomicExch(err, 8u);  // Rust f32::to_string on device: not implemented
+      } else if (ty == 'B') {
+        atomicExch(err, 6u);
+      } else {
+        const int64_t x = aux_int(p, ty);
+        v = true;
+        l = valid_scalar_cp(x) ? utf8_len_cp((uint32_t)x) : dec_len_i64(x);
+      }
+    }
+    len[i] = l;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && act) valid[i >> 6] = m;
+}
+void launch_tag_utf8_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                         uint32_t* len, uint64_t* valid, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_tag_utf8_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, loc, typ, len, valid, err);
+}
+__global__ void k_tag_utf8_scatter(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                   const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ,
+                                   const uint64_t* __restrict__ off64, const uint64_t* __restrict__ valid, uint64_t row0,
+                                   uint8_t* __restrict__ dst) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  const uint64_t i = row0 + li;
+  if (!((valid[i >> 6] >> (i & 63)) & 1ull)) return;
+  const uint8_t ty = typ[li];
+  const uint8_t* p = u + rows[li] + loc[li];
+  uint8_t* d = dst + off64[i];
+  if (ty == 'Z' || ty == 'H') {
+    for (uint32_t k = 0; p[k]; k++) d[k] = p[k];
+  } else if (ty == 'A') {
+    utf8_write_cp(d, p[0]);
+  } else {
+    const int64_t x = aux_int(p, ty);
+    if (valid_scalar_cp(x)) utf8_write_cp(d, (uint32_t)x); else dec_write_i64(d, x);
+  }
+}
+void launch_tag_utf8_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                             const uint64_t* off64, const uint64_t* valid, uint64_t row0, uint8_t* dst, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_tag_utf8_scatter, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, n, loc, typ, off64, valid, row0, dst);
+}
+
+// List<T> tag builder (sam_tag_io.rs:761-1036): range-checked element casts, float <-> int mismatch is an error
+__device__ __forceinline__ uint32_t list_elem_bytes(int32_t elem) { return elem < 2 ? 1u : elem < 4 ? 2u : 4u; }
+__global__ void k_tag_list_len(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
+                               const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ, int32_t elem,
+                               uint32_t* __restrict__ len, uint64_t* __restrict__ valid, uint32_t* err) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = li < n;
+  const uint64_t i = row0 + li;
+  bool v = false;
+  uint32_t l = 0;
+  if (act) {
+    const uint8_t ty = typ[li];
+    if (ty) {
+      if (ty != 'B') atomicExch(err, 6u);
+      else {
+        const uint8_t* p = u + rows[li] + loc[li];
+        const uint8_t st = p[0];
+        if ((st == 'f') != (elem == 6)) atomicExch(err, 6u);
+        else { v = true; l = ld_u32(p + 1); }
+      }
+    }
+    len[i] = l;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && act) valid[i >> 6] = m;
+}
+void launch_tag_list_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint32_t* loc, const uint8_t* typ,
+                         int32_t elem, uint32_t* len, uint64_t* valid, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_tag_list_len, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, loc, typ, elem, len, valid, err);
+}
+__global__ void k_tag_list_scatter(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                   const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ, int32_t elem,
+                                   const uint64_t* __restrict__ off64, uint8_t* __restrict__ dst, uint32_t* err) {
+  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= n) return;
+  if (typ[li] != 'B') return;
+  const uint8_t* p = u + rows[li] + loc[li];
+  const uint8_t st = p[0];
+  const uint32_t cnt = ld_u32(p + 1);
+  const uint8_t* src = p + 5;
+  const uint32_t es = aux_elem_size(st), ob = list_elem_bytes(elem);
+  uint8_t* d = dst + off64[li] * ob;  // off64 here is indexed by local row (caller passes the partition-local scan)
+  static const int64_t lo[6] = {-128, 0, -32768, 0, -2147483648ll, 0};
+  static const int64_t hi[6] = {127, 255, 32767, 65535, 2147483647ll, 4294967295ll};
+  for (uint32_t k = 0; k < cnt; k++) {
+    if (elem == 6) {
+      uint32_t w = ld_u32(src + 4 * k);
+      d[4 * k] = (uint8_t)w; d[4 * k + 1] = (uint8_t)(w >> 8); d[4 * k + 2] = (uint8_t)(w >> 16); d[4 * k + 3] = (uint8_t)(w >> 24);
+    } else {
+      int64_t x = aux_int(src + es * k, st);
+      if (x < lo[elem] || x > hi[elem]) { atomicExch(err, 7u); x = 0; }
+      uint64_t w = (uint64_t)x;
+      for (uint32_t q = 0; q < ob; q++) d[ob * k + q] = (uint8_t)(w >> (8 * q));
+    }
+  }
+}
+void launch_tag_list_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint32_t* loc, const uint8_t* typ, int32_t elem,
+                             const uint64_t* off64, uint8_t* dst, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_tag_list_scatter, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, n, loc, typ, elem, off64, dst, err);
+}
+
+}  // namespace bioscan

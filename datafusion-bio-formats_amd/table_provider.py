@@ -1,0 +1,282 @@
+"""ctypes binding of include/bioscan.h + the BamTableProvider / BamExec mirror."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterator, Optional, Sequence
+
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbioscan.so")
+_lib = None
+
+
+class BioscanError(RuntimeError):
+    """DataFusionError::Execution analogue."""
+
+
+class _ArrowSchema(C.Structure):
+    _fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64),
+                ("n_children", C.c_int64), ("children", C.c_void_p), ("dictionary", C.c_void_p),
+                ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _ArrowArray(C.Structure):
+    _fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                ("n_children", C.c_int64), ("buffers", C.c_void_p), ("children", C.c_void_p),
+                ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _Options(C.Structure):
+    _fields_ = [("coordinate_system_zero_based", C.c_int32), ("tag_fields", C.POINTER(C.c_char_p)),
+                ("n_tag_fields", C.c_int32), ("binary_cigar", C.c_int32), ("infer_tag_types", C.c_int32),
+                ("infer_tag_sample_size", C.c_int32), ("tag_type_hints", C.POINTER(C.c_char_p)),
+                ("n_tag_type_hints", C.c_int32), ("index_path", C.c_char_p), ("device_id", C.c_int32)]
+
+
+class _Literal(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("i", C.c_int64), ("f", C.c_double), ("s", C.c_char_p)]
+
+
+class _Filter(C.Structure):
+    _fields_ = [("column", C.c_char_p), ("op", C.c_int32), ("values", C.POINTER(_Literal)), ("n_values", C.c_int32)]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64),
+                ("arrow_bytes", C.c_uint64), ("n_records", C.c_uint64), ("n_rows", C.c_uint64),
+                ("ms_h2d", C.c_double), ("ms_frame", C.c_double), ("ms_inflate", C.c_double), ("ms_chain", C.c_double),
+                ("ms_extract", C.c_double), ("ms_total_gpu", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/bioscan.h declares (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = [
+    "bioscan_bam_options_default", "bioscan_bam_open", "bioscan_schema", "bioscan_supports_filters_pushdown",
+    "bioscan_scan", "bioscan_plan_num_partitions", "bioscan_plan_schema", "bioscan_plan_display",
+    "bioscan_plan_partition_desc", "bioscan_execute", "bioscan_next", "bioscan_stream_close", "bioscan_plan_close",
+    "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
+    "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
+]
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise BioscanError(f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    lib.bioscan_last_error.restype = C.c_char_p
+    lib.bioscan_bam_open.argtypes = [C.c_char_p, C.POINTER(_Options), C.POINTER(C.c_void_p)]
+    lib.bioscan_schema.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bioscan_supports_filters_pushdown.argtypes = [C.c_void_p, C.POINTER(_Filter), C.c_int32, C.POINTER(C.c_int32)]
+    lib.bioscan_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_Filter), C.c_int32, C.c_int64,
+                                 C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_plan_num_partitions.argtypes = [C.c_void_p]
+    lib.bioscan_plan_schema.argtypes = [C.c_void_p, C.c_void_p]
+    lib.bioscan_plan_display.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.bioscan_plan_partition_desc.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32]
+    lib.bioscan_execute.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_execute_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ScanStats), C.POINTER(C.c_void_p)]
+    lib.bioscan_next.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    lib.bioscan_stream_close.argtypes = [C.c_void_p]
+    lib.bioscan_plan_close.argtypes = [C.c_void_p]
+    lib.bioscan_provider_close.argtypes = [C.c_void_p]
+    lib.bioscan_provider_make_resident.argtypes = [C.c_void_p]
+    lib.bioscan_bgzf_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
+    lib.bioscan_free.argtypes = [C.c_void_p]
+    lib.bioscan_device_check.argtypes = [C.c_int32, C.c_char_p, C.c_int32]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise BioscanError(load_library().bioscan_last_error().decode("utf-8", "replace"))
+
+
+def device_check(device_id: int = 0) -> str:
+    lib = load_library()
+    buf = C.create_string_buffer(256)
+    _check(lib.bioscan_device_check(device_id, buf, 256))
+    return buf.value.decode()
+
+
+def bgzf_inflate(data: bytes, device_id: int = 0, check_crc: bool = True):
+    """K1 alone: inflate every BGZF member of `data` on the GPU -> (bytes, kernel_ms)."""
+    lib = load_library()
+    out = C.c_void_p()
+    n = C.c_size_t()
+    ms = C.c_double()
+    _check(lib.bioscan_bgzf_inflate(data, len(data), device_id, 1 if check_crc else 0, C.byref(out), C.byref(n), C.byref(ms)))
+    try:
+        return C.string_at(out, n.value), ms.value
+    finally:
+        lib.bioscan_free(out)
+
+
+_OPS = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "between": 6, "not between": 7, "in": 8, "not in": 9}
+
+
+def _make_filters(filters):
+    """(col, op, value) tuples -> C array (keeps python objects alive in the returned holder)."""
+    keep = []
+    arr = (_Filter * max(len(filters), 1))()
+    for k, (col, op, val) in enumerate(filters):
+        vals = [val] if op in ("=", "!=", "<", "<=", ">", ">=") else list(val)
+        lits = (_Literal * max(len(vals), 1))()
+        for j, v in enumerate(vals):
+            if v is None:
+                lits[j].kind = 0
+            elif isinstance(v, bool):
+                raise TypeError("bool literal")
+            elif isinstance(v, int):
+                lits[j].kind, lits[j].i = 1, v
+            elif isinstance(v, float):
+                lits[j].kind, lits[j].f = 2, v
+            else:
+                b = str(v).encode()
+                keep.append(b)
+                lits[j].kind, lits[j].s = 3, b
+        cb = col.encode()
+        keep += [cb, lits]
+        arr[k].column, arr[k].op, arr[k].values, arr[k].n_values = cb, _OPS[op], lits, len(vals)
+    return arr, keep
+
+
+class BamTableProvider:
+    """Mirror of BamTableProvider::new (bio-format-bam/src/table_provider.rs:381-390): same
+    positional arguments (object_storage_options accepted and ignored: local files only)."""
+
+    def __init__(self, file_path: str, object_storage_options=None, coordinate_system_zero_based: bool = True,
+                 tag_fields: Optional[Sequence[str]] = None, binary_cigar: bool = False, infer_tag_types: bool = True,
+                 infer_tag_sample_size: int = 100, tag_type_hints: Optional[Sequence[str]] = None,
+                 device_id: int = 0, index_path: Optional[str] = None):
+        lib = load_library()
+        o = _Options()
+        lib.bioscan_bam_options_default(C.byref(o))
+        o.coordinate_system_zero_based = 1 if coordinate_system_zero_based else 0
+        self._keep = []
+        if tag_fields is not None:
+            tf = (C.c_char_p * max(len(tag_fields), 1))(*[t.encode() for t in tag_fields])
+            o.tag_fields, o.n_tag_fields = tf, len(tag_fields)
+            self._keep.append(tf)
+        o.binary_cigar = 1 if binary_cigar else 0
+        o.infer_tag_types = 1 if infer_tag_types else 0
+        o.infer_tag_sample_size = infer_tag_sample_size
+        if tag_type_hints:
+            th = (C.c_char_p * len(tag_type_hints))(*[t.encode() for t in tag_type_hints])
+            o.tag_type_hints, o.n_tag_type_hints = th, len(tag_type_hints)
+            self._keep.append(th)
+        if index_path is not None:
+            o.index_path = index_path.encode()
+        o.device_id = device_id
+        self._h = C.c_void_p()
+        _check(lib.bioscan_bam_open(file_path.encode(), C.byref(o), C.byref(self._h)))
+        self.file_path = file_path
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            load_library().bioscan_provider_close(h)
+            self._h = None
+
+    def schema(self) -> pa.Schema:
+        s = _ArrowSchema()
+        _check(load_library().bioscan_schema(self._h, C.addressof(s)))
+        return pa.Schema._import_from_c(C.addressof(s))
+
+    def supports_filters_pushdown(self, filters):
+        arr, keep = _make_filters(list(filters))
+        out = (C.c_int32 * max(len(filters), 1))()
+        _check(load_library().bioscan_supports_filters_pushdown(self._h, arr, len(filters), out))
+        return ["Inexact" if out[i] else "Unsupported" for i in range(len(filters))]
+
+    def make_resident(self):
+        _check(load_library().bioscan_provider_make_resident(self._h))
+
+    def scan(self, projection: Optional[Sequence[int]] = None, filters=(), limit: Optional[int] = None,
+             target_partitions: int = 1) -> "BamExec":
+        filters = list(filters)
+        arr, keep = _make_filters(filters)
+        if projection is None:
+            proj, nproj = None, 0
+        else:
+            proj = (C.c_int32 * max(len(projection), 1))(*projection)
+            nproj = len(projection)
+        plan = C.c_void_p()
+        _check(load_library().bioscan_scan(self._h, proj, nproj, arr, len(filters), -1 if limit is None else limit,
+                                           target_partitions, C.byref(plan)))
+        return BamExec(self, plan)
+
+
+class BamExec:
+    """Mirror of BamExec (bio-format-bam/src/physical_exec.rs:39-173)."""
+
+    def __init__(self, provider: BamTableProvider, handle):
+        self._provider = provider  # keeps the provider alive
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            load_library().bioscan_plan_close(h)
+            self._h = None
+
+    def name(self) -> str:
+        return "BamExec"
+
+    def num_partitions(self) -> int:
+        return load_library().bioscan_plan_num_partitions(self._h)
+
+    def schema(self) -> pa.Schema:
+        s = _ArrowSchema()
+        _check(load_library().bioscan_plan_schema(self._h, C.addressof(s)))
+        return pa.Schema._import_from_c(C.addressof(s))
+
+    def display(self) -> str:
+        buf = C.create_string_buffer(4096)
+        load_library().bioscan_plan_display(self._h, buf, 4096)
+        return buf.value.decode()
+
+    def partition_desc(self, partition: int) -> str:
+        buf = C.create_string_buffer(1 << 16)
+        load_library().bioscan_plan_partition_desc(self._h, partition, buf, 1 << 16)
+        return buf.value.decode()
+
+    def execute(self, partition: int, batch_size: int = 8192) -> Iterator[pa.RecordBatch]:
+        lib = load_library()
+        st = C.c_void_p()
+        _check(lib.bioscan_execute(self._h, partition, batch_size, C.byref(st)))
+        schema = self.schema()
+        try:
+            while True:
+                arr = _ArrowArray()
+                has = C.c_int32()
+                _check(lib.bioscan_next(st, C.addressof(arr), C.byref(has)))
+                if not has.value:
+                    break
+                sch = _ArrowSchema()
+                _check(lib.bioscan_plan_schema(self._h, C.addressof(sch)))
+                if len(schema) == 0:
+                    sa = pa.Array._import_from_c(C.addressof(arr), C.addressof(sch))
+                    yield pa.RecordBatch.from_struct_array(sa).replace_schema_metadata(schema.metadata)
+                else:
+                    yield pa.RecordBatch._import_from_c(C.addressof(arr), C.addressof(sch))
+        finally:
+            lib.bioscan_stream_close(st)
+
+    def execute_device(self, partition: int, batch_size: int = 8192) -> dict:
+        """Runs the whole partition on the GPU, leaves the Arrow buffers in HBM, returns stats."""
+        lib = load_library()
+        st = C.c_void_p()
+        stats = ScanStats()
+        _check(lib.bioscan_execute_device(self._h, partition, batch_size, C.byref(stats), C.byref(st)))
+        lib.bioscan_stream_close(st)
+        return stats.as_dict()

@@ -1,0 +1,160 @@
+/* bioscan.h -- C ABI of the MI355X-native BGZF -> Arrow scan engine (libbioscan.so).
+ *
+ * This is the drop-in boundary for ONE path of biodatageeks/datafusion-bio-formats: the
+ * partitioned DataFusion TableProvider / ExecutionPlan scan of BGZF files.  Every entry
+ * point names the reference interface it replaces (paths relative to
+ * /root/reference/datafusion).  Plain pointers and sizes only; results cross the boundary
+ * through the Arrow C Data Interface (struct ArrowSchema / struct ArrowArray), which is
+ * what `arrow::ffi` (Rust), pyarrow and every other Arrow binding import zero-copy.
+ *
+ * Threading contract (mirrors bio-format-core/src/sync_stream.rs:7-33): distinct streams
+ * may be driven from distinct threads; one stream is used by one thread at a time.
+ * All functions return 0 on success; on failure they return non-zero and
+ * bioscan_last_error() (thread-local) describes the failure -- the analogue of the
+ * reference yielding DataFusionError::Execution(..) as a stream item
+ * (bio-format-bam/src/physical_exec.rs:567-571).
+ */
+#ifndef BIOSCAN_H
+#define BIOSCAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct ArrowSchema; /* Arrow C Data Interface (arrow.apache.org/docs/format/CDataInterface.html) */
+struct ArrowArray;
+
+typedef struct bioscan_provider bioscan_provider; /* BamTableProvider            */
+typedef struct bioscan_plan bioscan_plan;         /* BamExec (an ExecutionPlan)  */
+typedef struct bioscan_stream bioscan_stream;     /* SendableRecordBatchStream   */
+
+/* ---- BamTableProvider::new (bio-format-bam/src/table_provider.rs:381-529) ------------
+ * Same knobs as the reference constructor's positional arguments; object-storage options
+ * are out of scope (local files only).  `index_path` NULL = auto-discover `<path>.bai` /
+ * `<stem>.bai` (bio-format-core/src/index_utils.rs:68-83); "" = force no index. */
+typedef struct bioscan_bam_options {
+  int32_t coordinate_system_zero_based; /* default 1 */
+  const char* const* tag_fields;        /* NULL = no tag columns */
+  int32_t n_tag_fields;
+  int32_t binary_cigar;                 /* 0 = Utf8 cigar */
+  int32_t infer_tag_types;              /* sample the file for tags outside the SAM registry */
+  int32_t infer_tag_sample_size;        /* reference default 100 */
+  const char* const* tag_type_hints;    /* "XY:i", "pa:B:f" ...; NULL = none */
+  int32_t n_tag_type_hints;
+  const char* index_path;
+  int32_t device_id;                    /* HIP device ordinal this provider's scans run on */
+} bioscan_bam_options;
+
+void bioscan_bam_options_default(bioscan_bam_options* o);
+
+int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_provider** out);
+
+/* TableProvider::schema (table_provider.rs:933-935); caller releases the ArrowSchema. */
+int bioscan_schema(const bioscan_provider* p, struct ArrowSchema* out);
+
+/* ---- filters handed to TableProvider::scan ---------------------------------------------
+ * One entry per conjunct of the WHERE clause, restricted to the shapes the reference can
+ * push down (bio-format-core/src/genomic_filter.rs:143-331, record_filter.rs:40-356):
+ * column <op> literal, column [NOT] BETWEEN lo AND hi, column [NOT] IN (...). */
+enum bioscan_filter_op {
+  BIOSCAN_OP_EQ = 0, BIOSCAN_OP_NE, BIOSCAN_OP_LT, BIOSCAN_OP_LE, BIOSCAN_OP_GT, BIOSCAN_OP_GE,
+  BIOSCAN_OP_BETWEEN, BIOSCAN_OP_NOT_BETWEEN, BIOSCAN_OP_IN, BIOSCAN_OP_NOT_IN
+};
+enum bioscan_literal_kind { BIOSCAN_LIT_NULL = 0, BIOSCAN_LIT_INT, BIOSCAN_LIT_FLOAT, BIOSCAN_LIT_STR };
+typedef struct bioscan_literal {
+  int32_t kind;
+  int64_t i;
+  double f;
+  const char* s;
+} bioscan_literal;
+typedef struct bioscan_filter {
+  const char* column;
+  int32_t op;
+  const bioscan_literal* values; /* 1 (comparison), 2 (between) or n (in-list) literals */
+  int32_t n_values;
+} bioscan_filter;
+
+/* TableProvider::supports_filters_pushdown (table_provider.rs:941-962):
+ * out[i] = 0 Unsupported, 1 Inexact. */
+int bioscan_supports_filters_pushdown(const bioscan_provider* p, const bioscan_filter* filters,
+                                      int32_t n_filters, int32_t* out);
+
+/* ---- TableProvider::scan (table_provider.rs:964-1115) -----------------------------------
+ * projection NULL = all columns; n_projection 0 with non-NULL pointer = empty projection
+ * (COUNT(*) batches).  `limit` < 0 = none (stored, never applied, like BamExec.limit).
+ * `target_partitions` = SessionConfig::target_partitions.  The plan may have zero
+ * partitions (EmptyExec: unsatisfiable genomic bounds). */
+int bioscan_scan(const bioscan_provider* p, const int32_t* projection, int32_t n_projection,
+                 const bioscan_filter* filters, int32_t n_filters, int64_t limit,
+                 int32_t target_partitions, bioscan_plan** out);
+
+/* ExecutionPlan::properties().partitioning (UnknownPartitioning(n)) */
+int32_t bioscan_plan_num_partitions(const bioscan_plan* plan);
+/* projected schema of the plan (incl. metadata) */
+int bioscan_plan_schema(const bioscan_plan* plan, struct ArrowSchema* out);
+/* DisplayAs: "BamExec: projection=[...]" (physical_exec.rs:66-82); returns bytes written */
+int32_t bioscan_plan_display(const bioscan_plan* plan, char* buf, int32_t cap);
+/* Human-readable partition assignment (regions of PartitionAssignment, for tests/diagnostics):
+ * "chrom:start-end[;...]" with '*' markers for unmapped tails. */
+int32_t bioscan_plan_partition_desc(const bioscan_plan* plan, int32_t partition, char* buf, int32_t cap);
+
+/* ---- ExecutionPlan::execute(partition, ctx) (physical_exec.rs:108-172) -----------------
+ * batch_size = ctx.session_config().batch_size() (reference default 8192). */
+int bioscan_execute(const bioscan_plan* plan, int32_t partition, int32_t batch_size, bioscan_stream** out);
+
+/* Stream::poll_next: *has_batch = 0 at end of stream.  The exported array is a struct
+ * array of the projected columns with `length` rows; its release callback frees the host
+ * staging memory.  Zero-column plans export a zero-child struct whose length is the row
+ * count (bio-format-core/src/alignment_utils.rs:360-363). */
+int bioscan_next(bioscan_stream* s, struct ArrowArray* out, int32_t* has_batch);
+
+void bioscan_stream_close(bioscan_stream* s);
+void bioscan_plan_close(bioscan_plan* plan);
+void bioscan_provider_close(bioscan_provider* p);
+
+const char* bioscan_last_error(void);
+
+/* ---- Device-resident entry points (measurement / embedding in a GPU pipeline) -----------
+ * Runs the whole partition on the GPU and leaves the Arrow column buffers in HBM, without
+ * the D2H export that bioscan_next performs.  `stats` (may be NULL) receives per-stage GPU
+ * times measured with HIP events on the stream the kernels ran on. */
+typedef struct bioscan_scan_stats {
+  uint64_t n_blocks;          /* BGZF blocks inflated */
+  uint64_t compressed_bytes;  /* C: bytes of those blocks */
+  uint64_t inflated_bytes;    /* U */
+  uint64_t arrow_bytes;       /* A: bytes of Arrow buffers produced (values+offsets+validity) */
+  uint64_t n_records;         /* records walked */
+  uint64_t n_rows;            /* rows emitted (after region / residual filters) */
+  double ms_h2d;              /* host -> device copy of the compressed bytes (0 if resident) */
+  double ms_frame;            /* BGZF framing */
+  double ms_inflate;          /* K1 bgzf_inflate */
+  double ms_chain;            /* record boundary scan */
+  double ms_extract;          /* field extract + Arrow scatter */
+  double ms_total_gpu;        /* first kernel start -> last kernel end */
+} bioscan_scan_stats;
+
+/* Make the file's compressed bytes resident in HBM (idempotent); later executes reuse them. */
+int bioscan_provider_make_resident(bioscan_provider* p);
+/* Execute a partition entirely on the device; columns stay in HBM until the stream is closed
+ * or drained with bioscan_next. */
+int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t batch_size,
+                           bioscan_scan_stats* stats, bioscan_stream** out);
+
+/* ---- Kernel-level entry point: K1 alone (parity tests against libdeflate/zlib) ----------
+ * Inflates every BGZF member of a host buffer on the GPU and returns the concatenated
+ * payload in a malloc'd host buffer (caller frees with bioscan_free).
+ * Replaces noodles-bgzf Reader::read_block + libdeflate (bio-format-bam/src/storage.rs:161-169). */
+int bioscan_bgzf_inflate(const uint8_t* data, size_t len, int32_t device_id, int32_t check_crc,
+                         uint8_t** out, size_t* out_len, double* kernel_ms);
+void bioscan_free(void* p);
+
+/* Library / device probe: returns 0 when a gfx950-capable HIP device is usable. */
+int bioscan_device_check(int32_t device_id, char* name_buf, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOSCAN_H */

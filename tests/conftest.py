@@ -1,0 +1,50 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG_DIR = os.path.join(ROOT, "datafusion-bio-formats_amd")
+
+
+def load_pkg():
+    """The package directory name has a hyphen (it mirrors the upstream repo name), so it is
+    loaded by path under the importable alias `datafusion_bio_formats_amd`."""
+    name = "datafusion_bio_formats_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(PKG_DIR, "__init__.py"),
+                                                  submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_oracle():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import bam_oracle
+    return bam_oracle
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return load_pkg()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return GOLDEN
