@@ -1,0 +1,69 @@
+"""ctypes wrapper of oracle/bioscan_oracle.c (TEST INFRASTRUCTURE ONLY -- see that file's header)."""
+import ctypes as C
+import os
+
+import pyarrow as pa
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+class _Col(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offsets", C.c_void_p), ("valid", C.c_void_p), ("data_len", C.c_uint64)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64),
+                ("inflated_bytes", C.c_uint64), ("cols", _Col * 20), ("n_cols", C.c_int),
+                ("seconds_inflate", C.c_double), ("seconds_chain", C.c_double), ("seconds_columns", C.c_double),
+                ("seconds_total", C.c_double), ("threads", C.c_int), ("used_libdeflate", C.c_int), ("error", C.c_char * 256)]
+
+
+_lib = None
+CORE = [("name", "s", False), ("chrom", "s", True), ("start", "u", True), ("end", "u", True), ("flags", "u", False),
+        ("cigar", "s", False), ("mapping_quality", "u", False), ("mate_chrom", "s", True), ("mate_start", "u", True),
+        ("sequence", "s", False), ("quality_scores", "s", False), ("template_length", "i", False)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            import subprocess
+            subprocess.check_call(["make", "-C", _HERE])
+        _lib = C.CDLL(_LIB)
+        _lib.oracle_bam_scan_mem.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_char_p,
+                                             C.POINTER(C.c_int), C.c_int, C.POINTER(_Result)]
+        _lib.oracle_free.argtypes = [C.POINTER(_Result)]
+    return _lib
+
+
+def scan(data: bytes, zero_based=True, threads=1, max_blocks=0, tags=(), tag_kinds=(), build_columns=True, to_arrow=True):
+    """Returns (stats dict, {column name: pyarrow array with 64-bit offsets}) for a sequential full scan."""
+    res = _Result()
+    tg = "".join(tags).encode()
+    kinds = (C.c_int * max(len(tags), 1))(*[0 if k == "i" else 3 for k in tag_kinds])
+    rc = lib().oracle_bam_scan_mem(data, len(data), 1 if zero_based else 0, threads, max_blocks, len(tags), tg, kinds,
+                                   1 if build_columns else 0, C.byref(res))
+    if rc:
+        raise RuntimeError(res.error.decode())
+    stats = {k: getattr(res, k) for k in ("n_rows", "n_blocks", "compressed_bytes", "inflated_bytes", "seconds_inflate",
+                                          "seconds_chain", "seconds_columns", "seconds_total", "threads", "used_libdeflate")}
+    cols = {}
+    if build_columns and to_arrow:
+        n = res.n_rows
+        spec = CORE + [(t, "i" if k == "i" else "s", True) for t, k in zip(tags, tag_kinds)]
+        for c, (name, kind, nullable) in enumerate(spec):
+            col = res.cols[c]
+            vb = None
+            if nullable and col.valid:
+                vb = pa.py_buffer(C.string_at(col.valid, (n + 7) // 8))
+            if kind == "s":
+                ob = pa.py_buffer(C.string_at(col.offsets, (n + 1) * 8))
+                db = pa.py_buffer(C.string_at(col.data, col.data_len))
+                cols[name] = pa.Array.from_buffers(pa.large_utf8(), n, [vb, ob, db])
+            else:
+                db = pa.py_buffer(C.string_at(col.data, n * 4))
+                cols[name] = pa.Array.from_buffers(pa.uint32() if kind == "u" else pa.int32(), n, [vb, db])
+    lib().oracle_free(C.byref(res))
+    return stats, cols
