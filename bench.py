@@ -154,7 +154,9 @@ def main():
             "pipeline_algorithmic_GB_s": round((tot_c + 2 * tot_u + tot_a) / per_step / 1e9, 3),
             "pipeline_hbm_frac": round((tot_c + 2 * tot_u + tot_a) / per_step / 1e9 / (HBM_PEAK_GBS * world), 5),
             "stage_ms": {"inflate": round(avg_infl, 3), "record_chain": round(sum(chain_ms) / len(chain_ms), 3),
-                         "extract": round(sum(extract_ms) / len(extract_ms), 3)},
+                         "extract": round(sum(extract_ms) / len(extract_ms), 3), "crc32": round(stats["ms_crc"], 3),
+                         "keys": round(stats["ms_keys"], 3), "select": round(stats["ms_select"], 3),
+                         "wall_last_step": round(stats["ms_wall"], 3), "chain_iterations": stats["chain_iterations"]},
             "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": int(c + u), "avg_launch_ms": round(avg_infl, 3)},

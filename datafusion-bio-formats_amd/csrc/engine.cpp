@@ -206,7 +206,7 @@ struct Provider {
     for (uint32_t i = 0; i < nb; i++)
       if (st[i] != INF_OK)
         throw Error(std::string("BAM read error: BGZF block ") + std::to_string(b0 + i) + " at offset " +
-                    std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st[i]));
+                    std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st[i] & 0xFF) + " (code " + std::to_string(st[i]) + ")");
   }
 
   // Inflate blocks [b0, b1) into a temporary device buffer and copy to the host (header / sampling).
@@ -240,8 +240,9 @@ struct Provider {
     t.start();
     launch_bgzf_inflate(d_comp.p, d_coff.p, d_uoff.p, d_u.p, n_blocks(), d_status.p, stream);
     s.ms_inflate = t.stop();
+    t.start();
     launch_bgzf_crc32(d_comp.p, d_coff.p, d_uoff.p, d_u.p, n_blocks(), d_status.p, stream);
-    HIP_CHECK(hipStreamSynchronize(stream));
+    s.ms_crc = t.stop();
     check_inflate_status(0, n_blocks());
 
     // ---- record chain ----
@@ -257,6 +258,7 @@ struct Provider {
     launch_seg_guess(d_u.p, ulen, first_rec, nseg, (int32_t)hdr.ref_names.size(), cb, stream);
     launch_seg_walk(d_u.p, ulen, nseg, cb, 0, stream);
     for (int iter = 0;; iter++) {
+      s.chain_iterations = (uint64_t)iter + 1;
       HIP_CHECK(hipMemsetAsync(ctr.p, 0, 4, stream));
       launch_seg_verify(ulen, first_rec, nseg, cb, stream);
       uint32_t nfix = 0;
@@ -294,7 +296,9 @@ struct Provider {
       k_refid.alloc(n_rec); k_pos.alloc(n_rec); k_end1.alloc(n_rec); k_fm.alloc(n_rec);
     }
     RecKeys rk{k_refid.p, k_pos.p, k_end1.p, k_fm.p};
+    t.start();
     launch_rec_keys(d_u.p, d_rec_off.p, n_rec, rk, stream);
+    s.ms_keys = t.stop();
     if (!d_ref_name_off.p) upload_ref_names();
     s.ms_total_gpu = tt.stop();
     decode_stats = s;
@@ -558,6 +562,7 @@ static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_
 
 static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
   Provider& p = *plan.prov;
+  const auto wall0 = std::chrono::steady_clock::now();
   p.decode(force_decode);
   std::lock_guard<std::mutex> lk(p.mu);
   p.set_device();
@@ -571,6 +576,8 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
   const uint64_t* rows = nullptr;
   uint64_t n = 0;
   select_rows(plan, partition, &rows_owned, &rows, &n);
+  res->stats.ms_select = t.stop();
+  t.start();
   res->n_rows = n;
   res->stats.n_rows = n;
   const uint64_t nwords = (n + 63) / 64;
@@ -705,7 +712,8 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
   // duplicate projected columns: not supported (DataFusion never sends duplicates)
   res->stats.ms_extract = t.stop();
   res->stats.arrow_bytes = arrow_bytes;
-  res->stats.ms_total_gpu = p.decode_stats.ms_total_gpu + res->stats.ms_extract;
+  res->stats.ms_total_gpu = p.decode_stats.ms_total_gpu + res->stats.ms_select + res->stats.ms_extract;
+  res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
   if (to_host) {
     for (auto& col : res->cols) {

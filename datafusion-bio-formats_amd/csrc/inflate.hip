@@ -30,6 +30,9 @@ struct __attribute__((aligned(16))) InflateLds {
   uint8_t lens[320];                  // code lengths litlen (0..287) then dist (288..319)
   uint8_t pre_fast[128];              // sym << 3 | len (code-length code, <= 7 bits)
   uint8_t pre_lens[19];
+  uint16_t t_offs[16];                // table-build scratch: first sorted index per length
+  uint16_t t_first[16];               // first canonical code per length
+  uint16_t t_w[16];
 };
 
 struct BitIn {
@@ -96,7 +99,7 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v)
 // fast[] has 1<<fast_bits entries; sorted[] receives symbols ordered by (len, sym); count[1..15].
 // Returns 0 on success, nonzero if the code is over-subscribed.
 __device__ int build_tables(const uint8_t* lens, int n, uint16_t* fast, int fast_bits, uint16_t* sorted,
-                            uint16_t* count, int lane) {
+                            uint16_t* count, uint16_t* t_offs, uint16_t* t_first, uint16_t* t_w, int lane) {
   __syncthreads();
   for (int i = lane; i < (1 << fast_bits); i += WAVE) fast[i] = 0;
   if (lane < 16) count[lane] = 0;
@@ -104,40 +107,36 @@ __device__ int build_tables(const uint8_t* lens, int n, uint16_t* fast, int fast
   if (lane == 0) {
     for (int s = 0; s < n; s++) count[lens[s]]++;
     count[0] = 0;
-  }
-  __syncthreads();
-  // offsets and first codes (uniform, every lane computes the same 15 values)
-  uint32_t offs[16], first[16];
-  uint32_t o = 0, code = 0;
-  int over = 0;
-  int left = 1;
-  for (int l = 1; l <= 15; l++) {
-    uint32_t c = count[l];
-    code <<= 1;
-    first[l] = code;
-    offs[l] = o;
-    o += c;
-    code += c;
-    left <<= 1;
-    left -= (int)c;
-    if (left < 0) over = 1;
-  }
-  if (over) return 1;
-  if (lane == 0) {
-    uint32_t w[16];
-    for (int l = 1; l <= 15; l++) w[l] = offs[l];
+    uint32_t o = 0, code = 0;
+    int left = 1, over = 0;
+    for (int l = 1; l <= 15; l++) {
+      uint32_t c = count[l];
+      code <<= 1;
+      t_first[l] = (uint16_t)code;
+      t_offs[l] = (uint16_t)o;
+      t_w[l] = (uint16_t)o;
+      o += c;
+      code += c;
+      left <<= 1;
+      left -= (int)c;
+      if (left < 0) over = 1;
+    }
+    t_offs[0] = (uint16_t)o;   // total coded symbols
+    t_first[0] = (uint16_t)over;
     for (int s = 0; s < n; s++) {
       int l = lens[s];
-      if (l) sorted[w[l]++] = (uint16_t)s;
+      if (l) sorted[t_w[l]++] = (uint16_t)s;
     }
   }
   __syncthreads();
+  if (uni(t_first[0])) return 1;
+  const uint32_t o = uni(t_offs[0]);
   // fill the fast table: lane-parallel over sorted symbols
   for (uint32_t k = lane; k < o; k += WAVE) {
     int sym = sorted[k];
     int l = lens[sym];
     if (l <= fast_bits) {
-      uint32_t c = first[l] + (k - offs[l]);
+      uint32_t c = (uint32_t)t_first[l] + (k - t_offs[l]);
       uint32_t r = bitrev(c, l);
       uint16_t e = (uint16_t)((sym << 4) | l);
       for (uint32_t i = r; i < (1u << fast_bits); i += (1u << l)) fast[i] = e;
@@ -154,11 +153,11 @@ __device__ __forceinline__ int slow_decode(BitIn& s, const uint16_t* sorted, con
   for (int l = 1; l <= 15; l++) {
     code |= (int)(bb & 1);
     bb >>= 1;
-    int c = count[l];
+    const int c = (int)uni(count[l]);
     if (code - c < first) {
       s.bb = bb;
       s.bc -= l;
-      return sorted[index + (code - first)];
+      return (int)uni(sorted[index + (code - first)]);
     }
     index += c;
     first += c;
@@ -191,13 +190,11 @@ __device__ void resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst, ui
     if (ready) {
       uint8_t* d = out + m_dst;
       const uint8_t* s = out + src_lo;
-      if (m_dist >= 8) {
+      if (m_dist >= 4) {
         uint32_t k = 0;
-        for (; k + 8 <= m_len; k += 8) {
+        for (; k + 4 <= m_len; k += 4) {
           uint8_t b0 = s[k], b1 = s[k + 1], b2 = s[k + 2], b3 = s[k + 3];
-          uint8_t b4 = s[k + 4], b5 = s[k + 5], b6 = s[k + 6], b7 = s[k + 7];
           d[k] = b0; d[k + 1] = b1; d[k + 2] = b2; d[k + 3] = b3;
-          d[k + 4] = b4; d[k + 5] = b5; d[k + 6] = b6; d[k + 7] = b7;
         }
         for (; k < m_len; k++) d[k] = s[k];
       } else {
@@ -227,8 +224,9 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
   uint32_t st = INF_OK;
 
   // gzip member header: 1f 8b 08 04 .... XLEN ; payload starts at 12 + XLEN
-  const uint32_t xlen = (uint32_t)hdr[10] | ((uint32_t)hdr[11] << 8);
-  if (hdr[0] != 0x1f || hdr[1] != 0x8b || hdr[2] != 8 || !(hdr[3] & 4)) {
+  const uint32_t xlen = uni((uint32_t)hdr[10] | ((uint32_t)hdr[11] << 8));
+  const uint32_t magic = uni((uint32_t)hdr[0] | ((uint32_t)hdr[1] << 8) | ((uint32_t)hdr[2] << 16) | ((uint32_t)hdr[3] << 24));
+  if ((magic & 0x04FFFFFFu) != 0x04088B1Fu) {
     if (lane == 0) status[b] = INF_BAD_HEADER;
     return;
   }
@@ -254,8 +252,8 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
       bitin_take(in, in.bc & 7);  // to byte boundary
       uint64_t bytepos = bitin_bytepos(in) - base_skew;  // relative to payload
       const uint8_t* p = payload + bytepos;
-      uint32_t len = (uint32_t)p[0] | ((uint32_t)p[1] << 8);
-      uint32_t nlen = (uint32_t)p[2] | ((uint32_t)p[3] << 8);
+      uint32_t len = uni((uint32_t)p[0] | ((uint32_t)p[1] << 8));
+      uint32_t nlen = uni((uint32_t)p[2] | ((uint32_t)p[3] << 8));
       if ((len ^ 0xFFFFu) != nlen) { st = INF_BAD_STORED; break; }
       if (opos + len > isize || bytepos + 4 + len > payload_len) { st = INF_OVERRUN; break; }
       p += 4;
@@ -280,8 +278,8 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
         L.lens[i] = l;
       }
       __syncthreads();
-      build_tables(L.lens, 288, L.lit_fast, LIT_BITS, L.lit_sorted, L.lit_count, lane);
-      build_tables(L.lens + 288, 32, L.dist_fast, DIST_BITS, L.dist_sorted, L.dist_count, lane);
+      build_tables(L.lens, 288, L.lit_fast, LIT_BITS, L.lit_sorted, L.lit_count, L.t_offs, L.t_first, L.t_w, lane);
+      build_tables(L.lens + 288, 32, L.dist_fast, DIST_BITS, L.dist_sorted, L.dist_count, L.t_offs, L.t_first, L.t_w, lane);
       (void)fixed_built;
     } else {
       // dynamic Huffman code (RFC 1951 3.2.7)
@@ -289,7 +287,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
       const uint32_t hlit = bitin_take(in, 5) + 257;
       const uint32_t hdist = bitin_take(in, 5) + 1;
       const uint32_t hclen = bitin_take(in, 4) + 4;
-      if (hlit > 286 || hdist > 30) { st = INF_BAD_CODE; break; }
+      if (hlit > 286 || hdist > 30) { st = INF_BAD_CODE | (1u << 8); break; }
       if (lane < 19) L.pre_lens[lane] = 0;
       __syncthreads();
       {
@@ -352,14 +350,14 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
             i += rep;
           }
         }
-        if (bad) { st = INF_BAD_CODE; break; }
+        if (bad) { st = INF_BAD_CODE | (2u << 8); break; }
         // zero the unused tails
         for (uint32_t k = hlit + lane; k < 288; k += WAVE) L.lens[k] = 0;
         for (uint32_t k = 288 + hdist + lane; k < 320; k += WAVE) L.lens[k] = 0;
         __syncthreads();
       }
-      if (build_tables(L.lens, 288, L.lit_fast, LIT_BITS, L.lit_sorted, L.lit_count, lane)) { st = INF_BAD_CODE; break; }
-      if (build_tables(L.lens + 288, 32, L.dist_fast, DIST_BITS, L.dist_sorted, L.dist_count, lane)) { st = INF_BAD_CODE; break; }
+      if (build_tables(L.lens, 288, L.lit_fast, LIT_BITS, L.lit_sorted, L.lit_count, L.t_offs, L.t_first, L.t_w, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
+      if (build_tables(L.lens + 288, 32, L.dist_fast, DIST_BITS, L.dist_sorted, L.dist_count, L.t_offs, L.t_first, L.t_w, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
     }
 
     // ---- symbol loop ----
@@ -373,7 +371,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
         bitin_take(in, e & 15u);
       } else {
         sym = slow_decode(in, L.lit_sorted, L.lit_count);
-        if (sym < 0) { err = INF_BAD_CODE; break; }
+        if (sym < 0) { err = INF_BAD_CODE | (5u << 8); break; }
       }
       if (sym < 256) {
         if (opos >= isize) { err = INF_OVERRUN; break; }
@@ -383,7 +381,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
       }
       if (sym == 256) break;
       sym -= 257;
-      if (sym >= 29) { err = INF_BAD_CODE; break; }
+      if (sym >= 29) { err = INF_BAD_CODE | (6u << 8); break; }
       uint32_t mlen;
       if (sym < 8) mlen = 3 + sym;
       else if (sym == 28) mlen = 258;
@@ -399,9 +397,9 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
         bitin_take(in, de & 15u);
       } else {
         ds = slow_decode(in, L.dist_sorted, L.dist_count);
-        if (ds < 0) { err = INF_BAD_CODE; break; }
+        if (ds < 0) { err = INF_BAD_CODE | (7u << 8); break; }
       }
-      if (ds >= 30) { err = INF_BAD_CODE; break; }
+      if (ds >= 30) { err = INF_BAD_CODE | (8u << 8); break; }
       uint32_t dist;
       if (ds < 4) dist = 1 + ds;
       else {
@@ -426,79 +424,52 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
   if (lane == 0) status[b] = st;
 }
 
-// ---- K2: CRC32 (IEEE, reflected) of each inflated member vs trailer -----------------------------
-// One wave per member: each lane CRCs a contiguous slice, slices are combined with the
-// GF(2) "advance by n zero bytes" operator (same idea as zlib's crc32_combine).
-__device__ __forceinline__ uint32_t crc_byte(uint32_t c, uint8_t b) {
-  c ^= b;
+// ---- K2: CRC32 (IEEE 802.3, reflected) of each inflated member vs its BGZF trailer ----------------
+// noodles-bgzf verifies every block's CRC32 after inflating it; this is the same check.
+// One lane per member (64 members per wave): slice-by-4 tables live in LDS (4 KiB per
+// workgroup, built by the workgroup itself), each lane streams its member with aligned dword
+// loads.  No cross-lane combine is needed, so the kernel is a plain table-driven CRC whose
+// throughput comes from having ~650 k members in flight.
+constexpr int CRC_T = 256;
+__global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict__ comp,
+                                                       const uint64_t* __restrict__ blk_coff,
+                                                       const uint64_t* __restrict__ blk_uoff,
+                                                       const uint8_t* __restrict__ out_all, uint32_t n_blocks,
+                                                       uint32_t* status) {
+  __shared__ uint32_t T[4][256];
+  {
+    uint32_t c = threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-  return c;
-}
-__device__ uint32_t gf2_times(const uint32_t* mat, uint32_t vec) {
-  uint32_t sum = 0;
-  int i = 0;
-  while (vec) {
-    if (vec & 1) sum ^= mat[i];
-    vec >>= 1;
-    i++;
+    for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+    T[0][threadIdx.x] = c;
   }
-  return sum;
-}
-__device__ void gf2_square(uint32_t* sq, const uint32_t* mat) {
-  for (int n = 0; n < 32; n++) sq[n] = gf2_times(mat, mat[n]);
-}
-// crc of (A || B) given crc(A), crc(B), len(B)
-__device__ uint32_t crc32_combine_dev(uint32_t crc1, uint32_t crc2, uint32_t len2) {
-  if (len2 == 0) return crc1;
-  uint32_t even[32], odd[32];
-  odd[0] = 0xEDB88320u;
-  uint32_t row = 1;
-  for (int n = 1; n < 32; n++) { odd[n] = row; row <<= 1; }
-  gf2_square(even, odd);
-  gf2_square(odd, even);
-  do {
-    gf2_square(even, odd);
-    if (len2 & 1) crc1 = gf2_times(even, crc1);
-    len2 >>= 1;
-    if (len2 == 0) break;
-    gf2_square(odd, even);
-    if (len2 & 1) crc1 = gf2_times(odd, crc1);
-    len2 >>= 1;
-  } while (len2 != 0);
-  return crc1 ^ crc2;
-}
-
-__global__ __launch_bounds__(WAVE) void k_bgzf_crc32(const uint8_t* __restrict__ comp,
-                                                      const uint64_t* __restrict__ blk_coff,
-                                                      const uint64_t* __restrict__ blk_uoff,
-                                                      const uint8_t* __restrict__ out_all, uint32_t n_blocks,
-                                                      uint32_t* status) {
-  __shared__ uint32_t s_crc[WAVE];
-  __shared__ uint32_t s_len[WAVE];
-  const int lane = threadIdx.x;
-  const uint32_t b = blockIdx.x;
+  __syncthreads();
+  {
+    uint32_t c = T[0][threadIdx.x];
+    c = (c >> 8) ^ T[0][c & 0xFF]; T[1][threadIdx.x] = c;
+    c = (c >> 8) ^ T[0][c & 0xFF]; T[2][threadIdx.x] = c;
+    c = (c >> 8) ^ T[0][c & 0xFF]; T[3][threadIdx.x] = c;
+  }
+  __syncthreads();
+  const uint32_t b = blockIdx.x * CRC_T + threadIdx.x;
   if (b >= n_blocks) return;
-  const uint8_t* out = out_all + blk_uoff[b];
-  const uint32_t isize = (uint32_t)(blk_uoff[b + 1] - blk_uoff[b]);
+  const uint8_t* p = out_all + blk_uoff[b];
+  uint32_t n = (uint32_t)(blk_uoff[b + 1] - blk_uoff[b]);
   const uint8_t* tr = comp + blk_coff[b + 1] - 8;
   const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
-  const uint32_t per = (isize + WAVE - 1) / WAVE;
-  uint32_t lo = lane * per;
-  uint32_t hi = lo + per;
-  if (lo > isize) lo = isize;
-  if (hi > isize) hi = isize;
   uint32_t c = 0xFFFFFFFFu;
-  for (uint32_t k = lo; k < hi; k++) c = crc_byte(c, out[k]);
-  c ^= 0xFFFFFFFFu;
-  s_crc[lane] = c;
-  s_len[lane] = hi - lo;
-  __syncthreads();
-  if (lane == 0) {
-    uint32_t acc = s_crc[0];
-    for (int i = 1; i < WAVE; i++) acc = crc32_combine_dev(acc, s_crc[i], s_len[i]);
-    if (acc != want && status[b] == INF_OK) status[b] = INF_CRC_MISMATCH;
+  while (n && ((uintptr_t)p & 3)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF]; n--; }
+  const uint32_t* w = (const uint32_t*)p;
+  uint32_t nw = n >> 2;
+  for (uint32_t k = 0; k < nw; k++) {
+    c ^= w[k];
+    c = T[3][c & 0xFF] ^ T[2][(c >> 8) & 0xFF] ^ T[1][(c >> 16) & 0xFF] ^ T[0][c >> 24];
   }
+  p += (size_t)nw * 4;
+  n &= 3;
+  while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
+  c ^= 0xFFFFFFFFu;
+  if (c != want && status[b] == INF_OK) status[b] = INF_CRC_MISMATCH;
 }
 
 void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
@@ -509,7 +480,7 @@ void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const ui
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, const uint8_t* out,
                        uint32_t n_blocks, uint32_t* status, hipStream_t st) {
   if (!n_blocks) return;
-  hipLaunchKernelGGL(k_bgzf_crc32, dim3(n_blocks), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status);
+  hipLaunchKernelGGL(k_bgzf_crc32, dim3((n_blocks + CRC_T - 1) / CRC_T), dim3(CRC_T), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status);
 }
 
 }  // namespace bioscan

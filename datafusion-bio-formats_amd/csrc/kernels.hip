@@ -145,6 +145,12 @@ __device__ __forceinline__ bool plausible_rec(const uint8_t* u, uint64_t ulen, u
   uint64_t need = 32ull + lrn + 4ull * ncig + (uint64_t)((lseq + 1) / 2) + (uint64_t)lseq;
   if (need > (uint64_t)bs) return false;
   if (r[36 + lrn - 1] != 0) return false;
+  // read names are [!-?A-~]{1,254} (SAM spec 1.4): a cheap, very selective test.  It only steers the
+  // GUESS; a file with exotic names still decodes exactly through the verify/fix loop.
+  for (uint32_t k = 0; k + 1 < lrn; k++) {
+    uint8_t c = r[36 + k];
+    if (c < 0x21 || c > 0x7E) return false;
+  }
   *next = p + 4 + (uint64_t)bs;
   return true;
 }
@@ -213,8 +219,11 @@ __global__ void k_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, C
   uint64_t t = s - 1;
   while (t > first_seg && cb.exit_[t] == SEG_NONE) t--;
   const uint64_t e = cb.exit_[t];
+  // A BAD predecessor exit means its entry is a false positive that will be corrected this round
+  // (or the data is corrupt, which is reported after convergence): do not judge this segment yet.
+  if (e == SEG_BAD) return;
   uint64_t expect;
-  if (e == SEG_BAD || e == SEG_NONE) expect = SEG_NONE;      // upstream is broken / empty: nothing starts here yet
+  if (e == SEG_NONE) expect = SEG_NONE;
   else if (e >= B && e < E) expect = e;
   else expect = SEG_NONE;                                      // a long record covers this segment (or stream ended)
   if (cb.entry[s] != expect) {

@@ -47,7 +47,8 @@ class ScanStats(C.Structure):
     _fields_ = [("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64),
                 ("arrow_bytes", C.c_uint64), ("n_records", C.c_uint64), ("n_rows", C.c_uint64),
                 ("ms_h2d", C.c_double), ("ms_frame", C.c_double), ("ms_inflate", C.c_double), ("ms_chain", C.c_double),
-                ("ms_extract", C.c_double), ("ms_total_gpu", C.c_double)]
+                ("ms_extract", C.c_double), ("ms_total_gpu", C.c_double), ("ms_crc", C.c_double), ("ms_keys", C.c_double),
+                ("ms_select", C.c_double), ("ms_wall", C.c_double), ("chain_iterations", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -133,7 +133,12 @@ typedef struct bioscan_scan_stats {
   double ms_inflate;          /* K1 bgzf_inflate */
   double ms_chain;            /* record boundary scan */
   double ms_extract;          /* field extract + Arrow scatter */
-  double ms_total_gpu;        /* first kernel start -> last kernel end */
+  double ms_total_gpu;        /* sum of the stage times above that ran for this call */
+  double ms_crc;              /* K2 bgzf_crc32 (validation, as noodles-bgzf verifies every block) */
+  double ms_keys;             /* record key table (refid,pos,end,flag,mapq) */
+  double ms_select;           /* row selection (region / tail / residual filters) */
+  double ms_wall;             /* host wall-clock of the whole call (allocation + launches + syncs) */
+  uint64_t chain_iterations;  /* verify/fix rounds of the record boundary scan (1 = all guesses right) */
 } bioscan_scan_stats;
 
 /* Make the file's compressed bytes resident in HBM (idempotent); later executes reuse them. */
