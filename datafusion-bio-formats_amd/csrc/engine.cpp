@@ -264,6 +264,7 @@ struct Provider {
       uint32_t nfix = 0;
       HIP_CHECK(hipMemcpyAsync(&nfix, ctr.p, 4, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
+      if (getenv("BIOSCAN_DEBUG")) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
       if (nfix == 0) break;
       if ((uint64_t)iter > nseg + 2) throw Error("record boundary scan did not converge");
       launch_seg_walk(d_u.p, ulen, nseg, cb, 1, stream);

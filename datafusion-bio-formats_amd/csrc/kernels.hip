@@ -223,9 +223,11 @@ __global__ void k_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, C
   // (or the data is corrupt, which is reported after convergence): do not judge this segment yet.
   if (e == SEG_BAD) return;
   uint64_t expect;
-  if (e == SEG_NONE) expect = SEG_NONE;
-  else if (e >= B && e < E) expect = e;
-  else expect = SEG_NONE;                                      // a long record covers this segment (or stream ended)
+  if (e == SEG_NONE) expect = SEG_NONE;          // nothing upstream has a record yet (only inside the header)
+  else if (e < B) return;                        // a segment between t and s must start at e but is NONE right now:
+                                                 // it is corrected this round; judge s once its exit is known
+  else if (e < E) expect = e;
+  else expect = SEG_NONE;                        // a long record covers this whole segment (or the stream ended)
   if (cb.entry[s] != expect) {
     cb.entry[s] = expect;
     cb.dirty[s] = 1;
