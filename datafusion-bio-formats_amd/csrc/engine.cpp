@@ -1335,4 +1335,62 @@ int bioscan_bgzf_inflate(const uint8_t* data, size_t len, int32_t device_id, int
   API_END
 }
 
+static int32_t write_plan(const std::vector<PartitionAssignment>& parts, char* buf, int32_t cap) {
+  std::string o;
+  for (auto& p : parts) { o += describe_partition(p); o += "\n"; }
+  if (buf && cap > 0) snprintf(buf, cap, "%s", o.c_str());
+  return (int32_t)o.size();
+}
+
+int32_t bioscan_debug_balance_partitions(int32_t n, const char* const* chroms, const uint64_t* region_start,
+                                         const uint64_t* region_end, const uint64_t* est_bytes, const uint64_t* contig_len,
+                                         const uint64_t* unmapped, const uint64_t* const* bins, const int32_t* n_bins,
+                                         uint64_t leaf_span, int32_t target_partitions, char* buf, int32_t cap) {
+  std::vector<RegionSizeEstimate> est;
+  for (int32_t i = 0; i < n; i++) {
+    RegionSizeEstimate e;
+    e.region.chrom = chroms[i];
+    if (region_start && region_start[i]) { e.region.has_start = true; e.region.start = region_start[i]; }
+    if (region_end && region_end[i]) { e.region.has_end = true; e.region.end = region_end[i]; }
+    e.estimated_bytes = est_bytes[i];
+    if (contig_len && contig_len[i]) { e.has_contig_length = true; e.contig_length = contig_len[i]; }
+    e.unmapped_count = unmapped ? unmapped[i] : 0;
+    if (bins && n_bins) e.nonempty_bin_positions.assign(bins[i], bins[i] + n_bins[i]);
+    e.leaf_bin_span = leaf_span;
+    est.push_back(std::move(e));
+  }
+  return write_plan(balance_partitions(est, (size_t)std::max(target_partitions, 0)), buf, cap);
+}
+
+int32_t bioscan_debug_plan_full_scan(const char* bai_path, int32_t n_ref, const char* const* ref_names, const int64_t* ref_lengths,
+                                     int32_t target_partitions, char* buf, int32_t cap) {
+  std::ifstream f(bai_path, std::ios::binary);
+  if (!f.good()) return -1;
+  std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  Bai bai;
+  std::string e;
+  if (!parse_bai(d, &bai, &e)) return -1;
+  std::vector<std::string> names;
+  std::vector<int64_t> lens;
+  std::vector<GenomicRegion> regions;
+  for (int32_t i = 0; i < n_ref; i++) {
+    names.push_back(ref_names[i]);
+    lens.push_back(ref_lengths[i]);
+    GenomicRegion r;
+    r.chrom = ref_names[i];
+    regions.push_back(r);
+  }
+  auto parts = balance_partitions(estimate_sizes_from_bai(&bai, regions, names, lens), (size_t)std::max(target_partitions, 0));
+  if (bai.has_no_coor && bai.n_no_coor > 0) {
+    PartitionAssignment a;
+    GenomicRegion r;
+    r.chrom = "*";
+    r.unmapped_tail = true;
+    a.regions.push_back(r);
+    a.total_estimated_bytes = std::max<uint64_t>(bai.n_no_coor, 1);
+    parts.push_back(a);
+  }
+  return write_plan(parts, buf, cap);
+}
+
 }  // extern "C"

@@ -61,6 +61,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_plan_partition_desc", "bioscan_execute", "bioscan_next", "bioscan_stream_close", "bioscan_plan_close",
     "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
+    "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan",
 ]
 
 
@@ -120,6 +121,46 @@ def bgzf_inflate(data: bytes, device_id: int = 0, check_crc: bool = True):
         return C.string_at(out, n.value), ms.value
     finally:
         lib.bioscan_free(out)
+
+
+def debug_balance_partitions(estimates, target_partitions: int) -> str:
+    """estimates: list of dicts {chrom,start,end,bytes,contig_len,unmapped,bins,leaf_span} -> plan text."""
+    lib = load_library()
+    n = len(estimates)
+    if n == 0:
+        return ""
+    chroms = (C.c_char_p * n)(*[e["chrom"].encode() for e in estimates])
+    u64 = C.c_uint64 * n
+    rs = u64(*[e.get("start") or 0 for e in estimates])
+    re_ = u64(*[e.get("end") or 0 for e in estimates])
+    eb = u64(*[e["bytes"] for e in estimates])
+    cl = u64(*[e.get("contig_len") or 0 for e in estimates])
+    um = u64(*[e.get("unmapped") or 0 for e in estimates])
+    bin_arrays = [(C.c_uint64 * max(len(e.get("bins") or []), 1))(*(e.get("bins") or [])) for e in estimates]
+    bins = (C.POINTER(C.c_uint64) * n)(*[C.cast(a, C.POINTER(C.c_uint64)) for a in bin_arrays])
+    nb = (C.c_int32 * n)(*[len(e.get("bins") or []) for e in estimates])
+    leaf = max([e.get("leaf_span") or 0 for e in estimates])
+    buf = C.create_string_buffer(1 << 20)
+    lib.bioscan_debug_balance_partitions.argtypes = [C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64),
+                                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                                     C.POINTER(C.c_uint64), C.POINTER(C.POINTER(C.c_uint64)),
+                                                     C.POINTER(C.c_int32), C.c_uint64, C.c_int32, C.c_char_p, C.c_int32]
+    lib.bioscan_debug_balance_partitions(n, chroms, rs, re_, eb, cl, um, bins, nb, leaf, target_partitions, buf, 1 << 20)
+    return buf.value.decode()
+
+
+def debug_plan_full_scan(bai_path: str, ref_names, ref_lengths, target_partitions: int) -> str:
+    lib = load_library()
+    n = len(ref_names)
+    names = (C.c_char_p * max(n, 1))(*[r.encode() for r in ref_names])
+    lens = (C.c_int64 * max(n, 1))(*ref_lengths)
+    buf = C.create_string_buffer(1 << 22)
+    lib.bioscan_debug_plan_full_scan.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
+                                                 C.c_int32, C.c_char_p, C.c_int32]
+    rc = lib.bioscan_debug_plan_full_scan(bai_path.encode(), n, names, lens, target_partitions, buf, 1 << 22)
+    if rc < 0:
+        raise BioscanError("cannot read BAI " + bai_path)
+    return buf.value.decode()
 
 
 _OPS = {"=": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5, "between": 6, "not between": 7, "in": 8, "not in": 9}

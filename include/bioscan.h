@@ -156,6 +156,21 @@ int bioscan_bgzf_inflate(const uint8_t* data, size_t len, int32_t device_id, int
                          uint8_t** out, size_t* out_len, double* kernel_ms);
 void bioscan_free(void* p);
 
+/* ---- Planning test hooks (host only, usable without a GPU) --------------------------------
+ * balance_partitions (bio-format-core/src/partition_balancer.rs:61-295) on caller-supplied
+ * estimates.  region_start/region_end: 0 = None; contig_len: 0 = None; bins[i] = n_bins[i] sorted
+ * non-empty leaf-bin positions.  Output: one line per partition "bytes|chrom:start-end[*];...". */
+int32_t bioscan_debug_balance_partitions(int32_t n, const char* const* chroms, const uint64_t* region_start,
+                                         const uint64_t* region_end, const uint64_t* est_bytes,
+                                         const uint64_t* contig_len, const uint64_t* unmapped,
+                                         const uint64_t* const* bins, const int32_t* n_bins, uint64_t leaf_span,
+                                         int32_t target_partitions, char* buf, int32_t cap);
+/* Full-scan plan of TableProvider::scan (table_provider.rs:1014-1056) from a BAI file and the
+ * header's reference names/lengths: estimate_sizes_from_bai + balance_partitions + no-coor
+ * partition.  Same output format. */
+int32_t bioscan_debug_plan_full_scan(const char* bai_path, int32_t n_ref, const char* const* ref_names,
+                                     const int64_t* ref_lengths, int32_t target_partitions, char* buf, int32_t cap);
+
 /* Library / device probe: returns 0 when a gfx950-capable HIP device is usable. */
 int bioscan_device_check(int32_t device_id, char* name_buf, int32_t cap);
 

@@ -1,0 +1,151 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; the C++ host planning
+(balance_partitions, estimate_sizes_from_bai) matches the oracle and the reference's own
+partition_balancer tests (bio-format-core/src/partition_balancer.rs:321-1005); sharding logic."""
+import os
+import random
+import re
+
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_declared_symbols(pkg):
+    lib = pkg.load_library()
+    hdr = open(os.path.join(ROOT, "include", "bioscan.h")).read()
+    declared = set(re.findall(r"\b(bioscan_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+
+
+def test_no_gpu_fails_loudly(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(pkg.BioscanError, match="no HIP device"):
+        pkg.BamTableProvider(os.path.join(G, "multi_chrom.bam"))
+
+
+def _desc(parts):
+    out = []
+    for p in parts:
+        rs = []
+        for r in p.regions:
+            rs.append(f"{r.chrom}:{r.start if r.start is not None else ''}-{r.end if r.end is not None else ''}{'*' if r.unmapped_tail else ''}")
+        out.append(f"{p.total_estimated_bytes}|" + ";".join(rs))
+    return "\n".join(out) + ("\n" if out else "")
+
+
+def _py(oracle, ests, target):
+    E = [oracle.RegionSizeEstimate(oracle.GenomicRegion(e["chrom"], e.get("start"), e.get("end")), e["bytes"],
+                                   e.get("contig_len"), e.get("unmapped") or 0, list(e.get("bins") or []), e.get("leaf_span") or 0)
+         for e in ests]
+    return oracle.balance_partitions(E, target)
+
+
+def _est(chrom, b, cl=None, unmapped=0, bins=None, leaf=0):
+    return {"chrom": chrom, "bytes": b, "contig_len": cl, "unmapped": unmapped, "bins": bins, "leaf_span": leaf}
+
+
+HUMAN = [("chr1", 249), ("chr2", 243), ("chr3", 198), ("chr4", 191), ("chr5", 181), ("chr6", 171), ("chr7", 159), ("chr8", 146),
+         ("chr9", 141), ("chr10", 136), ("chr11", 135), ("chr12", 134), ("chr13", 115), ("chr14", 107), ("chr15", 102),
+         ("chr16", 90), ("chr17", 84), ("chr18", 80), ("chr19", 59), ("chr20", 64), ("chr21", 47), ("chr22", 51), ("chrX", 155), ("chrY", 57)]
+
+
+def test_balancer_reference_kats(pkg, oracle):
+    """Properties asserted by the reference's own tests, checked on BOTH implementations."""
+    def both(ests, target):
+        py = _py(oracle, ests, target)
+        assert pkg.debug_balance_partitions(ests, target) == _desc(py)
+        return py
+    assert both([], 4) == []
+    r = both([_est("chr1", 100), _est("chr2", 50), _est("chrX", 30)], 1)
+    assert len(r) == 1 and len(r[0].regions) == 3 and r[0].total_estimated_bytes == 180
+    r = both([_est(f"chr{i}", 100) for i in range(1, 5)], 2)
+    assert [p.total_estimated_bytes for p in r] == [200, 200]
+    r = both([_est("chr1", 100), _est("chr2", 50), _est("chr3", 10)], 2)
+    assert [p.total_estimated_bytes for p in r] == [100, 60]
+    r = both([_est("chr1", 100, 249_000_000), _est("chr2", 50), _est("chr3", 10)], 2)
+    assert [p.total_estimated_bytes for p in r] == [80, 80]
+    r = both([_est("chr1", 200, 249_000_000), _est("chr2", 10)], 4)
+    assert sum(len(p.regions) for p in r) > 2 and len(r) <= 4
+    r = both([_est(f"chr{i}", 0) for i in range(1, 5)], 2)
+    assert [len(p.regions) for p in r] == [2, 2]
+    assert len(both([_est("chr1", 100), _est("chr2", 50)], 8)) == 2
+    r = both([_est("chr1", 100, 249_000_000), _est("chr2", 50, 243_000_000)], 8)
+    assert 2 < len(r) <= 8
+    for target in (2, 4, 8):
+        r = both([_est("chr1", 1000, 249_000_000)], target)
+        assert len(r) == target
+        regs = [x for p in r for x in p.regions]
+        assert all(x.chrom == "chr1" and x.start is not None for x in regs)
+        assert all(x.end is not None for x in regs[:-1]) and regs[-1].end is None
+    ests = [_est(c, b, b * 1_000_000) for c, b in HUMAN]
+    r = both(ests, 8)
+    tot = [p.total_estimated_bytes for p in r]
+    assert sum(tot) == sum(b for _, b in HUMAN) and max(tot) <= 2 * min(tot) and 0 < len(r) <= 8
+    r = both([_est("chr1", 200, 249_000_000, 1000), _est("chr2", 10)], 4)
+    tails = [x for p in r for x in p.regions if x.unmapped_tail]
+    assert len(tails) == 1 and tails[0].chrom == "chr1" and tails[0].start is None and tails[0].end is None
+    r = both([_est("chr1", 100, 249_000_000, 500), _est("chr2", 95, 243_000_000, 300), _est("chrM", 5, 16_569, 100)], 4)
+    assert len([x for p in r for x in p.regions if x.chrom == "chrM" and x.unmapped_tail]) == 1
+    r = both([_est("chr1", 249, 249_000_000), _est("chr2", 243, 243_000_000), _est("chr3", 198, 198_000_000), _est("chrX", 60, 155_000_000)], 4)
+    assert len(r) == 4 and all(187 <= p.total_estimated_bytes <= 189 for p in r)
+    r = both([_est("chr1", 0), _est("chr2", 100), _est("chrX", 0)], 4)
+    assert sorted(x.chrom for p in r for x in p.regions) == ["chr1", "chr2", "chrX"]
+    for target in (2, 3, 4, 8, 16):
+        r = both([_est("chr1", 249, 249_000_000), _est("chr2", 243, 243_000_000), _est("chr3", 198, 198_000_000)], target)
+        assert sum(p.total_estimated_bytes for p in r) == 690
+    # bin-aware split concentrates on data (partition_balancer.rs:747-800)
+    bins = [i * 16384 + 1 for i in range(100)]
+    r = both([_est("chr1", 1000, 249_000_000, 0, bins, 16384)], 4)
+    ends = [x.end for p in r for x in p.regions if x.end is not None]
+    assert len(r) == 4 and all(e < 25_000_000 for e in ends)
+
+
+def test_balancer_differential_fuzz(pkg, oracle):
+    rng = random.Random(1234)
+    for _ in range(300):
+        n = rng.randint(1, 12)
+        ests = []
+        for i in range(n):
+            cl = rng.choice([None, rng.randint(1, 300_000_000)])
+            nb = rng.choice([0, 0, rng.randint(1, 200)])
+            hi = max((cl or 1_000_000) // 16384, 1)
+            bins = sorted({rng.randrange(0, hi) * 16384 + 1 for _ in range(nb)})
+            ests.append(_est(f"c{i}", rng.choice([0, 1, rng.randint(0, 10_000), rng.randint(0, 1 << 40)]), cl,
+                             rng.choice([0, 0, 7]), bins, 16384 if bins else 0))
+            if rng.random() < 0.15:
+                a = rng.randint(1, 1_000_000)
+                ests[-1]["start"], ests[-1]["end"] = a, a + rng.randint(0, 5_000_000)
+        target = rng.randint(1, 40)
+        assert pkg.debug_balance_partitions(ests, target) == _desc(_py(oracle, ests, target)), (ests, target)
+
+
+@pytest.mark.parametrize("fname", ["multi_chrom.bam", "multi_chrom_large.bam", "bam_with_tags.bam", "no_coor_only.bam",
+                                   "nanopore_custom_tags.bam", "10x_pbmc_tags.bam"])
+def test_full_scan_plan_matches_oracle(pkg, oracle, fname):
+    """C++ parse_bai + estimate_sizes_from_bai + balance_partitions == oracle on the reference's BAI fixtures."""
+    b = oracle.BamOracle(os.path.join(G, fname))
+    for target in (1, 2, 3, 4, 8, 16, 64):
+        parts, _ = b.scan(target_partitions=target)
+        got = pkg.debug_plan_full_scan(os.path.join(G, fname + ".bai"), b.hdr.ref_names, b.hdr.ref_lengths, target)
+        assert got == _desc(parts), (fname, target)
+
+
+def test_shard_partitions_in_order(pkg):
+    f = pkg.shard_partitions_in_order
+    assert f([], 4) == [[], [], [], []]
+    assert f([10, 10, 10, 10], 2) == [[0, 1], [2, 3]]
+    assert f([100, 1, 1, 1], 2) == [[0], [1, 2, 3]]
+    assert f([5, 5], 4) == [[0], [1], [], []]
+    rng = random.Random(5)
+    for _ in range(200):
+        w = [rng.randint(0, 1000) for _ in range(rng.randint(1, 60))]
+        world = rng.randint(1, 8)
+        runs = f(w, world)
+        assert len(runs) == world
+        assert [i for r in runs for i in r] == list(range(len(w)))   # contiguous, ordered, complete
+        assert sum(1 for r in runs if r) == min(world, len(w))
