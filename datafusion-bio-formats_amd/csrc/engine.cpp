@@ -90,6 +90,9 @@ struct Provider {
   DevBuf<uint8_t> d_comp;
   DevBuf<uint64_t> d_coff, d_uoff;
   DevBuf<uint32_t> d_status;
+  DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..2] debug counters
+  DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
+  uint32_t v2_grid = 0;
 
   bool decoded = false;
   DevBuf<uint8_t> d_u;
@@ -172,6 +175,15 @@ struct Provider {
     HIP_CHECK(hipMemcpyAsync(d_coff.p, blk_coff.data(), blk_coff.size() * 8, hipMemcpyHostToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(d_uoff.p, blk_uoff.data(), blk_uoff.size() * 8, hipMemcpyHostToDevice, stream));
     d_status.alloc(std::max<size_t>(n_blocks(), 1));
+    {
+      hipDeviceProp_t pr;
+      HIP_CHECK(hipGetDeviceProperties(&pr, device));
+      const char* g = getenv("BIOSCAN_V2_WG_PER_CU");
+      v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)(g ? atoi(g) : 12);
+      v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
+      d_v2_ctr.alloc(32);
+      d_v2_scratch.alloc((size_t)v2_grid * V2_SCRATCH_STRIDE);
+    }
     // reference-name LUT
     std::vector<uint32_t> off{0}, len;
     std::string blob;
@@ -200,7 +212,31 @@ struct Provider {
     if (!len.empty()) HIP_CHECK(hipMemcpy(d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
   }
 
+  void launch_inflate(uint8_t* dst, uint32_t nb) {
+    if (getenv("BIOSCAN_INFLATE_V1")) {
+      launch_bgzf_inflate(d_comp.p, d_coff.p, d_uoff.p, dst, nb, d_status.p, stream);
+    } else {
+      HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
+      launch_bgzf_inflate_v2(d_comp.p, d_coff.p, d_uoff.p, dst, nb, d_status.p, d_v2_ctr.p, d_v2_scratch.p, V2_SCRATCH_STRIDE,
+                             v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
+    }
+  }
+  void report_v2_debug(uint32_t nb) {
+    if (!getenv("BIOSCAN_DEBUG") || getenv("BIOSCAN_INFLATE_V1")) return;
+    uint32_t h[32];
+    HIP_CHECK(hipMemcpy(h, d_v2_ctr.p, 128, hipMemcpyDeviceToHost));
+    unsigned long long tc[5];
+    memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
+    fprintf(stderr, "[bioscan] inflate v2: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
+            h[2] ? (double)h[3] / h[2] : 0.0);
+    double tot = 0;
+    for (int i = 0; i < 5; i++) tot += (double)tc[i];
+    const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
+    for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+  }
+
   void check_inflate_status(uint32_t b0, uint32_t nb) {
+    if (getenv("BIOSCAN_V2_ABLATE")) return;  // timing-only ablation builds produce wrong bytes on purpose
     std::vector<uint32_t> st(nb);
     HIP_CHECK(hipMemcpy(st.data(), d_status.p + b0, nb * 4, hipMemcpyDeviceToHost));
     for (uint32_t i = 0; i < nb; i++)
@@ -215,7 +251,7 @@ struct Provider {
     b1 = std::min(b1, n_blocks());
     uint64_t bytes = blk_uoff[b1];
     DevBuf<uint8_t> tmp(bytes + 64);
-    launch_bgzf_inflate(d_comp.p, d_coff.p, d_uoff.p, tmp.p, b1, d_status.p, stream);
+    launch_inflate(tmp.p, b1);
     launch_bgzf_crc32(d_comp.p, d_coff.p, d_uoff.p, tmp.p, b1, d_status.p, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     check_inflate_status(0, b1);
@@ -238,8 +274,13 @@ struct Provider {
     tt.start();
     if (d_u.n < ulen + 64) d_u.alloc(ulen + 64);
     t.start();
-    launch_bgzf_inflate(d_comp.p, d_coff.p, d_uoff.p, d_u.p, n_blocks(), d_status.p, stream);
+    launch_inflate(d_u.p, n_blocks());
     s.ms_inflate = t.stop();
+    report_v2_debug(n_blocks());
+    if (getenv("BIOSCAN_V2_ABLATE")) {
+      fprintf(stderr, "[bioscan] ablate=%s inflate_ms=%.3f\n", getenv("BIOSCAN_V2_ABLATE"), s.ms_inflate);
+      throw Error("ablation run: timing only");
+    }
     t.start();
     launch_bgzf_crc32(d_comp.p, d_coff.p, d_uoff.p, d_u.p, n_blocks(), d_status.p, stream);
     s.ms_crc = t.stop();
@@ -1321,7 +1362,7 @@ int bioscan_bgzf_inflate(const uint8_t* data, size_t len, int32_t device_id, int
   DevBuf<uint8_t> u(p.ulen + 64);
   StageTimer t(p.stream);
   t.start();
-  launch_bgzf_inflate(p.d_comp.p, p.d_coff.p, p.d_uoff.p, u.p, p.n_blocks(), p.d_status.p, p.stream);
+  p.launch_inflate(u.p, p.n_blocks());
   double ms = t.stop();
   if (check_crc) launch_bgzf_crc32(p.d_comp.p, p.d_coff.p, p.d_uoff.p, u.p, p.n_blocks(), p.d_status.p, p.stream);
   HIP_CHECK(hipStreamSynchronize(p.stream));

@@ -1,0 +1,764 @@
+// inflate_v2.hip -- K1 v2: BGZF inflate with wave-parallel Huffman decoding (gfx950, wave64).
+//
+// Same contract as K1 v1 (inflate.hip): one BGZF member per wavefront, output window = the
+// member's own range of the inflated stream.  What changes is how a DEFLATE block's symbol
+// stream is decoded.  v1 walks it serially (one symbol per ~35 wave-instructions, 63 lanes
+// idle).  v2 cuts the compressed body into 64 sub-streams of `sub_dw` dwords and lets every lane
+// decode its own sub-stream at once:
+//   1. speculative pass: lane 0 starts at the exact bit position; lane i>0 starts at its
+//      sub-stream boundary (almost never a symbol start).  Huffman/DEFLATE streams
+//      self-synchronise, so each lane's END position (first symbol start at/after the next
+//      boundary) is usually already correct even when its start was wrong.
+//   2. fix-point: lane i+1 adopts lane i's end as its start and re-decodes if that changed; repeat
+//      until no lane changes (lane 0 is exact, so by induction the chain is exact -- speculation
+//      only affects speed).  Lanes after the first END-OF-BLOCK are dead.
+//   3. wave prefix sums of per-lane output bytes / match counts give every lane its output
+//      offset; a last pass writes literals straight to the output window and appends LZ77
+//      matches to the workgroup's match list (L2-resident scratch).
+//   4. the match list is resolved 64 matches at a time by the dependency-ordered batch copy
+//      shared with v1 (resolve_batch).
+// Tables (u32 entries with length/distance base and extra-bit count folded in) live in LDS next
+// to the staged compressed bytes of the round; block headers / code lengths are parsed by the
+// uniform register-staged bit reader of v1.  Persistent grid: workgroups pull members from an
+// atomic counter so the per-workgroup match scratch is bounded by residency.
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace bioscan {
+
+#define WAVE 64
+#ifndef V2_SUB_DW
+#define V2_SUB_DW 9
+#endif
+#ifndef V2_OV_BITS
+#define V2_OV_BITS 96
+#endif
+#ifndef V2_WIN_BYTES
+#define V2_WIN_BYTES 7168
+#endif
+constexpr int V2_LIT_BITS = 9;                          // zlib's root sizes: ENOUGH_LENS = 852, ENOUGH_DISTS = 592
+constexpr int V2_DIST_BITS = 6;
+constexpr int V2_MAX_SUB_DW = V2_SUB_DW;                // odd => conflict-free initial LDS reads
+constexpr int V2_WIN = V2_WIN_BYTES;                    // LDS output window of one round (multiple of 16)
+constexpr int V2_STAGE_DW = 64 * V2_MAX_SUB_DW + 8;
+constexpr int V2_LIT_SUB = 352;    // 852 - 512 = 340 sub-table entries at most
+constexpr int V2_DIST_SUB = 528;   // 592 - 64
+constexpr uint32_t E_LEN = 1u << 17, E_EOB = 1u << 18, E_SUB = 1u << 19;  // E_SUB: bits[4:7] = sub-table index bits, [8:18] = base
+constexpr uint32_t F_EOB = 1, F_BAD = 2;
+
+struct __attribute__((aligned(16))) V2Lds {
+  uint32_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];     // len[0:3] extra[4:7] base[8:16] E_LEN E_EOB | E_SUB pointer ; 0 = no code
+  uint32_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // len[0:3] extra[4:7] base[8:23] | E_SUB pointer
+  uint32_t stage[V2_STAGE_DW];
+  uint8_t win[V2_WIN] __attribute__((aligned(16)));
+  uint16_t lit_sorted[288];
+  uint16_t dist_sorted[32];
+  uint16_t lit_count[16];
+  uint16_t dist_count[16];
+  uint16_t t_offs[16], t_first[16], t_w[16];
+  uint8_t lens[320];
+  uint8_t pre_fast[128];
+  uint8_t pre_lens[20];
+};
+
+__device__ __forceinline__ uint32_t uni2(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t bitrev2(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// ---- uniform register-staged bit reader (as v1) ---------------------------------------------------
+struct UBits {
+  const uint32_t* base;
+  uint32_t cur, nxt, cidx, wpos;
+  uint64_t bb;
+  int bc;
+};
+// start reading at bit `bitpos` counted from the 4-byte aligned pointer `base`
+__device__ __forceinline__ void ub_init(UBits& s, const uint32_t* base, uint64_t bitpos, int lane) {
+  s.base = base;
+  uint32_t w = (uint32_t)(bitpos >> 5);
+  s.cidx = w >> 6;
+  s.cur = base[(size_t)s.cidx * 64 + lane];
+  s.nxt = base[(size_t)(s.cidx + 1) * 64 + lane];
+  uint32_t first = __builtin_amdgcn_readlane(s.cur, w & 63);
+  s.wpos = w + 1;
+  int skip = (int)(bitpos & 31);
+  s.bb = (uint64_t)(first >> skip);
+  s.bc = 32 - skip;
+}
+__device__ __forceinline__ uint32_t ub_next_word(UBits& s, int lane) {
+  uint32_t c = s.wpos >> 6;
+  if (c != s.cidx) {
+    s.cur = s.nxt;
+    s.cidx = c;
+    s.nxt = s.base[(size_t)(c + 1) * 64 + lane];
+  }
+  uint32_t w = __builtin_amdgcn_readlane(s.cur, s.wpos & 63);
+  s.wpos++;
+  return w;
+}
+__device__ __forceinline__ void ub_refill(UBits& s, int lane) {
+  if (s.bc <= 32) {
+    s.bb |= (uint64_t)ub_next_word(s, lane) << s.bc;
+    s.bc += 32;
+  }
+}
+__device__ __forceinline__ uint32_t ub_take(UBits& s, int n) {
+  uint32_t v = (uint32_t)s.bb & ((1u << n) - 1u);
+  s.bb >>= n;
+  s.bc -= n;
+  return v;
+}
+__device__ __forceinline__ uint64_t ub_bitpos(const UBits& s) { return (uint64_t)s.wpos * 32 - (uint64_t)s.bc; }
+
+// ---- table entries ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lit_entry(int sym, int len) {
+  if (sym < 256) return ((uint32_t)sym << 8) | (uint32_t)len;
+  if (sym == 256) return E_EOB | (uint32_t)len;
+  int s = sym - 257;
+  uint32_t base, eb;
+  if (s < 8) { base = 3 + s; eb = 0; }
+  else if (s == 28) { base = 258; eb = 0; }
+  else if (s < 28) { eb = (uint32_t)(s - 4) >> 2; base = 3 + ((4 + (s & 3)) << eb); }
+  else { base = 0; eb = 15; }  // invalid length symbol 286/287: flagged at decode time (eb == 15)
+  return E_LEN | (base << 8) | (eb << 4) | (uint32_t)len;
+}
+__device__ __forceinline__ uint32_t dist_entry(int sym, int len) {
+  uint32_t base, eb;
+  if (sym < 4) { base = 1 + sym; eb = 0; }
+  else if (sym < 30) { eb = (uint32_t)(sym - 2) >> 1; base = 1 + ((2 + (sym & 1)) << eb); }
+  else { base = 0; eb = 15; }  // invalid distance symbol 30/31
+  return (base << 8) | (eb << 4) | (uint32_t)len;
+}
+
+// Build the two-level decode table of one alphabet: root table of 2^root_bits entries followed by
+// sub-tables for codes longer than root_bits (canonical codes that share a root prefix are
+// contiguous in (len, sym) order, so each sub-table is sized by the last = longest code of its
+// group).  Returns 1 if the code is over-subscribed or the sub-table space is exhausted.
+__device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, int root_bits, int sub_cap, uint16_t* sorted,
+                        uint16_t* count, bool is_dist, int lane) {
+  __syncthreads();
+  for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = 0;
+  if (lane < 16) count[lane] = 0;
+  __syncthreads();
+  if (lane == 0) {
+    for (int s = 0; s < n; s++) count[lens[s]]++;
+    count[0] = 0;
+    uint32_t o = 0, code = 0;
+    int left = 1, over = 0;
+    for (int l = 1; l <= 15; l++) {
+      uint32_t c = count[l];
+      code <<= 1;
+      L.t_first[l] = (uint16_t)code;
+      L.t_offs[l] = (uint16_t)o;
+      L.t_w[l] = (uint16_t)o;
+      o += c;
+      code += c;
+      left <<= 1;
+      left -= (int)c;
+      if (left < 0) over = 1;
+    }
+    L.t_offs[0] = (uint16_t)o;
+    for (int s = 0; s < n; s++) {
+      int l = lens[s];
+      if (l) sorted[L.t_w[l]++] = (uint16_t)s;
+    }
+    // sub-tables (serial: long codes are few)
+    uint32_t k = root_bits < 15 ? L.t_offs[root_bits + 1] : o;
+    uint32_t next_free = 1u << root_bits;
+    while (k < o && !over) {
+      const int sym_k = sorted[k];
+      const int len_k = lens[sym_k];
+      const uint32_t code_k = (uint32_t)L.t_first[len_k] + (k - L.t_offs[len_k]);
+      const uint32_t prefix = code_k >> (len_k - root_bits);
+      uint32_t j = k + 1;
+      int max_len = len_k;
+      while (j < o) {
+        const int sj = sorted[j];
+        const int lj = lens[sj];
+        const uint32_t cj = (uint32_t)L.t_first[lj] + (j - L.t_offs[lj]);
+        if ((cj >> (lj - root_bits)) != prefix) break;
+        max_len = lj;
+        j++;
+      }
+      const uint32_t sbits = (uint32_t)(max_len - root_bits);
+      if (next_free + (1u << sbits) > (1u << root_bits) + (uint32_t)sub_cap) { over = 1; break; }
+      fast[bitrev2(prefix, root_bits)] = E_SUB | (next_free << 8) | (sbits << 4);
+      for (uint32_t m = k; m < j; m++) {
+        const int sm = sorted[m];
+        const int lm = lens[sm];
+        const uint32_t cm = (uint32_t)L.t_first[lm] + (m - L.t_offs[lm]);
+        const uint32_t r = bitrev2(cm, lm) >> root_bits;  // bits after the root, LSB-first
+        const uint32_t e = is_dist ? dist_entry(sm, lm) : lit_entry(sm, lm);
+        for (uint32_t i = r; i < (1u << sbits); i += (1u << (lm - root_bits))) fast[next_free + i] = e;
+      }
+      next_free += 1u << sbits;
+      k = j;
+    }
+    L.t_first[0] = (uint16_t)over;
+  }
+  __syncthreads();
+  if (uni2(L.t_first[0])) return 1;
+  const uint32_t o = uni2(L.t_offs[0]);
+  for (uint32_t k = lane; k < o; k += WAVE) {
+    int sym = sorted[k];
+    int l = lens[sym];
+    if (l <= root_bits) {
+      uint32_t c = (uint32_t)L.t_first[l] + (k - L.t_offs[l]);
+      uint32_t r = bitrev2(c, l);
+      uint32_t e = is_dist ? dist_entry(sym, l) : lit_entry(sym, l);
+      for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
+    }
+  }
+  __syncthreads();
+  return 0;
+}
+
+// One decode pass of this lane's sub-stream [start, limit).  MODE 0: count only; 1: write literals to
+// HBM; 2: write literals to the LDS window.  The lane keeps a 64-bit bit buffer in registers and
+// refills it one dword at a time from the staged input.  The body is written predicated (selects,
+// wave-uniform ballot branches, no break) so it compiles to straight-line code instead of nested
+// exec-mask regions.
+template <int MODE>
+__device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, uint32_t limit, uint32_t& end_out,
+                                        uint32_t& nout, uint32_t& nmatch, uint32_t& flags, uint8_t* out, uint32_t opos,
+                                        unsigned long long* mlist, uint32_t mpos, uint32_t win_base,
+                                        uint32_t count_from, uint32_t& first_out) {
+  constexpr bool WRITE = MODE != 0;
+  uint32_t pos = start;
+  uint32_t fl = 0, no = 0, nm = 0;
+  bool run = active && pos < limit;
+  // speculative lanes start `overlap` bits early: symbols that begin before count_from only serve to
+  // synchronise; the first symbol start at/after count_from is reported and counting restarts there.
+  bool seen = pos >= count_from;
+  uint32_t first = pos;
+  uint32_t wp = run ? (pos >> 5) : 0u;
+  uint64_t bb;
+  int bc;
+  {
+    const uint64_t lo = L.stage[wp], hi = L.stage[wp + 1];
+    bb = ((hi << 32) | lo) >> (pos & 31);
+    bc = 64 - (int)(pos & 31);
+    wp += 2;
+  }
+  while (__ballot(run) != 0ull) {
+    if (MODE == 0) {
+      const bool cross = run && !seen && pos >= count_from;
+      if (cross) { first = pos; no = 0; nm = 0; }
+      seen = seen || cross;
+    }
+    // refill to >= 33 bits (reads of finished lanes stay inside the staged region: wp only moves while running)
+    {
+      const bool rf = run && bc <= 32;
+      const uint64_t w = L.stage[wp];
+      if (rf) { bb |= w << bc; bc += 32; wp++; }
+    }
+    uint32_t e = L.lit_fast[(uint32_t)bb & ((1u << V2_LIT_BITS) - 1u)];
+    {
+      const bool need2 = (e & 15u) == 0;
+      if (__ballot(run && need2) != 0ull) {
+        const uint32_t idx = ((e >> 8) & 0x7FFu) + ((uint32_t)(bb >> V2_LIT_BITS) & ((1u << ((e >> 4) & 15u)) - 1u));
+        const uint32_t e2 = L.lit_fast[(need2 && (e & E_SUB)) ? idx : 0u];
+        e = need2 ? ((e & E_SUB) ? e2 : 0u) : e;
+      }
+    }
+    uint32_t l = e & 15u;                    // 0 => no such code (F_BAD)
+    const bool is_len = run && (e & E_LEN) != 0;
+    const bool is_eob = run && (e & E_EOB) != 0;
+    const bool is_lit = run && l != 0 && !(e & (E_LEN | E_EOB));
+    uint32_t bad = (run && l == 0) ? F_BAD : 0u;
+    if (!run) l = 0;
+    bb >>= l; bc -= (int)l; pos += l;
+    if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)(e >> 8); }
+    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 8); }
+    opos += is_lit ? 1u : 0u;
+    no += is_lit ? 1u : 0u;
+    if (__ballot(is_len) != 0ull) {
+      const uint32_t eb = is_len ? ((e >> 4) & 15u) : 0u;
+      const uint32_t ebv = eb == 15u ? 0u : eb;           // invalid length symbol: flagged below
+      const uint32_t mlen = ((e >> 8) & 511u) + ((uint32_t)bb & ((1u << ebv) - 1u));
+      bb >>= ebv; bc -= (int)ebv; pos += ebv;
+      {
+        const bool rf = is_len && bc <= 32;
+        const uint64_t w = L.stage[wp];
+        if (rf) { bb |= w << bc; bc += 32; wp++; }
+      }
+      uint32_t de = L.dist_fast[(uint32_t)bb & ((1u << V2_DIST_BITS) - 1u)];
+      {
+        const bool need2 = is_len && (de & 15u) == 0;
+        if (__ballot(need2) != 0ull) {
+          const uint32_t idx = ((de >> 8) & 0x7FFu) + ((uint32_t)(bb >> V2_DIST_BITS) & ((1u << ((de >> 4) & 15u)) - 1u));
+          const uint32_t d2 = L.dist_fast[(need2 && (de & E_SUB)) ? idx : 0u];
+          de = need2 ? ((de & E_SUB) ? d2 : 0u) : de;
+        }
+      }
+      const uint32_t dl = is_len ? (de & 15u) : 0u;
+      const uint32_t deb = is_len ? ((de >> 4) & 15u) : 0u;
+      const uint32_t debv = deb == 15u ? 0u : deb;
+      const uint32_t dist = (de >> 8) + ((uint32_t)(bb >> dl) & ((1u << debv) - 1u));
+      const uint32_t adv = dl + debv;
+      bb >>= adv; bc -= (int)adv; pos += adv;
+      uint32_t mbad = (is_len && (eb == 15u || dl == 0u || deb == 15u)) ? F_BAD : 0u;
+      if (WRITE) {
+        if (is_len && dist > opos) mbad = F_BAD;
+        if (is_len && !mbad)
+          mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)dist << 44);
+        mpos += (is_len && !mbad) ? 1u : 0u;
+      }
+      const bool ok = is_len && !mbad;
+      opos += ok ? mlen : 0u;
+      no += ok ? mlen : 0u;
+      nm += ok ? 1u : 0u;
+      bad |= mbad;
+    }
+    fl |= bad | (is_eob ? F_EOB : 0u);
+    run = run && fl == 0 && pos < limit;
+  }
+  if (active) {
+    // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no
+    // valid result, even if it stopped exactly on a true symbol boundary
+    if (!seen) { first = 0xFFFFFFFFu; no = 0; nm = 0; }  // never equals a predecessor's end: forces a re-decode
+    end_out = pos; nout = no; nmatch = nm; flags = fl; first_out = first;
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    uint32_t o = __shfl_up(inc, d, WAVE);
+    if (lane >= d) inc += o;
+  }
+  *total = __builtin_amdgcn_readlane(inc, 63);
+  return inc - v;
+}
+
+// unaligned vector access helpers (gfx950 runs with unaligned global access enabled)
+typedef uint32_t u32x4_raw __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) u32x4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) u64p { uint64_t v; };
+struct __attribute__((packed, aligned(1))) u32p { uint32_t v; };
+struct __attribute__((packed, aligned(1))) u16p { uint16_t v; };
+__device__ __forceinline__ u32x4 ld16(const uint8_t* p) { return *(const u32x4*)p; }
+__device__ __forceinline__ void st16(uint8_t* p, u32x4 v) { *(u32x4*)p = v; }
+__device__ __forceinline__ void st8(uint8_t* p, uint64_t v) { ((u64p*)p)->v = v; }
+__device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { ((u32p*)p)->v = v; }
+__device__ __forceinline__ void st2(uint8_t* p, uint16_t v) { ((u16p*)p)->v = v; }
+
+// dependency-ordered copy of <= 64 matches (one per lane)
+__device__ void v2_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
+  const bool valid = lane < nm;
+  const uint32_t src_lo = m_dst - m_dist;
+  const uint32_t src_end = src_lo + m_len;
+  const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
+  const uint32_t first_dst = __builtin_amdgcn_readlane(m_dst, 0);
+  uint64_t dep = 0;
+  const bool maybe = valid && src_hi > first_dst;
+  if (__ballot(maybe) != 0ull) {
+    // destinations are sorted and disjoint: the earlier matches overlapping [src_lo, src_hi) are the
+    // index range [first i with dst_end_i > src_lo, last i with dst_i < src_hi]; two binary searches
+    // over the lanes (ds_bpermute) instead of a 63-step sweep.
+    const uint32_t dend = valid ? m_dst + m_len : 0xFFFFFFFFu;
+    const uint32_t dbeg = valid ? m_dst : 0xFFFFFFFFu;
+    int lo1 = 0, hi1 = nm, lo2 = 0, hi2 = nm;
+#pragma unroll
+    for (int step = 0; step < 7; step++) {
+      const int mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
+      const uint32_t v1 = (uint32_t)__shfl((int)dend, mid1 & 63, WAVE);
+      const uint32_t v2 = (uint32_t)__shfl((int)dbeg, mid2 & 63, WAVE);
+      if (lo1 < hi1) { if (v1 > src_lo) hi1 = mid1; else lo1 = mid1 + 1; }
+      if (lo2 < hi2) { if (v2 >= src_hi) hi2 = mid2; else lo2 = mid2 + 1; }
+    }
+    // lo1 = first overlapping index, lo2 = count of matches with dst < src_hi
+    int a = lo1, b = lo2 - 1;
+    if (b > lane - 1) b = lane - 1;
+    if (maybe && a <= b) {
+      const uint64_t hi_mask = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+      dep = hi_mask & ~((1ull << a) - 1ull);
+    }
+  }
+  const uint64_t all = nm >= 64 ? ~0ull : ((1ull << nm) - 1ull);
+  uint64_t done = 0;
+  while (done != all) {
+    const bool ready = valid && !((done >> lane) & 1ull) && ((dep & ~done) == 0ull);
+    if (ready) {
+      uint8_t* d = out + m_dst;
+      const uint8_t* s = out + src_lo;
+      if (m_dist >= 16) {
+        // source and destination are >= 16 bytes apart: stream 16-byte unaligned vectors
+        uint32_t k = 0;
+        for (; k + 16 <= m_len; k += 16) st16(d + k, ld16(s + k));
+        const uint32_t rem = m_len - k;
+        if (rem) {
+          const u32x4 v = ld16(s + k);  // over-read is inside the (padded) buffer
+          uint8_t* t = d + k;
+          uint32_t o = 0;
+          if (rem & 8) { st8(t, (uint64_t)v.x | ((uint64_t)v.y << 32)); o = 8; }
+          if (rem & 4) { st4(t + o, o ? v.z : v.x); o += 4; }
+          // remaining 0..3 bytes come from dword (o/4) of v
+          const uint32_t w = o == 0 ? v.x : o == 4 ? v.y : o == 8 ? v.z : v.w;
+          if (rem & 2) { st2(t + o, (uint16_t)w); if (rem & 1) t[o + 2] = (uint8_t)(w >> 16); }
+          else if (rem & 1) t[o] = (uint8_t)w;
+        }
+      } else if (m_dist >= 4) {
+        uint32_t k = 0;
+        for (; k + 4 <= m_len; k += 4) {
+          uint8_t b0 = s[k], b1 = s[k + 1], b2 = s[k + 2], b3 = s[k + 3];
+          d[k] = b0; d[k + 1] = b1; d[k + 2] = b2; d[k + 3] = b3;
+        }
+        for (; k < m_len; k++) d[k] = s[k];
+      } else {
+        for (uint32_t k = 0; k < m_len; k++) d[k] = s[k];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    done |= __ballot(ready);
+  }
+}
+
+// Same dependency-ordered batch copy, but the round's output lives in the LDS window `win`
+// (absolute output position R maps to win[0]).  Sources before R are final bytes in HBM; sources at or
+// after R are in the window, so dependency rounds cost LDS latency instead of HBM round trips.
+__device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t R, int lane, int nm, uint32_t m_dst,
+                                     uint32_t m_len, uint32_t m_dist) {
+  const bool valid = lane < nm;
+  const uint32_t src_lo = m_dst - m_dist;
+  const uint32_t src_end = src_lo + m_len;
+  const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
+  const uint32_t first_dst = __builtin_amdgcn_readlane(m_dst, 0);
+  uint64_t dep = 0;
+  const bool maybe = valid && src_hi > first_dst;
+  if (__ballot(maybe) != 0ull) {
+    const uint32_t dend = valid ? m_dst + m_len : 0xFFFFFFFFu;
+    const uint32_t dbeg = valid ? m_dst : 0xFFFFFFFFu;
+    int lo1 = 0, hi1 = nm, lo2 = 0, hi2 = nm;
+#pragma unroll
+    for (int step = 0; step < 7; step++) {
+      const int mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
+      const uint32_t v1 = (uint32_t)__shfl((int)dend, mid1 & 63, WAVE);
+      const uint32_t v2 = (uint32_t)__shfl((int)dbeg, mid2 & 63, WAVE);
+      if (lo1 < hi1) { if (v1 > src_lo) hi1 = mid1; else lo1 = mid1 + 1; }
+      if (lo2 < hi2) { if (v2 >= src_hi) hi2 = mid2; else lo2 = mid2 + 1; }
+    }
+    int a = lo1, b = lo2 - 1;
+    if (b > lane - 1) b = lane - 1;
+    if (maybe && a <= b) {
+      const uint64_t hi_mask = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+      dep = hi_mask & ~((1ull << a) - 1ull);
+    }
+  }
+  // far part: the first n_far source bytes precede the window (final bytes in HBM) -- no dependency
+  uint32_t n_far = 0;
+  if (valid && src_lo < R) { n_far = R - src_lo; if (n_far > m_len) n_far = m_len; }
+  if (n_far) {
+    uint8_t* d = win + (m_dst - R);
+    const uint8_t* s = out + src_lo;
+    uint32_t k = 0;
+    for (; k + 16 <= n_far; k += 16) {
+      const u32x4 v = ld16(s + k);
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 16; q++) d[k + q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    }
+    if (k < n_far) {
+      const u32x4 v = ld16(s + k);
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int q = 0; q < 16; q++) if (k + q < n_far) d[k + q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    }
+  }
+  const uint64_t all = nm >= 64 ? ~0ull : ((1ull << nm) - 1ull);
+  uint64_t done = 0;
+  while (done != all) {
+    const bool ready = valid && !((done >> lane) & 1ull) && ((dep & ~done) == 0ull);
+    if (ready && n_far < m_len) {
+      uint8_t* d = win + (m_dst - R);
+      const uint8_t* s = win + (src_lo - R);  // only indexed at k >= n_far, where src_lo + k >= R
+      uint32_t k = n_far;
+      if (m_dist >= 4) {
+        for (; k + 4 <= m_len; k += 4) {
+          uint8_t b0 = s[k], b1 = s[k + 1], b2 = s[k + 2], b3 = s[k + 3];
+          d[k] = b0; d[k + 1] = b1; d[k + 2] = b2; d[k + 3] = b3;
+        }
+      }
+      for (; k < m_len; k++) d[k] = s[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    done |= __ballot(ready);
+  }
+}
+
+__global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __restrict__ comp,
+                                                           const uint64_t* __restrict__ blk_coff,
+                                                           const uint64_t* __restrict__ blk_uoff, uint8_t* out_all,
+                                                           uint32_t n_blocks, uint32_t* __restrict__ status,
+                                                           uint32_t* counter, unsigned long long* scratch,
+                                                           uint32_t scratch_stride, uint32_t* dbg, uint32_t ablate, uint32_t dbg_block) {
+  __shared__ V2Lds L;
+  const int lane = threadIdx.x;
+  unsigned long long* mlist = scratch + (size_t)blockIdx.x * scratch_stride;
+  uint32_t dbg_rounds = 0, dbg_passes = 0;
+  unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = 0;
+#define TICK() (t0 = dbg ? clock64() : 0)
+#define TOCK(i) do { if (dbg) { unsigned long long t1 = clock64(); tc[i] += t1 - t0; t0 = t1; } } while (0)
+
+  for (;;) {
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(counter, 1u);
+    b = uni2(b);
+    if (b >= n_blocks) break;
+
+    const uint64_t coff = blk_coff[b];
+    const uint64_t cend = blk_coff[b + 1];
+    const uint8_t* hdr = comp + coff;
+    uint8_t* out = out_all + blk_uoff[b];
+    const uint32_t isize = (uint32_t)(blk_uoff[b + 1] - blk_uoff[b]);
+    uint32_t st = INF_OK;
+    const uint32_t xlen = uni2((uint32_t)hdr[10] | ((uint32_t)hdr[11] << 8));
+    const uint32_t magic = uni2((uint32_t)hdr[0] | ((uint32_t)hdr[1] << 8) | ((uint32_t)hdr[2] << 16) | ((uint32_t)hdr[3] << 24));
+    if ((magic & 0x04FFFFFFu) != 0x04088B1Fu) {
+      if (lane == 0) status[b] = INF_BAD_HEADER;
+      continue;
+    }
+    const uint8_t* payload = hdr + 12 + xlen;
+    const uint64_t payload_len = (cend - coff) - 12 - xlen - 8;
+    // all bit positions are counted from the 4-byte aligned word at/before the payload
+    const uint32_t* base32 = (const uint32_t*)((uintptr_t)payload & ~(uintptr_t)3);
+    const uint64_t skew = (uint64_t)((uintptr_t)payload & 3) * 8;
+    const uint64_t end_bits = skew + payload_len * 8;
+    uint64_t P = skew;
+    uint32_t opos = 0;
+
+    for (;;) {  // DEFLATE blocks
+      TICK();
+      UBits in;
+      ub_init(in, base32, P, lane);
+      ub_refill(in, lane);
+      const uint32_t bfinal = ub_take(in, 1);
+      const uint32_t btype = ub_take(in, 2);
+      if (btype == 3) { st = INF_BAD_BTYPE; break; }
+      if (btype == 0) {
+        ub_take(in, in.bc & 7);
+        const uint64_t bytepos = (ub_bitpos(in) - skew) >> 3;  // relative to payload
+        const uint8_t* p = payload + bytepos;
+        const uint32_t len = uni2((uint32_t)p[0] | ((uint32_t)p[1] << 8));
+        const uint32_t nlen = uni2((uint32_t)p[2] | ((uint32_t)p[3] << 8));
+        if ((len ^ 0xFFFFu) != nlen) { st = INF_BAD_STORED; break; }
+        if (opos + len > isize || bytepos + 4 + len > payload_len) { st = INF_OVERRUN; break; }
+        p += 4;
+        for (uint32_t k = lane; k < len; k += WAVE) out[opos + k] = p[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        opos += len;
+        P = skew + (bytepos + 4 + len) * 8;
+        if (bfinal) break;
+        continue;
+      }
+      if (btype == 1) {
+        for (int i = lane; i < 320; i += WAVE) {
+          uint8_t l;
+          if (i < 144) l = 8; else if (i < 256) l = 9; else if (i < 280) l = 7; else if (i < 288) l = 8; else l = 5;
+          L.lens[i] = l;
+        }
+        __syncthreads();
+      } else {
+        ub_refill(in, lane);
+        const uint32_t hlit = ub_take(in, 5) + 257;
+        const uint32_t hdist = ub_take(in, 5) + 1;
+        const uint32_t hclen = ub_take(in, 4) + 4;
+        if (hlit > 286 || hdist > 30) { st = INF_BAD_CODE | (1u << 8); break; }
+        if (lane < 20) L.pre_lens[lane] = 0;
+        __syncthreads();
+        {
+          const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+          for (uint32_t i = 0; i < hclen; i++) {
+            ub_refill(in, lane);
+            uint32_t v = ub_take(in, 3);
+            if (lane == 0) L.pre_lens[order[i]] = (uint8_t)v;
+          }
+        }
+        __syncthreads();
+        for (int i = lane; i < 128; i += WAVE) L.pre_fast[i] = 0;
+        __syncthreads();
+        if (lane == 0) {
+          uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int s = 0; s < 19; s++) cnt[L.pre_lens[s]]++;
+          cnt[0] = 0;
+          uint32_t next[8];
+          uint32_t code = 0;
+          for (int l = 1; l <= 7; l++) { code = (code + cnt[l - 1]) << 1; next[l] = code; }
+          for (int s = 0; s < 19; s++) {
+            int l = L.pre_lens[s];
+            if (!l) continue;
+            uint32_t r = bitrev2(next[l]++, l);
+            for (uint32_t i = r; i < 128; i += (1u << l)) L.pre_fast[i] = (uint8_t)((s << 3) | l);
+          }
+        }
+        __syncthreads();
+        {
+          const uint32_t total = hlit + hdist;
+          uint32_t i = 0, prev = 0;
+          int bad = 0;
+          while (i < total) {
+            ub_refill(in, lane);
+            uint32_t e = uni2(L.pre_fast[(uint32_t)in.bb & 127]);
+            uint32_t l = e & 7, sym = e >> 3;
+            if (l == 0) { bad = 1; break; }
+            ub_take(in, l);
+            if (sym < 16) {
+              if (lane == 0) L.lens[i < hlit ? i : 288 + (i - hlit)] = (uint8_t)sym;
+              prev = sym;
+              i++;
+            } else {
+              uint32_t rep, val;
+              if (sym == 16) { if (i == 0) { bad = 1; break; } rep = 3 + ub_take(in, 2); val = prev; }
+              else if (sym == 17) { rep = 3 + ub_take(in, 3); val = 0; }
+              else { rep = 11 + ub_take(in, 7); val = 0; }
+              if (i + rep > total) { bad = 1; break; }
+              if (lane == 0)
+                for (uint32_t k = 0; k < rep; k++) {
+                  uint32_t j = i + k;
+                  L.lens[j < hlit ? j : 288 + (j - hlit)] = (uint8_t)val;
+                }
+              if (sym != 16) prev = 0;
+              i += rep;
+            }
+          }
+          if (bad) { st = INF_BAD_CODE | (2u << 8); break; }
+          for (uint32_t k = hlit + lane; k < 288; k += WAVE) L.lens[k] = 0;
+          for (uint32_t k = 288 + hdist + lane; k < 320; k += WAVE) L.lens[k] = 0;
+          __syncthreads();
+        }
+      }
+      if (v2_build(L, L.lens, 288, L.lit_fast, V2_LIT_BITS, V2_LIT_SUB, L.lit_sorted, L.lit_count, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
+      if (v2_build(L, L.lens + 288, 32, L.dist_fast, V2_DIST_BITS, V2_DIST_SUB, L.dist_sorted, L.dist_count, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
+      P = ub_bitpos(in);
+      TOCK(0);
+
+      // ---- rounds over the block body ----
+      bool block_done = false;
+      while (!block_done) {
+        // sub-stream size: cover what is left of the payload with 64 lanes, 5..17 dwords (odd)
+        uint64_t rem_bits = end_bits > P ? end_bits - P : 0;
+        uint32_t sub_dw = (uint32_t)((rem_bits + 64ull * 32 - 1) / (64ull * 32));
+        if (sub_dw > (uint32_t)V2_MAX_SUB_DW) sub_dw = V2_MAX_SUB_DW;
+        if (sub_dw < 5) sub_dw = 5;
+        sub_dw |= 1u;
+        const uint32_t subb = sub_dw * 32;
+        const uint64_t wb = P >> 5;
+        const uint32_t nstage = 64 * sub_dw + 6;
+        __syncthreads();
+        for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
+        __syncthreads();
+        TOCK(1);
+        const uint32_t rel0 = (uint32_t)(P & 31);
+        const uint32_t bnd = rel0 + (uint32_t)lane * subb;
+        const uint32_t limit = rel0 + (uint32_t)(lane + 1) * subb;
+        uint32_t start = bnd, end = bnd, nout = 0, nmatch = 0, flags = 0;
+        {
+          const uint32_t ov = lane == 0 ? 0u : (uint32_t)V2_OV_BITS;
+          uint32_t first = bnd;
+          v2_pass<0>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first);
+          start = first;  // counts are valid from here
+        }
+        dbg_passes++;
+        for (int it = 0; it < 66; it++) {
+          const unsigned long long stopm = __ballot(flags != 0);
+          const int first_stop = stopm ? __builtin_ctzll(stopm) : 64;
+          uint32_t pe = __shfl_up(end, 1, WAVE);
+          const bool alive = lane > 0 && lane <= first_stop;
+          const bool changed = alive && pe != start;
+          if (__ballot(changed) == 0ull) break;
+          if (changed) start = pe;
+          // a lane whose corrected start already lies beyond its limit owns no symbols
+          if (changed && start >= limit) { end = start; nout = 0; nmatch = 0; flags = 0; }
+          { uint32_t f_ = 0; v2_pass<0>(L, changed && start < limit, start, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, 0, f_); }
+          dbg_passes++;
+        }
+        TOCK(2);
+        const unsigned long long stopm = __ballot(flags != 0);
+        const int last = stopm ? __builtin_ctzll(stopm) : 63;
+        const uint32_t last_flags = __builtin_amdgcn_readlane(flags, last);
+        if (stopm && (last_flags & F_BAD)) { st = INF_BAD_CODE | (5u << 8); break; }
+        const bool valid = lane <= last;
+        uint32_t tot_out, tot_m;
+        const uint32_t obase = opos + wave_excl_scan_u32(valid ? nout : 0u, lane, &tot_out);
+        const uint32_t mbase = wave_excl_scan_u32(valid ? nmatch : 0u, lane, &tot_m);
+        if (opos + tot_out > isize) { st = INF_OVERRUN; break; }
+        if (tot_m > scratch_stride) { st = INF_OVERRUN | (1u << 8); break; }
+        // write pass: literals to the (LDS or HBM) window, matches to the list
+        const bool use_win = tot_out <= (uint32_t)V2_WIN;
+        {
+          uint32_t e2 = 0, o2 = 0, m2 = 0, f2 = 0;
+          if (!(ablate & 2u)) {
+            uint32_t f_ = 0;
+            if (use_win) v2_pass<2>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_);
+            else v2_pass<1>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_);
+          }
+          dbg_passes++;
+          if (__ballot(valid && (f2 & F_BAD)) != 0ull) { st = INF_BAD_DIST; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        TOCK(3);
+        if (!(ablate & 1u)) {
+          unsigned long long m_next = 0;
+          if ((uint32_t)lane < tot_m) m_next = mlist[lane];
+          for (uint32_t k = 0; k < tot_m; k += WAVE) {
+            const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
+            const unsigned long long m = m_next;
+            if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
+            const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
+            if (use_win) v2_resolve_batch_win(L.win, out, opos, lane, (int)nmb, md, ml, mdist);
+            else v2_resolve_batch(out, lane, (int)nmb, md, ml, mdist);
+          }
+          if (use_win) {
+            // coalesced flush of the window (16 B per lane; the destination may be unaligned)
+            uint8_t* dstp = out + opos;
+            const uint32_t full = tot_out & ~15u;
+            for (uint32_t i = (uint32_t)lane * 16; i < full; i += WAVE * 16) {
+              const uint32_t* w = (const uint32_t*)(L.win + i);
+              u32x4 v;
+              v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+              st16(dstp + i, v);
+            }
+            if ((uint32_t)lane < (tot_out & 15u)) dstp[full + lane] = L.win[full + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
+        }
+        TOCK(4);
+        opos += tot_out;
+        dbg_rounds++;
+        const uint32_t end_last = __builtin_amdgcn_readlane(end, last);
+        P = (wb << 5) + end_last;
+        if (stopm) block_done = true;
+        else if (P >= end_bits + 64) { st = INF_OVERRUN | (2u << 8); break; }
+      }
+      if (st != INF_OK) break;
+      if (bfinal) break;
+    }
+    if (st == INF_OK && opos != isize) st = INF_SIZE_MISMATCH;
+    if (ablate) st = INF_OK;
+    if (lane == 0) status[b] = st;
+  }
+  if (dbg && lane == 0) {
+    atomicAdd(&dbg[0], dbg_rounds);
+    atomicAdd(&dbg[1], dbg_passes);
+    for (int i = 0; i < 5; i++) atomicAdd((unsigned long long*)(dbg + 2) + i, tc[i]);
+  }
+}
+
+static uint32_t g_v2_grid = 0;
+void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
+                            uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
+                            uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st) {
+  if (!n_blocks) return;
+  const char* ab = getenv("BIOSCAN_V2_ABLATE");
+  const uint32_t ablate = (ab && n_blocks > 64) ? (uint32_t)atoi(ab) : 0u;
+  const char* db = getenv("BIOSCAN_DBG_BLOCK");
+  const uint32_t dbg_block = db ? (uint32_t)atoi(db) : 0xFFFFFFFFu;
+  (void)g_v2_grid;
+  hipMemsetAsync(counter, 0, 4, st);
+  uint32_t g = grid < n_blocks ? grid : n_blocks;
+  hipLaunchKernelGGL(k_bgzf_inflate_v2, dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status, counter,
+                     scratch, scratch_stride, dbg, ablate, dbg_block);
+}
+
+}  // namespace bioscan

@@ -21,6 +21,12 @@ enum InflateStatus : uint32_t {
 // BGZF member i, blk_uoff[i] = offset of its payload in `out`; blk_uoff[n] = total.
 void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
                          uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
+// K1 v2 (inflate_v2.hip): wave-parallel Huffman decode, persistent grid.  counter: 1 u32; scratch:
+// grid * scratch_stride u64 match-list entries; dbg: 2 u32 counters (rounds, passes) or nullptr.
+constexpr uint32_t V2_SCRATCH_STRIDE = 19456;
+void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
+                            uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
+                            uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st);
 // K2: CRC32 of each inflated block vs the BGZF trailer (validation mode).
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
                        const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
