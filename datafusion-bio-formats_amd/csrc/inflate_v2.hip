@@ -745,6 +745,11 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
   }
 }
 
+int v2_resident_wg_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v2, WAVE, 0) != hipSuccess || n < 1) n = 8;
+  return n;
+}
 static uint32_t g_v2_grid = 0;
 void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,

@@ -24,6 +24,7 @@ void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const ui
 // K1 v2 (inflate_v2.hip): wave-parallel Huffman decode, persistent grid.  counter: 1 u32; scratch:
 // grid * scratch_stride u64 match-list entries; dbg: 2 u32 counters (rounds, passes) or nullptr.
 constexpr uint32_t V2_SCRATCH_STRIDE = 19456;
+int v2_resident_wg_per_cu();  // occupancy of k_bgzf_inflate_v2 (workgroups per CU) from the HIP occupancy API
 void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st);

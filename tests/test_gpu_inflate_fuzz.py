@@ -1,0 +1,89 @@
+"""GPU: K1 parity against zlib on synthetic BGZF members that exercise every DEFLATE block type
+and the edge cases of the format (stored / fixed / dynamic blocks, several blocks per member, empty
+members, 1-byte members, 64 KiB members, long runs, incompressible data, long-distance matches)."""
+import os
+import random
+import struct
+import zlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def member(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, chunks=None) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    if chunks:
+        body = b""
+        o = 0
+        for n in chunks:                      # Z_FULL_FLUSH forces several DEFLATE blocks in one member
+            body += c.compress(payload[o:o + n]) + c.flush(zlib.Z_FULL_FLUSH)
+            o += n
+        body += c.compress(payload[o:]) + c.flush()
+    else:
+        body = c.compress(payload) + c.flush()
+    total = 18 + len(body) + 8
+    assert total <= 65536, total
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + body +
+            struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def corpus(rng):
+    text = (b"@SIM:1:1000:9642:18772\nACGTTGCAACGT\n+\nIIIIHHHGGFFF\n" * 1200)[:60000]
+    rnd = bytes(rng.getrandbits(8) for _ in range(30000))
+    runs = b"".join(bytes([rng.randrange(4) + 65]) * rng.randrange(1, 400) for _ in range(300))[:65000]
+    far = rnd[:20000] + bytes(12000) + rnd[:20000]          # matches at distance 32000
+    cases = [b"", b"x", b"ab" * 3, text, rnd, runs, far, bytes(65280), bytes(range(256)) * 255]
+    out = []
+    for p in cases:
+        out.append(member(p, 6))
+        out.append(member(p, 1))
+        out.append(member(p, 9))
+        out.append(member(p[:40000], 0))                                        # stored blocks
+        out.append(member(p, 6, zlib.Z_FIXED))                                  # fixed Huffman
+        out.append(member(p, 6, zlib.Z_HUFFMAN_ONLY))
+        out.append(member(p, 6, zlib.Z_RLE))
+        if len(p) > 3000:
+            out.append(member(p, 6, chunks=[1000, 1, 1500]))                    # several blocks / member
+            out.append(member(p[:30000], 0, chunks=[7, 5000]))                  # stored + stored
+            out.append(member(p, 6, zlib.Z_FIXED, chunks=[len(p) // 2]))
+    return out
+
+
+def test_inflate_block_types_vs_zlib(pkg, oracle):
+    rng = random.Random(99)
+    members = corpus(rng)
+    rng.shuffle(members)
+    data = b"".join(members) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    want, _ = oracle.bgzf_inflate_all(data)
+    got, _ = pkg.bgzf_inflate(data)
+    assert len(got) == len(want)
+    assert got == want
+
+
+def test_inflate_random_records(pkg, oracle):
+    rng = random.Random(7)
+    members = []
+    for _ in range(300):
+        n = rng.choice([1, 2, 17, 300, 5000, 30000, 65000])
+        alphabet = rng.choice([2, 4, 20, 256])
+        p = bytes(rng.randrange(alphabet) for _ in range(n))
+        members.append(member(p, rng.choice([1, 4, 6, 9])))
+    data = b"".join(members)
+    want, _ = oracle.bgzf_inflate_all(data)
+    got, _ = pkg.bgzf_inflate(data)
+    assert got == want
+
+
+def test_corrupt_members_are_rejected(pkg):
+    good = member(b"hello world, hello world, hello world" * 50)
+    bad_crc = bytearray(good)
+    bad_crc[-8] ^= 0xFF
+    with pytest.raises(pkg.BioscanError, match="CRC32"):
+        pkg.bgzf_inflate(bytes(bad_crc))
+    bad_body = bytearray(good)
+    bad_body[25] ^= 0x55
+    with pytest.raises(pkg.BioscanError):
+        pkg.bgzf_inflate(bytes(bad_body))
+    with pytest.raises(pkg.BioscanError, match="BGZF"):
+        pkg.bgzf_inflate(b"\x1f\x8b\x08\x00" + bytes(40))
