@@ -36,6 +36,10 @@ def main():
     ap.add_argument("--cpu-sample-blocks", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-file", action="store_true")
+    ap.add_argument("--mode", default="sequential", choices=["sequential", "indexed"],
+                    help="sequential: each rank scans its own file as one partition (weak scaling, default). "
+                         "indexed: every rank opens the SAME file, the BAI plan (target_partitions = 8 x ranks) is "
+                         "sharded in order across ranks and each rank inflates only its partitions' members (strong scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,7 +65,8 @@ def main():
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(16, ncpu // max(1, world if world > 1 else 1)))
     t0 = time.time()
-    meta = json.loads(subprocess.check_output([synth, path, str(args.blocks), str(42 + rank), str(gen_threads)]).decode())
+    seed = 42 if args.mode == "indexed" else 42 + rank
+    meta = json.loads(subprocess.check_output([synth, path, str(args.blocks), str(seed), str(gen_threads)]).decode())
     t_gen = time.time() - t0
 
     # ---- CPU baseline (rank 0, N == 1 only): the C oracle on a bounded sample of the same file ----
@@ -87,7 +92,8 @@ def main():
 
     # ---- provider: load + make the compressed bytes resident in HBM (outside the timed region) ----
     t0 = time.time()
-    prov = pkg.BamTableProvider(path, None, True, None, index_path="", device_id=local_rank)
+    prov = pkg.BamTableProvider(path, None, True, None, index_path=None if args.mode == "indexed" else "",
+                                device_id=local_rank)
     prov.make_resident()
     t_load = time.time() - t0
     if not args.keep_file:
@@ -103,8 +109,27 @@ def main():
     else:
         names = prov.schema().names
         projection = [names.index(c) for c in args.projection.split(",")]
-    plan = prov.scan(projection=projection, target_partitions=1)
-    assert plan.num_partitions() == 1
+    if args.mode == "indexed":
+        plan = prov.scan(projection=projection, target_partitions=8 * world)
+        weights = [plan.partition_estimated_bytes(p) for p in range(plan.num_partitions())]
+        my_parts = pkg.shard_partitions_in_order(weights, world)[rank]
+    else:
+        plan = prov.scan(projection=projection, target_partitions=1)
+        assert plan.num_partitions() == 1
+        my_parts = [0]
+
+    def run_step():
+        tot = None
+        for p in my_parts:
+            st = plan.execute_device(p, args.batch_size)
+            if tot is None:
+                tot = dict(st)
+            else:
+                for k in ("n_blocks", "compressed_bytes", "inflated_bytes", "arrow_bytes", "n_records", "n_rows", "ms_inflate",
+                          "ms_chain", "ms_extract", "ms_crc", "ms_keys", "ms_select", "ms_wall"):
+                    tot[k] += st[k]
+                tot["chain_iterations"] = max(tot["chain_iterations"], st["chain_iterations"])
+        return tot
 
     def sync():
         if world > 1:
@@ -113,12 +138,12 @@ def main():
 
     stats = None
     for _ in range(args.warmup):
-        stats = plan.execute_device(0, args.batch_size)
+        stats = run_step()
     sync()
     t0 = time.perf_counter()
     infl_ms, chain_ms, extract_ms = [], [], []
     for _ in range(args.steps):
-        stats = plan.execute_device(0, args.batch_size)
+        stats = run_step()
         infl_ms.append(stats["ms_inflate"])
         chain_ms.append(stats["ms_chain"])
         extract_ms.append(stats["ms_extract"])
@@ -136,6 +161,22 @@ def main():
         tot_rows, tot_u, tot_c, tot_a = (float(stats["n_rows"]), float(stats["inflated_bytes"]),
                                          float(stats["compressed_bytes"]), float(stats["arrow_bytes"]))
 
+    def pmc_traffic_per_member():
+        """HBM bytes per BGZF member of K1 from the committed rocprofv3 PMC passes (separate
+        FETCH_SIZE / WRITE_SIZE runs of this bench at 65 536 members, values in KiB as reported)."""
+        import csv
+        import glob
+        tot = 0.0
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"v2_pmc_{c}_65536blocks.csv")))
+            if not fs:
+                return None
+            rows = [r for r in csv.DictReader(open(fs[-1])) if "k_bgzf_inflate_v2" in r["Kernel_Name"] and int(r["Grid_Size"]) > 6400]
+            if not rows:
+                return None
+            tot += sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
+        return tot / 65536.0
+
     if rank == 0:
         per_step = elapsed / args.steps
         avg_infl = sum(infl_ms) / len(infl_ms)
@@ -144,11 +185,11 @@ def main():
         out = {
             "metric": "bgzf_bam_full_scan_records_per_sec", "value": round(tot_rows / per_step / 1e6, 3), "unit": "Mrec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.mode == "indexed" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BGZF-BAM full-table scan (config 2), synthetic 150bp paired reads, seed 42",
                        "n_blocks_per_gpu": meta["n_blocks"], "compressed_bytes_per_gpu": meta["compressed_bytes"],
                        "inflated_bytes_per_gpu": meta["inflated_bytes"], "records_per_gpu": meta["n_records"],
-                       "projection": args.projection, "batch_size": args.batch_size, "deflate_level": meta["level"],
+                       "projection": args.projection, "batch_size": args.batch_size, "mode": args.mode, "deflate_level": meta["level"],
                        "deflater": meta["deflate"], "parallelism": f"{world} independent block-range shard(s), no collective"},
             "decoded_GB_s": round(tot_u / per_step / 1e9, 3),
             "pipeline_algorithmic_GB_s": round((tot_c + 2 * tot_u + tot_a) / per_step / 1e9, 3),
@@ -157,8 +198,11 @@ def main():
                          "extract": round(sum(extract_ms) / len(extract_ms), 3), "crc32": round(stats["ms_crc"], 3),
                          "keys": round(stats["ms_keys"], 3), "select": round(stats["ms_select"], 3),
                          "wall_last_step": round(stats["ms_wall"], 3), "chain_iterations": stats["chain_iterations"]},
-            "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate_v2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": (int(pmc_traffic_per_member() * stats["n_blocks"]) if pmc_traffic_per_member() else None),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01/v2_pmc_*), "
+                                           "per-member average x members of this launch; FETCH_SIZE as reported (uncorrected)",
                          "algorithmic_bytes_per_launch": int(c + u), "avg_launch_ms": round(avg_infl, 3)},
             "cpu_baseline": cpu,
             "setup_s": {"generate": round(t_gen, 1), "load_and_h2d": round(t_load, 1)},

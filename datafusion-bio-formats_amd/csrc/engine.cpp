@@ -60,6 +60,15 @@ static const char* inflate_status_str(uint32_t s) {
   }
 }
 
+// members [b_lo, b_hi) + the record-aligned window of their inflated bytes that belongs to the caller
+struct DecodeRange {
+  uint32_t b_lo = 0, b_hi = 0;
+  uint64_t first_rel = 0, stop_rel = 0;  // relative to the range's first inflated byte
+  bool operator==(const DecodeRange& o) const {
+    return b_lo == o.b_lo && b_hi == o.b_hi && first_rel == o.first_rel && stop_rel == o.stop_rel;
+  }
+};
+
 // -------------------------------------------------------------------------------------------------
 // Provider
 // -------------------------------------------------------------------------------------------------
@@ -95,6 +104,7 @@ struct Provider {
   uint32_t v2_grid = 0;
 
   bool decoded = false;
+  DecodeRange dec_range;
   DevBuf<uint8_t> d_u;
   DevBuf<uint64_t> d_rec_off;
   uint64_t n_rec = 0;
@@ -109,6 +119,12 @@ struct Provider {
   }
 
   uint32_t n_blocks() const { return (uint32_t)(blk_coff.size() - 1); }
+  DecodeRange whole_file() const {
+    DecodeRange r;
+    r.b_lo = 0; r.b_hi = n_blocks();
+    r.first_rel = hdr.first_record_offset; r.stop_rel = ulen;
+    return r;
+  }
 
   void set_device() { HIP_CHECK(hipSetDevice(device)); }
 
@@ -212,14 +228,20 @@ struct Provider {
     if (!len.empty()) HIP_CHECK(hipMemcpy(d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
   }
 
-  void launch_inflate(uint8_t* dst, uint32_t nb) {
+  // Inflate members [b0, b0+nb) so that member b0's payload lands at dst[0]: the kernels index the
+  // output by absolute inflated offsets, so they get the base pointer shifted back by blk_uoff[b0].
+  void launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0 = 0) {
+    uint8_t* base = dst - blk_uoff[b0];
     if (getenv("BIOSCAN_INFLATE_V1")) {
-      launch_bgzf_inflate(d_comp.p, d_coff.p, d_uoff.p, dst, nb, d_status.p, stream);
+      launch_bgzf_inflate(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, stream);
     } else {
       HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
-      launch_bgzf_inflate_v2(d_comp.p, d_coff.p, d_uoff.p, dst, nb, d_status.p, d_v2_ctr.p, d_v2_scratch.p, V2_SCRATCH_STRIDE,
-                             v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
+      launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
+                             V2_SCRATCH_STRIDE, v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
     }
+  }
+  void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0) {
+    launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);
   }
   void report_v2_debug(uint32_t nb) {
     if (!getenv("BIOSCAN_DEBUG") || getenv("BIOSCAN_INFLATE_V1")) return;
@@ -252,7 +274,7 @@ struct Provider {
     uint64_t bytes = blk_uoff[b1];
     DevBuf<uint8_t> tmp(bytes + 64);
     launch_inflate(tmp.p, b1);
-    launch_bgzf_crc32(d_comp.p, d_coff.p, d_uoff.p, tmp.p, b1, d_status.p, stream);
+    launch_crc(tmp.p, b1);
     HIP_CHECK(hipStreamSynchronize(stream));
     check_inflate_status(0, b1);
     std::vector<uint8_t> out(bytes);
@@ -261,54 +283,60 @@ struct Provider {
   }
 
   // Full decode: inflate every block, find every record, build the key table.  Cached.
-  void decode(bool force) {
+  // Decode members [r.b_lo, r.b_hi): inflate, CRC-check, find every record that starts in
+  // [r.first_rel, r.stop_rel) of the range's inflated bytes, build the key table.  One range is cached.
+  void decode(bool force, const DecodeRange& r) {
     std::lock_guard<std::mutex> lk(mu);
-    if (decoded && !force) return;
+    if (decoded && !force && r == dec_range) return;
     make_resident();
     set_device();
+    decoded = false;
+    const uint32_t nb_r = r.b_hi - r.b_lo;
+    const uint64_t ulen = blk_uoff[r.b_hi] - blk_uoff[r.b_lo];  // shadows the file total on purpose
+    const uint64_t stop = r.stop_rel;
     bioscan_scan_stats s{};
-    s.n_blocks = n_blocks();
-    s.compressed_bytes = file_len;
+    s.n_blocks = nb_r;
+    s.compressed_bytes = blk_coff[r.b_hi] - blk_coff[r.b_lo];
     s.inflated_bytes = ulen;
     StageTimer t(stream), tt(stream);
     tt.start();
     if (d_u.n < ulen + 64) d_u.alloc(ulen + 64);
     t.start();
-    launch_inflate(d_u.p, n_blocks());
+    launch_inflate(d_u.p, nb_r, r.b_lo);
     s.ms_inflate = t.stop();
-    report_v2_debug(n_blocks());
+    report_v2_debug(nb_r);
     if (getenv("BIOSCAN_V2_ABLATE")) {
       fprintf(stderr, "[bioscan] ablate=%s inflate_ms=%.3f\n", getenv("BIOSCAN_V2_ABLATE"), s.ms_inflate);
       throw Error("ablation run: timing only");
     }
     t.start();
-    launch_bgzf_crc32(d_comp.p, d_coff.p, d_uoff.p, d_u.p, n_blocks(), d_status.p, stream);
+    launch_crc(d_u.p, nb_r, r.b_lo);
     s.ms_crc = t.stop();
-    check_inflate_status(0, n_blocks());
+    check_inflate_status(r.b_lo, nb_r);
 
-    // ---- record chain ----
+    // ---- record chain: records starting in [first_rec, stop) ----
     t.start();
-    const uint64_t first_rec = hdr.first_record_offset;
-    if (first_rec > ulen) throw Error("BAM read error: header extends past end of data");
-    const uint64_t nseg = std::max<uint64_t>((ulen + SEG_BYTES - 1) / SEG_BYTES, 1);
+    const uint64_t first_rec = r.first_rel;
+    if (first_rec > stop || stop > ulen) throw Error("BAM read error: record range extends past end of data");
+    const uint64_t nseg = std::max<uint64_t>((stop + SEG_BYTES - 1) / SEG_BYTES, 1);
     DevBuf<uint64_t> entry(nseg), exit_(nseg), base(nseg + 1), tmp(scan_tmp_elems(nseg));
     DevBuf<uint32_t> count(nseg), dirty(nseg), ctr(2);
     HIP_CHECK(hipMemsetAsync(ctr.p, 0, 8, stream));
     HIP_CHECK(hipMemsetAsync(dirty.p, 0, nseg * 4, stream));
     ChainBuffers cb{entry.p, exit_.p, count.p, dirty.p, ctr.p, ctr.p + 1};
-    launch_seg_guess(d_u.p, ulen, first_rec, nseg, (int32_t)hdr.ref_names.size(), cb, stream);
-    launch_seg_walk(d_u.p, ulen, nseg, cb, 0, stream);
+    launch_seg_guess(d_u.p, stop, first_rec, nseg, (int32_t)hdr.ref_names.size(), cb, stream);
+    launch_seg_walk(d_u.p, stop, nseg, cb, 0, stream);
     for (int iter = 0;; iter++) {
       s.chain_iterations = (uint64_t)iter + 1;
       HIP_CHECK(hipMemsetAsync(ctr.p, 0, 4, stream));
-      launch_seg_verify(ulen, first_rec, nseg, cb, stream);
+      launch_seg_verify(stop, first_rec, nseg, cb, stream);
       uint32_t nfix = 0;
       HIP_CHECK(hipMemcpyAsync(&nfix, ctr.p, 4, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
       if (getenv("BIOSCAN_DEBUG")) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
       if (nfix == 0) break;
       if ((uint64_t)iter > nseg + 2) throw Error("record boundary scan did not converge");
-      launch_seg_walk(d_u.p, ulen, nseg, cb, 1, stream);
+      launch_seg_walk(d_u.p, stop, nseg, cb, 1, stream);
     }
     launch_exclusive_scan_u32_to_u64(count.p, base.p, nseg, tmp.p, stream);
     uint64_t total = 0;
@@ -316,7 +344,7 @@ struct Provider {
     HIP_CHECK(hipStreamSynchronize(stream));
     n_rec = total;
     if (d_rec_off.n < n_rec + 1) d_rec_off.alloc(n_rec + 1);
-    launch_seg_emit(d_u.p, ulen, nseg, cb, base.p, d_rec_off.p, stream);
+    launch_seg_emit(d_u.p, stop, nseg, cb, base.p, d_rec_off.p, stream);
     // last exit must be exactly the end of the stream
     {
       std::vector<uint64_t> ex(nseg), en(nseg);
@@ -329,7 +357,7 @@ struct Provider {
       for (uint64_t k = nseg; k-- > 0;)
         if (ex[k] != SEG_NONE) { last = ex[k]; break; }
       if (last == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
-      if (first_rec < ulen && last != ulen) throw Error("BAM read error: unexpected end of record stream");
+      if (first_rec < stop && last != stop) throw Error("BAM read error: unexpected end of record stream");
     }
     s.ms_chain = t.stop();
     s.n_records = n_rec;
@@ -344,6 +372,7 @@ struct Provider {
     if (!d_ref_name_off.p) upload_ref_names();
     s.ms_total_gpu = tt.stop();
     decode_stats = s;
+    dec_range = r;
     decoded = true;
   }
 };
@@ -496,6 +525,56 @@ static uint64_t voff_to_uoff(const Provider& p, uint64_t voff) {
   size_t b = it - p.blk_coff.begin();
   return p.blk_uoff[b] + (voff & 0xFFFF);
 }
+static size_t block_of_coff(const Provider& p, uint64_t c) {
+  auto it = std::lower_bound(p.blk_coff.begin(), p.blk_coff.end(), c);
+  if (it == p.blk_coff.end() || *it != c) throw Error("BGZF seek failed: virtual offset does not address a block start");
+  return (size_t)(it - p.blk_coff.begin());
+}
+
+// The members a partition has to inflate: the span of the BAI chunks of its regions.
+// Mapped regions -> noodles' merged chunk list (reg2bins, linear-index floor).  The no-coor
+// partition starts after the last placed record (coordinate-sorted file: everything a BAI indexes).
+// Per-reference unmapped tails scan "from the reference's last chunk until the reference changes",
+// which is only decidable by looking at every later record: those partitions decode the whole file.
+static DecodeRange partition_range(const Plan& plan, int partition) {
+  const Provider& p = *plan.prov;
+  if (!plan.indexed) return p.whole_file();
+  uint64_t lo = ~0ull, hi = 0;
+  bool to_eof = false;
+  for (auto& r : plan.assignments[partition].regions) {
+    if (r.unmapped_tail) {
+      if (r.chrom != "*") return p.whole_file();
+      if (!(p.bai.has_no_coor && p.bai.n_no_coor > 0)) continue;
+      uint64_t seek = 0;
+      for (auto& rf : p.bai.refs)
+        for (auto& b : rf.bins)
+          for (auto& c : b.second) seek = std::max(seek, c.second);
+      if (seek == 0) return p.whole_file();
+      lo = std::min(lo, seek);
+      to_eof = true;
+      continue;
+    }
+    long ref = -1;
+    for (size_t i = 0; i < p.hdr.ref_names.size(); i++) if (p.hdr.ref_names[i] == r.chrom) { ref = (long)i; break; }
+    if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
+    auto chunks = bai_query_chunks(p.bai, (size_t)ref, r.has_start, r.start, r.has_end, r.end);
+    for (auto& c : chunks) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
+  }
+  DecodeRange d;
+  if (lo == ~0ull) return d;  // nothing to read
+  d.b_lo = (uint32_t)block_of_coff(p, lo >> 16);
+  const uint64_t base = p.blk_uoff[d.b_lo];
+  d.first_rel = (lo & 0xFFFF);
+  if (to_eof) {
+    d.b_hi = p.n_blocks();
+    d.stop_rel = p.ulen - base;
+  } else {
+    const size_t be = block_of_coff(p, hi >> 16);
+    if ((hi & 0xFFFF) == 0) { d.b_hi = (uint32_t)be; d.stop_rel = p.blk_uoff[be] - base; }
+    else { d.b_hi = (uint32_t)be + 1; d.stop_rel = p.blk_uoff[be] + (hi & 0xFFFF) - base; }
+  }
+  return d;
+}
 
 // Select the rows of one partition, in region order (file order inside a region).
 static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_owned, const uint64_t** rows, uint64_t* n_rows) {
@@ -605,7 +684,7 @@ static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_
 static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
   Provider& p = *plan.prov;
   const auto wall0 = std::chrono::steady_clock::now();
-  p.decode(force_decode);
+  p.decode(force_decode, partition_range(plan, partition));
   std::lock_guard<std::mutex> lk(p.mu);
   p.set_device();
   hipStream_t st = p.stream;
@@ -1364,7 +1443,7 @@ int bioscan_bgzf_inflate(const uint8_t* data, size_t len, int32_t device_id, int
   t.start();
   p.launch_inflate(u.p, p.n_blocks());
   double ms = t.stop();
-  if (check_crc) launch_bgzf_crc32(p.d_comp.p, p.d_coff.p, p.d_uoff.p, u.p, p.n_blocks(), p.d_status.p, p.stream);
+  if (check_crc) p.launch_crc(u.p, p.n_blocks());
   HIP_CHECK(hipStreamSynchronize(p.stream));
   p.check_inflate_status(0, p.n_blocks());
   uint8_t* h = (uint8_t*)malloc(p.ulen ? p.ulen : 1);

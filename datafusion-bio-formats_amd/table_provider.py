@@ -292,6 +292,11 @@ class BamExec:
         load_library().bioscan_plan_partition_desc(self._h, partition, buf, 1 << 16)
         return buf.value.decode()
 
+    def partition_estimated_bytes(self, partition: int) -> int:
+        """PartitionAssignment.total_estimated_bytes (0 for the sequential single-partition plan)."""
+        d = self.partition_desc(partition)
+        return int(d.split("|", 1)[0]) if "|" in d else 0
+
     def execute(self, partition: int, batch_size: int = 8192) -> Iterator[pa.RecordBatch]:
         lib = load_library()
         st = C.c_void_p()

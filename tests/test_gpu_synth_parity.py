@@ -61,3 +61,30 @@ def test_partition_invariants(pkg, synth):
                 rows.extend(zip(*[b.column(i).to_pylist() for i in range(3)]))
         assert len(rows) == meta["n_records"], target
         assert sorted(rows, key=lambda r: (r[0], str(r[1]), r[2] or -1)) == base_rows, target
+
+
+def test_multi_gpu_sharding_reproduces_single_gpu_order(pkg, synth):
+    """contiguous runs of BAI partitions per GPU, no exchange.  Simulated on one GPU: the
+    ranks' shards, executed independently (each decodes only the BGZF members its chunks touch) and
+    concatenated in rank order, reproduce the single-GPU row order exactly."""
+    path, meta = synth
+    prov = pkg.BamTableProvider(path)
+    plan = prov.scan(projection=[0, 2], target_partitions=16)
+    n = plan.num_partitions()
+    single = []
+    for p in range(n):
+        for b in plan.execute(p, 8192):
+            single.extend(zip(b.column(0).to_pylist(), b.column(1).to_pylist()))
+    assert len(single) == meta["n_records"]
+    weights = [plan.partition_estimated_bytes(p) for p in range(n)]
+    for world in (2, 4, 8):
+        shards = pkg.shard_partitions_in_order(weights, world)
+        assert [i for s in shards for i in s] == list(range(n))
+        got = []
+        for rank in range(world):
+            rank_prov = pkg.BamTableProvider(path)          # every rank owns its provider / device buffers
+            rank_plan = rank_prov.scan(projection=[0, 2], target_partitions=16)
+            for p in shards[rank]:
+                for b in rank_plan.execute(p, 8192):
+                    got.extend(zip(b.column(0).to_pylist(), b.column(1).to_pylist()))
+        assert got == single, world
