@@ -75,6 +75,10 @@ struct DecodeRange {
 struct Provider {
   std::string path;
   int device = 0;
+  int kind = 0;              // 0 = BAM, 1 = FASTQ
+  int fq_compression = 0;    // FASTQ: 0 = none, 1 = BGZF
+  bool fq_has_gzi = false;
+  std::vector<std::pair<uint64_t, uint64_t>> gzi;  // (compressed, uncompressed) per block boundary
   bool zero_based = true;
   bool binary_cigar = false;
   std::vector<std::string> tag_fields;
@@ -390,7 +394,12 @@ struct Plan {
   bool empty = false;    // EmptyExec
   std::vector<PartitionAssignment> assignments;
   std::vector<Filter> residual;
-  int n_partitions() const { return empty ? 0 : (indexed ? (int)assignments.size() : 1); }
+  int fq_strategy = 0;  // FASTQ: 0 sequential, 1 BGZF block ranges, 2 plain byte ranges
+  std::vector<std::pair<uint64_t, uint64_t>> fq_parts;  // (start, end); end = ~0 for open-ended
+  int n_partitions() const {
+    if (prov && prov->kind == 1) return fq_strategy == 0 ? 1 : (int)fq_parts.size();
+    return empty ? 0 : (indexed ? (int)assignments.size() : 1);
+  }
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -681,6 +690,36 @@ static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_
   *n_rows = total;
 }
 
+// D2H of a partition's Arrow buffers (bioscan_next then exports zero-copy windows of them)
+static void copy_result_to_host(Result& res, hipStream_t st) {
+  const uint64_t n = res.n_rows, nb = res.n_batches(), nwords = (n + 63) / 64;
+  const uint32_t batch_size = res.batch_size;
+  for (auto& col : res.cols) {
+    if (col.d_values.p && n) {
+      uint64_t bytes = col.is_var() ? col.total_bytes : col.is_list() ? col.total_bytes * col.list_elem_bytes() : n * 4;
+      col.h_values.alloc(std::max<uint64_t>(bytes, 1));
+      if (bytes) HIP_CHECK(hipMemcpyAsync(col.h_values.p, col.d_values.p, bytes, hipMemcpyDeviceToHost, st));
+    }
+    if (col.d_off32.p && n) {
+      uint64_t bytes = nb * ((uint64_t)batch_size + 1) * 4;
+      col.h_off32.alloc(bytes);
+      HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, st));
+      col.h_batch_base.resize(nb);
+      for (uint64_t b = 0; b < nb; b++)
+        HIP_CHECK(hipMemcpyAsync(&col.h_batch_base[b], col.d_off64.p + b * batch_size, 8, hipMemcpyDeviceToHost, st));
+    }
+    if (col.d_valid.p && n) {
+      col.h_valid.alloc(nwords * 8 + 8);
+      HIP_CHECK(hipMemcpyAsync(col.h_valid.p, col.d_valid.p, nwords * 8, hipMemcpyDeviceToHost, st));
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (auto& col : res.cols) {
+    col.d_values.reset(); col.d_off64.reset(); col.d_off32.reset(); col.d_valid.reset();
+  }
+  res.on_host = true;
+}
+
 static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
   Provider& p = *plan.prov;
   const auto wall0 = std::chrono::steady_clock::now();
@@ -836,35 +875,208 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
   res->stats.ms_total_gpu = p.decode_stats.ms_total_gpu + res->stats.ms_select + res->stats.ms_extract;
   res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
-  if (to_host) {
-    for (auto& col : res->cols) {
-      // every projected core column other than the first occurrence is unsupported
-      if (col.d_values.p && n) {
-        uint64_t bytes = col.is_var() ? col.total_bytes : col.is_list() ? col.total_bytes * col.list_elem_bytes() : n * 4;
-        col.h_values.alloc(std::max<uint64_t>(bytes, 1));
-        if (bytes) HIP_CHECK(hipMemcpyAsync(col.h_values.p, col.d_values.p, bytes, hipMemcpyDeviceToHost, st));
+  if (to_host) copy_result_to_host(*res, st);
+  return res;
+}
+
+// -------------------------------------------------------------------------------------------------
+// FASTQ (bio-format-fastq/src/physical_exec.rs)
+// -------------------------------------------------------------------------------------------------
+static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partition, uint32_t batch_size, bool to_host) {
+  Provider& p = *plan.prov;
+  std::lock_guard<std::mutex> lk(p.mu);
+  const auto wall0 = std::chrono::steady_clock::now();
+  p.make_resident();
+  p.set_device();
+  hipStream_t st = p.stream;
+  auto res = std::make_shared<Result>();
+  res->batch_size = batch_size;
+  res->cols.resize(plan.out_fields.size());
+  for (size_t c = 0; c < plan.out_fields.size(); c++) res->cols[c].fd = plan.out_fields[c];
+  const bool bgzf = p.fq_compression == 1;
+  const uint64_t total_len = bgzf ? p.ulen : p.file_len;  // length of the decoded text
+  uint64_t start = 0, end = ~0ull;
+  if (plan.fq_strategy != 0) { start = plan.fq_parts[partition].first; end = plan.fq_parts[partition].second; }
+
+  // ownership threshold T (absolute decoded offset): a record belongs to the partition iff its '@'
+  // lies before T (physical_exec.rs:492-494 / :530-535)
+  uint64_t T = total_len;
+  uint32_t b_start = 0, b_T = 0;
+  if (bgzf) {
+    if (plan.fq_strategy == 1) {
+      auto it = std::lower_bound(p.blk_uoff.begin(), p.blk_uoff.end(), start);
+      if (it == p.blk_uoff.end() || *it != start) throw Error("GZI start offset does not address a block start");
+      b_start = (uint32_t)(it - p.blk_uoff.begin());
+      if (end != ~0ull) {
+        auto jt = std::lower_bound(p.blk_coff.begin(), p.blk_coff.end(), end);
+        b_T = (uint32_t)std::min<size_t>(jt - p.blk_coff.begin(), p.n_blocks());
+        T = p.blk_uoff[b_T];
+      } else b_T = p.n_blocks();
+    } else b_T = p.n_blocks();
+  } else if (plan.fq_strategy == 2) {
+    T = std::min<uint64_t>(end, total_len);
+  }
+
+  StageTimer t(st);
+  DevBuf<unsigned long long> d_res(2);
+  DevBuf<uint32_t> err(1);
+  DevBuf<uint64_t> nl, nl_base, tmp;
+  DevBuf<uint32_t> nl_cnt;
+  uint64_t n_nl = 0, x0 = 0, n_rows = 0, base = 0, hi = 0;
+  const uint8_t* u = nullptr;
+  uint32_t extra = 2;
+  for (;;) {
+    // ---- bytes of this attempt: [lo, hi) in decoded coordinates, held at u[0 .. hi-base) ----
+    uint32_t b_hi = 0;
+    if (bgzf) {
+      b_hi = std::min<uint32_t>(p.n_blocks(), b_T + extra);
+      base = p.blk_uoff[b_start];
+      hi = p.blk_uoff[b_hi];
+      const uint64_t bytes = hi - base;
+      if (p.d_u.n < bytes + 64) p.d_u.alloc(bytes + 64);
+      t.start();
+      p.launch_inflate(p.d_u.p, b_hi - b_start, b_start);
+      res->stats.ms_inflate += t.stop();
+      t.start();
+      p.launch_crc(p.d_u.p, b_hi - b_start, b_start);
+      res->stats.ms_crc += t.stop();
+      p.check_inflate_status(b_start, b_hi - b_start);
+      p.decoded = false;  // the BAM cache (if any) no longer describes d_u
+      u = p.d_u.p;
+      res->stats.n_blocks = b_hi - b_start;
+      res->stats.compressed_bytes = p.blk_coff[b_hi] - p.blk_coff[b_start];
+      res->stats.inflated_bytes = bytes;
+    } else {
+      base = 0;
+      hi = plan.fq_strategy == 2 ? std::min<uint64_t>(total_len, T + (uint64_t)extra * 65536) : total_len;
+      u = p.d_comp.p;
+      res->stats.inflated_bytes = hi - start;
+    }
+    const bool at_eof = hi == total_len;
+    t.start();
+    // ---- resync (only when the partition does not start at byte 0) ----
+    x0 = start - base;
+    bool none = false;
+    if (start > 0) {
+      std::vector<uint64_t> we, wc, wn;
+      if (bgzf) {
+        for (uint32_t b = b_start; b < b_hi; b++) {
+          we.push_back(p.blk_uoff[b + 1] - base);
+          wc.push_back(p.blk_coff[b]);
+          wn.push_back(p.blk_coff[b + 1]);
+        }
+      } else {
+        for (uint64_t w = start; w < hi; w += 8192) {  // std::io::BufReader default capacity
+          we.push_back(std::min<uint64_t>(w + 8192, hi) - base);
+          wc.push_back(0);
+          wn.push_back(0);
+        }
       }
-      if (col.d_off32.p && n) {
-        uint64_t bytes = nb * ((uint64_t)batch_size + 1) * 4;
-        col.h_off32.alloc(bytes);
-        HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, st));
-        // per-batch base offsets
-        std::vector<uint64_t> all(1);
-        col.h_batch_base.resize(nb);
-        for (uint64_t b = 0; b < nb; b++)
-          HIP_CHECK(hipMemcpyAsync(&col.h_batch_base[b], col.d_off64.p + b * batch_size, 8, hipMemcpyDeviceToHost, st));
+      DevBuf<uint64_t> d_we(we.size() + 1), d_wc(wc.size() + 1), d_wn(wn.size() + 1);
+      if (!we.empty()) {
+        HIP_CHECK(hipMemcpyAsync(d_we.p, we.data(), we.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_wc.p, wc.data(), wc.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_wn.p, wn.data(), wn.size() * 8, hipMemcpyHostToDevice, st));
       }
-      if (col.d_valid.p && n) {
-        col.h_valid.alloc(nwords * 8 + 8);
-        HIP_CHECK(hipMemcpyAsync(col.h_valid.p, col.d_valid.p, nwords * 8, hipMemcpyDeviceToHost, st));
+      launch_fastq_sync(u, start - base, hi - base, d_we.p, d_wc.p, d_wn.p, (uint32_t)we.size(), end, (bgzf && end != ~0ull) ? 1 : 0,
+                        d_res.p, st);
+      unsigned long long r = 0;
+      HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (r == ~0ull) {
+        if (!at_eof) { extra *= 4; continue; }  // ran out of decoded bytes while resynchronising
+        none = true;
+      } else {
+        x0 = r;
+        if (x0 >= hi - base && !at_eof) { extra *= 4; continue; }
       }
+    }
+    n_rows = 0;
+    n_nl = 0;
+    if (!none && x0 < hi - base) {
+      // ---- newline index of [x0, hi) ----
+      const uint64_t nch = nl_chunks(x0, hi - base);
+      nl_cnt.alloc(nch + 1);
+      nl_base.alloc(nch + 2);
+      tmp.alloc(scan_tmp_elems(nch));
+      launch_nl_count(u, x0, hi - base, nl_cnt.p, st);
+      launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
+      HIP_CHECK(hipMemcpyAsync(&n_nl, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      nl.alloc(n_nl + 1);
+      launch_nl_write(u, x0, hi - base, nl_base.p, nl.p, st);
+      // ---- how many records start before T ----
+      const uint64_t T_rel = T > base ? T - base : 0;
+      launch_fastq_count_owned(nl.p, n_nl, x0, hi - base, T_rel, d_res.p, st);
+      unsigned long long r = 0;
+      HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      n_rows = r;
+      // the last owned record must be complete: 4 newline-terminated lines, or the data really ends
+      if (n_rows * 4 > n_nl + (at_eof ? 1 : 0)) {
+        if (!at_eof) { extra *= 4; continue; }
+        throw Error("FASTQ read error: unexpected end of file inside a record");
+      }
+    }
+    break;
+  }
+  res->stats.ms_chain = t.stop();
+  if (plan.limit >= 0 && n_rows > (uint64_t)plan.limit) n_rows = (uint64_t)plan.limit;
+  res->n_rows = n_rows;
+  res->stats.n_records = n_rows;
+  res->stats.n_rows = n_rows;
+  const uint64_t n = n_rows, nwords = (n + 63) / 64, nb = res->n_batches();
+  t.start();
+  uint64_t arrow_bytes = 0;
+  if (n) {
+    HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
+    int col_of[4] = {-1, -1, -1, -1};
+    for (size_t c = 0; c < plan.out_fields.size(); c++) {
+      int src = plan.has_projection ? plan.projection[c] : (int)c;
+      if (col_of[src] < 0) col_of[src] = (int)c;
+    }
+    DevBuf<uint64_t> srcs[4];
+    FastqCols fc{};
+    uint64_t** sp[4] = {&fc.src_name, &fc.src_desc, &fc.src_seq, &fc.src_qual};
+    uint32_t** lp[4] = {&fc.len_name, &fc.len_desc, &fc.len_seq, &fc.len_qual};
+    for (int k = 0; k < 4; k++) {
+      if (col_of[k] < 0) continue;
+      Column& col = res->cols[col_of[k]];
+      col.n_rows = n;
+      srcs[k].alloc(n);
+      col.d_len.alloc(n);
+      *sp[k] = srcs[k].p;
+      *lp[k] = col.d_len.p;
+      if (k == 1) { col.d_valid.alloc(nwords); fc.v_desc = col.d_valid.p; arrow_bytes += nwords * 8; }
+    }
+    launch_fastq_fields(u, x0, hi - base, nl.p, n_nl, n, fc, err.p, st);
+    uint32_t e = read_err(err, st);
+    if (e == 1) throw Error("FASTQ read error: invalid name prefix");
+    if (e == 2) throw Error("FASTQ read error: invalid description prefix");
+    DevBuf<uint64_t> stmp(scan_tmp_elems(n));
+    for (int k = 0; k < 4; k++) {
+      if (col_of[k] < 0) continue;
+      Column& col = res->cols[col_of[k]];
+      col.d_off64.alloc(n + 1);
+      launch_exclusive_scan_u32_to_u64(col.d_len.p, col.d_off64.p, n, stmp.p, st);
+      uint64_t tot = 0;
+      HIP_CHECK(hipMemcpyAsync(&tot, col.d_off64.p + n, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      col.total_bytes = tot;
+      col.d_values.alloc(std::max<uint64_t>(tot, 1));
+      col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
+      launch_batch_offsets(col.d_off64.p, n, batch_size, col.d_off32.p, st);
+      launch_scatter_ranges(u, srcs[k].p, n, col.d_off64.p, col.d_values.p, st);
+      arrow_bytes += tot + nb * ((uint64_t)batch_size + 1) * 4;
+      col.d_len.reset();
     }
     HIP_CHECK(hipStreamSynchronize(st));
-    for (auto& col : res->cols) {
-      col.d_values.reset(); col.d_off64.reset(); col.d_off32.reset(); col.d_valid.reset();
-    }
-    res->on_host = true;
   }
+  res->stats.ms_extract = t.stop();
+  res->stats.arrow_bytes = arrow_bytes;
+  res->stats.ms_total_gpu = res->stats.ms_inflate + res->stats.ms_crc + res->stats.ms_chain + res->stats.ms_extract;
+  res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  if (to_host) copy_result_to_host(*res, st);
   return res;
 }
 
@@ -1273,6 +1485,57 @@ int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_
   API_END
 }
 
+int bioscan_fastq_open(const char* path, int32_t device_id, bioscan_provider** out) {
+  API_BEGIN
+  std::unique_ptr<bioscan_provider> bp(new bioscan_provider);
+  Provider& p = bp->p;
+  p.kind = 1;
+  p.path = path;
+  p.device = device_id;
+  {
+    char nm[8];
+    if (bioscan_device_check(p.device, nm, sizeof nm)) throw Error(g_err);
+  }
+  p.set_device();
+  p.load_file();
+  // detect_compression_sync (bio-format-fastq/src/physical_exec.rs:70-89)
+  const uint8_t* d = p.file.p;
+  if (p.file_len >= 18 && d[0] == 0x1f && d[1] == 0x8b && d[2] == 8 && (d[3] & 4) && d[12] == 0x42 && d[13] == 0x43) {
+    p.fq_compression = 1;
+    p.frame();
+    std::ifstream f(p.path + ".gzi", std::ios::binary);
+    if (f.good()) {
+      std::vector<uint8_t> g((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      if (g.size() >= 8) {
+        uint64_t n;
+        memcpy(&n, g.data(), 8);
+        if (g.size() >= 8 + 16 * n) {
+          for (uint64_t i = 0; i < n; i++) {
+            uint64_t c, u;
+            memcpy(&c, g.data() + 8 + 16 * i, 8);
+            memcpy(&u, g.data() + 16 + 16 * i, 8);
+            p.gzi.emplace_back(c, u);
+          }
+          p.fq_has_gzi = true;
+        }
+      }
+    }
+  } else if (p.file_len >= 2 && d[0] == 0x1f && d[1] == 0x8b) {
+    throw Error("plain gzip FASTQ (not BGZF) has no block structure to decode in parallel: not supported by the GPU scan");
+  } else {
+    p.blk_coff = {0, p.file_len};
+    p.blk_uoff = {0, 0};
+    p.ulen = 0;
+  }
+  p.fields.clear();
+  p.fields.push_back(FieldDef{"name", AK_UTF8, false, {}});
+  p.fields.push_back(FieldDef{"description", AK_UTF8, true, {}});
+  p.fields.push_back(FieldDef{"sequence", AK_UTF8, false, {}});
+  p.fields.push_back(FieldDef{"quality_scores", AK_UTF8, false, {}});
+  *out = bp.release();
+  API_END
+}
+
 int bioscan_schema(const bioscan_provider* p, struct ArrowSchema* out) {
   API_BEGIN
   export_schema(p->p.fields, p->p.metadata, out);
@@ -1310,6 +1573,36 @@ int bioscan_scan(const bioscan_provider* cp, const int32_t* projection, int32_t 
         if (pl.projection[a] == pl.projection[b]) throw Error("duplicate column in projection");
   } else {
     pl.out_fields = p.fields;
+  }
+  if (p.kind == 1) {
+    // detect_local_strategy (bio-format-fastq/src/physical_exec.rs:94-138); filters are ignored (scan's `_filters`)
+    const size_t target = (size_t)std::max(target_partitions, 0);
+    if (p.fq_compression == 1) {
+      if (p.fq_has_gzi) {
+        // get_bgzf_partition_bounds (:140-175)
+        std::vector<std::pair<uint64_t, uint64_t>> blocks{{0, 0}};
+        blocks.insert(blocks.end(), p.gzi.begin(), p.gzi.end());
+        const size_t nbk = blocks.size(), nparts = std::min(target, nbk);
+        pl.fq_strategy = 1;
+        if (nparts == 0) pl.fq_parts.push_back({0, ~0ull});
+        size_t cur = 0;
+        for (size_t i = 0; i < nparts && cur < nbk; i++) {
+          const size_t cnt = nbk / nparts + (i < nbk % nparts ? 1 : 0);
+          const size_t nxt = cur + cnt;
+          pl.fq_parts.push_back({blocks[cur].second, nxt >= nbk ? ~0ull : blocks[nxt].first});
+          cur = nxt;
+        }
+      }
+    } else {
+      const uint64_t fsz = p.file_len;
+      if (fsz != 0 && target > 1 && fsz / target != 0) {
+        const uint64_t chunk = fsz / target;
+        pl.fq_strategy = 2;
+        for (size_t i = 0; i < target; i++) pl.fq_parts.push_back({i * chunk, i + 1 == target ? fsz : (i + 1) * chunk});
+      }
+    }
+    *out = bp.release();
+    return 0;
   }
   auto fs = copy_filters(filters, n_filters);
   if (p.has_index) {
@@ -1353,7 +1646,7 @@ int bioscan_plan_schema(const bioscan_plan* plan, struct ArrowSchema* out) {
 }
 
 int32_t bioscan_plan_display(const bioscan_plan* plan, char* buf, int32_t cap) {
-  std::string s = "BamExec: projection=[";
+  std::string s = plan->pl.prov->kind == 1 ? "FastqExec: projection=[" : "BamExec: projection=[";
   if (plan->pl.has_projection) {
     for (size_t i = 0; i < plan->pl.out_fields.size(); i++) {
       if (i) s += ", ";
@@ -1383,7 +1676,8 @@ static int execute_impl(const bioscan_plan* plan, int32_t partition, int32_t bat
   if (batch_size <= 0) throw Error("batch_size must be positive");
   std::unique_ptr<bioscan_stream> bs(new bioscan_stream);
   bs->s.prov = plan->pl.prov;
-  bs->s.res = run_partition(plan->pl, partition, (uint32_t)batch_size, device_only, !device_only);
+  bs->s.res = plan->pl.prov->kind == 1 ? run_partition_fastq(plan->pl, partition, (uint32_t)batch_size, !device_only)
+                                       : run_partition(plan->pl, partition, (uint32_t)batch_size, device_only, !device_only);
   if (stats) *stats = bs->s.res->stats;
   *out = bs.release();
   API_END

@@ -1,0 +1,194 @@
+// fastq_kernels.hip -- FASTQ record framing + field extract -> Arrow scatter (gfx950).
+//
+// Replaces the per-record loop of the reference's FastqExec
+// (bio-format-fastq/src/physical_exec.rs:393-465 `batch_producer`, :184-248 resync) and
+// noodles-fastq 0.23.0 `Reader::read_record` (un-vendored).  Byte work only.
+#include "kernels.h"
+
+namespace bioscan {
+
+#define WAVE 64
+
+// ---- wave-parallel byte search: first position in [from, to) holding `byte`, or ~0 ---------------
+__device__ __forceinline__ uint64_t wave_find(const uint8_t* u, uint64_t from, uint64_t to, uint8_t byte, int lane) {
+  for (uint64_t p0 = from; p0 < to; p0 += WAVE) {
+    const uint64_t p = p0 + lane;
+    const bool hit = p < to && u[p] == byte;
+    const unsigned long long m = __ballot(hit);
+    if (m) return p0 + (uint64_t)__builtin_ctzll(m);
+  }
+  return ~0ull;
+}
+
+// Resync (physical_exec.rs:184-248): walk buffered windows from `start`; inside one window look for
+// the first '@' whose line+2 starts with '+'.  win_end[j] = end of window j; win_coff[j] / win_next[j]
+// = compressed offset the reader reports inside window j / once window j is exhausted (BGZF only;
+// check_end = 0 for plain files, whose resync has no end test).  result[0] = position, or ~0 when the
+// stream ended.
+__global__ __launch_bounds__(WAVE) void k_fastq_sync(const uint8_t* __restrict__ u, uint64_t start, uint64_t ulen,
+                                                      const uint64_t* __restrict__ win_end,
+                                                      const uint64_t* __restrict__ win_coff,
+                                                      const uint64_t* __restrict__ win_next, uint32_t n_win,
+                                                      uint64_t end_comp, int check_end, unsigned long long* result) {
+  const int lane = threadIdx.x;
+  uint64_t x = start;
+  uint32_t j = 0;
+  while (j < n_win && win_end[j] <= x) j++;  // window containing x (x is a window start after a seek)
+  uint64_t res = ~0ull;
+  for (;;) {
+    if (j >= n_win || x >= ulen) { res = x < ulen ? x : ~0ull; break; }
+    if (check_end) {
+      const uint64_t vc = x < win_end[j] ? win_coff[j] : win_next[j];
+      if (vc >= end_comp) { res = x; break; }
+    }
+    if (x >= win_end[j]) { j++; continue; }  // fill_buf loads the next window
+    const uint64_t wend = win_end[j];
+    const uint64_t at = wave_find(u, x, wend, '@', lane);
+    if (at == ~0ull) { x = wend; continue; }
+    const uint64_t l1 = wave_find(u, at, wend, '\n', lane);
+    if (l1 != ~0ull) {
+      const uint64_t l2 = wave_find(u, l1 + 1, wend, '\n', lane);
+      if (l2 != ~0ull && l2 + 1 < wend && u[l2 + 1] == '+') { res = at; break; }
+      x = l1 + 1;
+    } else {
+      x = wend;
+    }
+  }
+  if (lane == 0) result[0] = res;
+}
+void launch_fastq_sync(const uint8_t* u, uint64_t start, uint64_t ulen, const uint64_t* win_end, const uint64_t* win_coff,
+                       const uint64_t* win_next, uint32_t n_win, uint64_t end_comp, int check_end, unsigned long long* result,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_fastq_sync, dim3(1), dim3(WAVE), 0, st, u, start, ulen, win_end, win_coff, win_next, n_win, end_comp,
+                     check_end, result);
+}
+
+// ---- newline index ------------------------------------------------------------------------------------
+constexpr int NL_CHUNK = 1024;
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi, uint32_t* __restrict__ cnt) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t a = lo + c * NL_CHUNK;
+  if (a >= hi) return;
+  const uint64_t b = a + NL_CHUNK < hi ? a + NL_CHUNK : hi;
+  uint32_t n = 0;
+  for (uint64_t p = a; p < b; p++) n += u[p] == '\n';
+  cnt[c] = n;
+}
+__global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi,
+                                                   const uint64_t* __restrict__ base, uint64_t* __restrict__ nl) {
+  const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t a = lo + c * NL_CHUNK;
+  if (a >= hi) return;
+  const uint64_t b = a + NL_CHUNK < hi ? a + NL_CHUNK : hi;
+  uint64_t o = base[c];
+  for (uint64_t p = a; p < b; p++)
+    if (u[p] == '\n') nl[o++] = p;
+}
+uint64_t nl_chunks(uint64_t lo, uint64_t hi) { return hi > lo ? (hi - lo + NL_CHUNK - 1) / NL_CHUNK : 0; }
+void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st) {
+  const uint64_t n = nl_chunks(lo, hi);
+  if (!n) return;
+  hipLaunchKernelGGL(k_nl_count, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, lo, hi, cnt);
+}
+void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base, uint64_t* nl, hipStream_t st) {
+  const uint64_t n = nl_chunks(lo, hi);
+  if (!n) return;
+  hipLaunchKernelGGL(k_nl_write, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, lo, hi, base, nl);
+}
+
+// ---- record fields ------------------------------------------------------------------------------------
+// Record r spans lines 4r..4r+3 counted from x0 (the first record start).  nl[] holds the newline
+// positions >= x0 in order; a last line without '\n' ends at `eof` (only legal at the end of the data).
+// Outputs per record: source offset + length of name, description, sequence, quality; description
+// validity (NULL when empty, physical_exec.rs:430-434); err: 1 = missing '@', 2 = missing '+'.
+__global__ __launch_bounds__(256) void k_fastq_fields(const uint8_t* __restrict__ u, uint64_t x0, uint64_t eof,
+                                                       const uint64_t* __restrict__ nl, uint64_t n_nl, uint64_t n_rec,
+                                                       FastqCols c, uint32_t* err) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = r < n_rec;
+  bool dvalid = false;
+  if (act) {
+    uint64_t s[4], e[4];
+    for (int k = 0; k < 4; k++) {
+      const uint64_t li = 4 * r + k;
+      s[k] = li == 0 ? x0 : (li - 1 < n_nl ? nl[li - 1] + 1 : eof);
+      uint64_t en = li < n_nl ? nl[li] : eof;
+      if (en > s[k] && u[en - 1] == '\r') en--;  // CRLF
+      e[k] = en < s[k] ? s[k] : en;
+    }
+    if (u[s[0]] != '@') atomicExch(err, 1u);
+    if (s[2] < eof && u[s[2]] != '+') atomicExch(err, 2u);
+    const uint64_t d0 = s[0] + 1;
+    uint64_t sp = d0;
+    while (sp < e[0] && u[sp] != ' ' && u[sp] != '\t') sp++;
+    const uint64_t name_len = sp - d0;
+    const uint64_t desc_off = sp < e[0] ? sp + 1 : e[0];
+    const uint64_t desc_len = e[0] - desc_off;
+    dvalid = desc_len != 0;
+    if (c.src_name) { c.src_name[r] = d0; c.len_name[r] = (uint32_t)name_len; }
+    if (c.src_desc) { c.src_desc[r] = desc_off; c.len_desc[r] = (uint32_t)desc_len; }
+    if (c.src_seq) { c.src_seq[r] = s[1]; c.len_seq[r] = (uint32_t)(e[1] - s[1]); }
+    if (c.src_qual) { c.src_qual[r] = s[3]; c.len_qual[r] = (uint32_t)(e[3] - s[3]); }
+  }
+  if (c.v_desc) {
+    const unsigned long long m = __ballot(dvalid);
+    if ((threadIdx.x & 63) == 0 && act) c.v_desc[r >> 6] = m;
+  }
+}
+void launch_fastq_fields(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec,
+                         FastqCols c, uint32_t* err, hipStream_t st) {
+  if (!n_rec) return;
+  hipLaunchKernelGGL(k_fastq_fields, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, u, x0, eof, nl, n_nl, n_rec, c, err);
+}
+
+// number of records whose first byte lies before `limit_off` (ownership threshold): record r starts at
+// x0 (r = 0) or nl[4r-1]+1.  Single thread binary search.
+__global__ void k_fastq_count_owned(const uint64_t* __restrict__ nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
+                                    unsigned long long* result) {
+  // candidate records: a record exists at index r if its start < eof
+  uint64_t lo = 0, hi = n_nl / 4 + 2;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    uint64_t st;
+    bool exists = true;
+    if (mid == 0) st = x0;
+    else if (4 * mid - 1 < n_nl) st = nl[4 * mid - 1] + 1;
+    else { st = eof; exists = false; }
+    if (exists && st < eof && st < limit_off) lo = mid + 1; else hi = mid;
+  }
+  result[0] = lo;
+}
+void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
+                              unsigned long long* result, hipStream_t st) {
+  hipLaunchKernelGGL(k_fastq_count_owned, dim3(1), dim3(1), 0, st, nl, n_nl, x0, eof, limit_off, result);
+}
+
+// ---- generic range scatter: row i copies len_i bytes from u[src_i..] to dst[off64_i..] -----------------
+// Output-centric like k_scatter_seqqual: 256 rows per workgroup, threads sweep the OUTPUT bytes.
+constexpr int RS_ROWS = 256;
+__global__ __launch_bounds__(256) void k_scatter_ranges(const uint8_t* __restrict__ u, const uint64_t* __restrict__ src,
+                                                         uint64_t n, const uint64_t* __restrict__ off64,
+                                                         uint8_t* __restrict__ dst) {
+  __shared__ uint64_t s_off[RS_ROWS + 1];
+  __shared__ uint64_t s_src[RS_ROWS];
+  const uint64_t r0 = (uint64_t)blockIdx.x * RS_ROWS;
+  const uint32_t nr = (uint32_t)((n - r0) < RS_ROWS ? (n - r0) : RS_ROWS);
+  for (uint32_t k = threadIdx.x; k <= nr; k += 256) s_off[k] = off64[r0 + k];
+  for (uint32_t k = threadIdx.x; k < nr; k += 256) s_src[k] = src[r0 + k];
+  __syncthreads();
+  const uint64_t b0 = s_off[0], b1 = s_off[nr];
+  for (uint64_t j = b0 + threadIdx.x; j < b1; j += 256) {
+    uint32_t lo = 0, hi = nr;
+    while (lo + 1 < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= j) lo = mid; else hi = mid;
+    }
+    dst[j] = u[s_src[lo] + (j - s_off[lo])];
+  }
+}
+void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scatter_ranges, dim3((uint32_t)((n + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0, st, u, src, n, off64, dst);
+}
+
+}  // namespace bioscan

@@ -138,4 +138,23 @@ void launch_tag_list_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, 
 void launch_tag_list_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint32_t* loc, const uint8_t* typ,
                              int32_t elem, const uint64_t* off64, uint8_t* dst, uint32_t* err, hipStream_t st);
 
+// ---- FASTQ (fastq_kernels.hip) -------------------------------------------------------------------
+struct FastqCols {   // nullptr = not projected
+  uint64_t* src_name; uint32_t* len_name;
+  uint64_t* src_desc; uint32_t* len_desc; uint64_t* v_desc;
+  uint64_t* src_seq; uint32_t* len_seq;
+  uint64_t* src_qual; uint32_t* len_qual;
+};
+void launch_fastq_sync(const uint8_t* u, uint64_t start, uint64_t ulen, const uint64_t* win_end, const uint64_t* win_coff,
+                       const uint64_t* win_next, uint32_t n_win, uint64_t end_comp, int check_end, unsigned long long* result,
+                       hipStream_t st);
+uint64_t nl_chunks(uint64_t lo, uint64_t hi);
+void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st);
+void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base, uint64_t* nl, hipStream_t st);
+void launch_fastq_fields(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec,
+                         FastqCols c, uint32_t* err, hipStream_t st);
+void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
+                              unsigned long long* result, hipStream_t st);
+void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
+
 }  // namespace bioscan

@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_plan_partition_desc", "bioscan_execute", "bioscan_next", "bioscan_stream_close", "bioscan_plan_close",
     "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
-    "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan",
+    "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
 ]
 
 
@@ -75,6 +75,7 @@ def load_library():
     lib = C.CDLL(_LIB_PATH)
     lib.bioscan_last_error.restype = C.c_char_p
     lib.bioscan_bam_open.argtypes = [C.c_char_p, C.POINTER(_Options), C.POINTER(C.c_void_p)]
+    lib.bioscan_fastq_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
     lib.bioscan_schema.argtypes = [C.c_void_p, C.c_void_p]
     lib.bioscan_supports_filters_pushdown.argtypes = [C.c_void_p, C.POINTER(_Filter), C.c_int32, C.POINTER(C.c_int32)]
     lib.bioscan_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_Filter), C.c_int32, C.c_int64,
@@ -327,3 +328,44 @@ class BamExec:
         _check(lib.bioscan_execute_device(self._h, partition, batch_size, C.byref(stats), C.byref(st)))
         lib.bioscan_stream_close(st)
         return stats.as_dict()
+
+
+class FastqExec(BamExec):
+    """Mirror of FastqExec (bio-format-fastq/src/physical_exec.rs:262-386)."""
+
+    def name(self) -> str:
+        return "FastqExec"
+
+
+class FastqTableProvider:
+    """Mirror of FastqTableProvider::new(file_path, object_storage_options)
+    (bio-format-fastq/src/table_provider.rs:49-66); local files only."""
+
+    def __init__(self, file_path: str, object_storage_options=None, device_id: int = 0):
+        lib = load_library()
+        self._h = C.c_void_p()
+        _check(lib.bioscan_fastq_open(file_path.encode(), device_id, C.byref(self._h)))
+        self.file_path = file_path
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            load_library().bioscan_provider_close(h)
+            self._h = None
+
+    def schema(self) -> pa.Schema:
+        s = _ArrowSchema()
+        _check(load_library().bioscan_schema(self._h, C.addressof(s)))
+        return pa.Schema._import_from_c(C.addressof(s))
+
+    def scan(self, projection: Optional[Sequence[int]] = None, filters=(), limit: Optional[int] = None,
+             target_partitions: int = 1) -> FastqExec:
+        if projection is None:
+            proj, nproj = None, 0
+        else:
+            proj = (C.c_int32 * max(len(projection), 1))(*projection)
+            nproj = len(projection)
+        plan = C.c_void_p()
+        _check(load_library().bioscan_scan(self._h, proj, nproj, None, 0, -1 if limit is None else limit, target_partitions,
+                                           C.byref(plan)))
+        return FastqExec(self, plan)

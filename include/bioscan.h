@@ -52,6 +52,14 @@ void bioscan_bam_options_default(bioscan_bam_options* o);
 
 int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_provider** out);
 
+/* FastqTableProvider::new (bio-format-fastq/src/table_provider.rs:49-66): 4-column schema
+ * (name, description, sequence, quality_scores).  The handle is used with the same
+ * bioscan_scan / bioscan_execute / bioscan_next entry points; `filters` are ignored by the FASTQ scan
+ * (bio-format-fastq/src/table_provider.rs:94 `_filters`) and `limit` stops each partition
+ * (physical_exec.rs:416).  Strategy = detect_local_strategy (physical_exec.rs:94-138): BGZF + `.gzi`
+ * -> block-range partitions, plain file -> byte ranges, BGZF without index -> one partition. */
+int bioscan_fastq_open(const char* path, int32_t device_id, bioscan_provider** out);
+
 /* TableProvider::schema (table_provider.rs:933-935); caller releases the ArrowSchema. */
 int bioscan_schema(const bioscan_provider* p, struct ArrowSchema* out);
 

@@ -1,0 +1,170 @@
+"""GPU parity for the FASTQ path: HIP scan (C ABI) vs oracle/fastq_oracle.py, per partition and per
+batch, on the reference's fixtures (sample.fastq.bgz + .gzi, sandbox example.fastq) plus edge cases;
+and the reference's own properties (fastq/tests/parallel_read_test.rs)."""
+import os
+import shutil
+import struct
+import sys
+import zlib
+
+import pyarrow as pa
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def fo():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fastq_oracle
+    return fastq_oracle
+
+
+def _run_gpu(pkg, path, target, projection=None, limit=None, bs=8192):
+    prov = pkg.FastqTableProvider(path)
+    plan = prov.scan(projection=projection, limit=limit, target_partitions=target)
+    return prov, plan, [list(plan.execute(p, bs)) for p in range(plan.num_partitions())]
+
+
+def _cmp(got, want, ctx):
+    assert len(got) == len(want), (ctx, len(got), len(want))
+    for g, w in zip(got, want):
+        assert g.num_rows == w.num_rows, ctx
+        assert g.schema.names == w.schema.names, ctx
+        for n in w.schema.names:
+            assert g.column(n).equals(w.column(n)), (ctx, n)
+
+
+@pytest.mark.parametrize("target", [1, 2, 3, 4, 5, 6, 7, 8, 16])
+def test_bgzf_gzi_partitions(pkg, fo, target):
+    path = os.path.join(G, "sample.fastq.bgz")
+    orc = fo.FastqOracle(path)
+    strat, parts = orc.scan(target)
+    prov, plan, got = _run_gpu(pkg, path, target, bs=300)
+    assert prov.schema().equals(fo.SCHEMA)
+    assert plan.num_partitions() == len(parts)
+    total = 0
+    for p, part in enumerate(parts):
+        _, want = orc.execute(strat, part, batch_size=300)
+        _cmp(got[p], want, (target, p))
+        total += sum(b.num_rows for b in got[p])
+    assert total == 2000                                         # parallel_read_test.rs:22-45
+
+
+def test_no_duplicates_and_same_rows_1_vs_4(pkg):
+    path = os.path.join(G, "sample.fastq.bgz")
+
+    def rows(target):
+        _, _, got = _run_gpu(pkg, path, target)
+        out = []
+        for part in got:
+            for b in part:
+                out += list(zip(b.column(0).to_pylist(), b.column(2).to_pylist(), b.column(3).to_pylist()))
+        return out
+    r1, r4 = rows(1), rows(4)
+    assert len({r[0] for r in r4}) == 2000                        # parallel_read_test.rs:48-105
+    assert sorted(r1) == sorted(r4)                               # parallel_read_test.rs:190-232
+
+
+def test_no_gzi_is_sequential(pkg, fo, tmp_path):
+    src = os.path.join(G, "sample.fastq.bgz")
+    dst = str(tmp_path / "nogzi.fastq.bgz")
+    shutil.copy(src, dst)
+    prov, plan, got = _run_gpu(pkg, dst, 4)
+    assert plan.num_partitions() == 1                             # parallel_read_test.rs:158-185
+    _, want = fo.FastqOracle(dst).execute("sequential", None)
+    _cmp(got[0], want, "nogzi")
+
+
+@pytest.mark.parametrize("target", [1, 2, 3, 4, 8, 13])
+def test_uncompressed_byte_ranges(pkg, fo, target):
+    path = os.path.join(G, "example.fastq")
+    orc = fo.FastqOracle(path)
+    strat, parts = orc.scan(target)
+    prov, plan, got = _run_gpu(pkg, path, target)
+    assert plan.num_partitions() == len(parts)
+    total = 0
+    for p, part in enumerate(parts):
+        _, want = orc.execute(strat, part)
+        _cmp(got[p], want, (target, p))
+        total += sum(b.num_rows for b in got[p])
+    assert total == 200
+
+
+def test_projection_limit_count(pkg, fo):
+    path = os.path.join(G, "sample.fastq.bgz")
+    orc = fo.FastqOracle(path)
+    strat, parts = orc.scan(3)
+    prov, plan, got = _run_gpu(pkg, path, 3, projection=[2, 0], limit=50)
+    assert plan.display() == "FastqExec: projection=[sequence, name]"
+    for p, part in enumerate(parts):
+        _, want = orc.execute(strat, part, projection=[2, 0], limit=50)
+        _cmp(got[p], want, p)
+        assert sum(b.num_rows for b in got[p]) <= 50              # parallel_read_test.rs:134-155
+    _, plan, got = _run_gpu(pkg, path, 4, projection=[])
+    assert sum(b.num_rows for part in got for b in part) == 2000  # row_count_integration_test.rs
+
+
+def _bgzf(chunks):
+    out = b""
+    for p in chunks:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(p) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(body) + 8 - 1) + body +
+                struct.pack("<II", zlib.crc32(p) & 0xFFFFFFFF, len(p)))
+    return out + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def test_edge_cases(pkg, fo, tmp_path):
+    """descriptions (space / tab / empty), CRLF, '@' leading a quality line, missing final newline, record
+    boundaries exactly on block boundaries, records straddling several blocks, tiny blocks."""
+    recs = []
+    for i in range(400):
+        name = f"r{i}"
+        desc = ["", " desc text here", "\tx=1", " "][i % 4]
+        seq = "ACGT" * (1 + i % 50)
+        qual = ("@" if i % 3 == 0 else "I") + "#" * (len(seq) - 1)
+        eol = "\r\n" if i % 7 == 0 else "\n"
+        recs.append(f"@{name}{desc}{eol}{seq}{eol}+{eol}{qual}{eol}")
+    text = "".join(recs).encode()
+    text = text[:-1] if text.endswith(b"\n") else text          # no final newline
+    cuts, o = [], 0
+    k = 0
+    while o < len(text):                                           # uneven blocks; some cuts land on record ends
+        step = [len(recs[k % 400].encode()), 97, 4096, 5, 1500][k % 5]
+        cuts.append(text[o:o + step])
+        o += step
+        k += 1
+    data = _bgzf(cuts)
+    path = str(tmp_path / "edge.fastq.bgz")
+    open(path, "wb").write(data)
+    # GZI from the block table
+    ents, co, uo = [], 0, 0
+    for c in cuts:
+        bs = struct.unpack_from("<H", data, co + 16)[0] + 1
+        co += bs
+        uo += len(c)
+        ents.append((co, uo))
+    ents = ents[:-1]                                               # like bgzip -i: no entry for the EOF member
+    open(path + ".gzi", "wb").write(struct.pack("<Q", len(ents)) + b"".join(struct.pack("<QQ", *e) for e in ents))
+    plain = str(tmp_path / "edge.fastq")
+    open(plain, "wb").write(text)
+    for p_ in (path, plain):
+        orc = fo.FastqOracle(p_)
+        for target in (1, 2, 5, 9, 33):
+            strat, parts = orc.scan(target)
+            prov, plan, got = _run_gpu(pkg, p_, target, bs=64)
+            assert plan.num_partitions() == len(parts)
+            n = 0
+            for p, part in enumerate(parts):
+                _, want = orc.execute(strat, part, batch_size=64)
+                _cmp(got[p], want, (p_, target, p))
+                n += sum(b.num_rows for b in got[p])
+            # The reference's resync only looks inside ONE buffered window (the rest of a BGZF block / an
+            # 8 KiB BufReader window), so with blocks smaller than a record it can skip records at partition
+            # starts; that behaviour is restated faithfully (GPU == oracle above).  Only the unsplit scan is
+            # guaranteed complete.
+            if target == 1:
+                assert n == 400, (p_, target, n)
