@@ -51,6 +51,14 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(x) ::bioscan::hip_check((x), #x, __FILE__, __LINE__)
 
+// Size-keyed cache of large device allocations: a scan allocates the same column / scratch sizes for
+// every partition and every step, and hipMalloc / hipFree of tens of GB per scan is driver work that
+// does not belong on the hot path.  Blocks >= 1 MiB are returned here instead of to the driver and
+// handed out again on an exact size match; dev_pool_trim() releases everything (provider close).
+void* dev_pool_alloc(size_t bytes);
+void dev_pool_free(void* p, size_t bytes);
+void dev_pool_trim();
+
 // device buffer with value semantics off (move only)
 template <typename T>
 struct DevBuf {
@@ -70,10 +78,10 @@ struct DevBuf {
     reset();
     n = count;
     size_t bytes = (count ? count : 1) * sizeof(T);
-    HIP_CHECK(hipMalloc((void**)&p, bytes));
+    p = (T*)dev_pool_alloc(bytes);
   }
   void reset() {
-    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+    if (p) { dev_pool_free(p, (n ? n : 1) * sizeof(T)); p = nullptr; n = 0; }
   }
   size_t bytes() const { return n * sizeof(T); }
 };

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -24,6 +25,49 @@
 using namespace bioscan;
 
 static thread_local std::string g_err;
+
+// ---- device allocation cache (see common.h) -------------------------------------------------------
+namespace bioscan {
+static std::mutex g_pool_mu;
+static std::multimap<size_t, void*> g_pool;
+static size_t g_pool_bytes = 0;
+constexpr size_t POOL_MIN = 1u << 20;
+void* dev_pool_alloc(size_t bytes) {
+  if (bytes >= POOL_MIN) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end()) {
+      void* p = it->second;
+      g_pool.erase(it);
+      g_pool_bytes -= bytes;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess && bytes >= POOL_MIN) {  // out of memory: give cached blocks back and retry once
+    dev_pool_trim();
+    e = hipMalloc(&p, bytes);
+  }
+  HIP_CHECK(e);
+  return p;
+}
+void dev_pool_free(void* p, size_t bytes) {
+  if (bytes >= POOL_MIN) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.emplace(bytes, p);
+    g_pool_bytes += bytes;
+    return;
+  }
+  (void)hipFree(p);
+}
+void dev_pool_trim() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& kv : g_pool) (void)hipFree(kv.second);
+  g_pool.clear();
+  g_pool_bytes = 0;
+}
+}  // namespace bioscan
 
 namespace {
 
@@ -1706,7 +1750,10 @@ int bioscan_next(bioscan_stream* s, struct ArrowArray* out, int32_t* has_batch) 
 
 void bioscan_stream_close(bioscan_stream* s) { delete s; }
 void bioscan_plan_close(bioscan_plan* p) { delete p; }
-void bioscan_provider_close(bioscan_provider* p) { delete p; }
+void bioscan_provider_close(bioscan_provider* p) {
+  delete p;
+  dev_pool_trim();
+}
 
 int bioscan_provider_make_resident(bioscan_provider* p) {
   API_BEGIN

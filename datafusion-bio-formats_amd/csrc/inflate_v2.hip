@@ -28,29 +28,30 @@ namespace bioscan {
 
 #define WAVE 64
 #ifndef V2_SUB_DW
-#define V2_SUB_DW 9
+#define V2_SUB_DW 7
+#endif
+#ifndef V2_GLOBAL_INPUT
+#define V2_GLOBAL_INPUT 1
 #endif
 #ifndef V2_OV_BITS
 #define V2_OV_BITS 96
 #endif
 #ifndef V2_WIN_BYTES
-#define V2_WIN_BYTES 7168
+#define V2_WIN_BYTES 5632
 #endif
 constexpr int V2_LIT_BITS = 9;                          // zlib's root sizes: ENOUGH_LENS = 852, ENOUGH_DISTS = 592
 constexpr int V2_DIST_BITS = 6;
 constexpr int V2_MAX_SUB_DW = V2_SUB_DW;                // odd => conflict-free initial LDS reads
 constexpr int V2_WIN = V2_WIN_BYTES;                    // LDS output window of one round (multiple of 16)
-constexpr int V2_STAGE_DW = 64 * V2_MAX_SUB_DW + 8;
+constexpr int V2_STAGE_DW = V2_GLOBAL_INPUT ? 4 : 64 * V2_MAX_SUB_DW + 8;
 constexpr int V2_LIT_SUB = 352;    // 852 - 512 = 340 sub-table entries at most
 constexpr int V2_DIST_SUB = 528;   // 592 - 64
 constexpr uint32_t E_LEN = 1u << 17, E_EOB = 1u << 18, E_SUB = 1u << 19;  // E_SUB: bits[4:7] = sub-table index bits, [8:18] = base
 constexpr uint32_t F_EOB = 1, F_BAD = 2;
 
-struct __attribute__((aligned(16))) V2Lds {
-  uint32_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];     // len[0:3] extra[4:7] base[8:16] E_LEN E_EOB | E_SUB pointer ; 0 = no code
-  uint32_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // len[0:3] extra[4:7] base[8:23] | E_SUB pointer
-  uint32_t stage[V2_STAGE_DW];
-  uint8_t win[V2_WIN] __attribute__((aligned(16)));
+// Table-build scratch (code lengths, canonical order, precode table) is only live while a block header
+// is parsed, the output window only while a round is written and resolved: they share LDS.
+struct V2Build {
   uint16_t lit_sorted[288];
   uint16_t dist_sorted[32];
   uint16_t lit_count[16];
@@ -60,6 +61,16 @@ struct __attribute__((aligned(16))) V2Lds {
   uint8_t pre_fast[128];
   uint8_t pre_lens[20];
 };
+struct __attribute__((aligned(16))) V2Lds {
+  uint32_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];     // len[0:3] extra[4:7] base[8:16] E_LEN E_EOB | E_SUB pointer ; 0 = no code
+  uint32_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // len[0:3] extra[4:7] base[8:23] | E_SUB pointer
+  uint32_t stage[V2_STAGE_DW];
+  union {
+    uint8_t win[V2_WIN] __attribute__((aligned(16)));
+    V2Build b;
+  };
+};
+static_assert(sizeof(V2Build) <= V2_WIN, "output window must be able to hold the table-build scratch");
 
 __device__ __forceinline__ uint32_t uni2(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t bitrev2(uint32_t v, int n) { return __brev(v) >> (32 - n); }
@@ -147,34 +158,34 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
     for (int l = 1; l <= 15; l++) {
       uint32_t c = count[l];
       code <<= 1;
-      L.t_first[l] = (uint16_t)code;
-      L.t_offs[l] = (uint16_t)o;
-      L.t_w[l] = (uint16_t)o;
+      L.b.t_first[l] = (uint16_t)code;
+      L.b.t_offs[l] = (uint16_t)o;
+      L.b.t_w[l] = (uint16_t)o;
       o += c;
       code += c;
       left <<= 1;
       left -= (int)c;
       if (left < 0) over = 1;
     }
-    L.t_offs[0] = (uint16_t)o;
+    L.b.t_offs[0] = (uint16_t)o;
     for (int s = 0; s < n; s++) {
       int l = lens[s];
-      if (l) sorted[L.t_w[l]++] = (uint16_t)s;
+      if (l) sorted[L.b.t_w[l]++] = (uint16_t)s;
     }
     // sub-tables (serial: long codes are few)
-    uint32_t k = root_bits < 15 ? L.t_offs[root_bits + 1] : o;
+    uint32_t k = root_bits < 15 ? L.b.t_offs[root_bits + 1] : o;
     uint32_t next_free = 1u << root_bits;
     while (k < o && !over) {
       const int sym_k = sorted[k];
       const int len_k = lens[sym_k];
-      const uint32_t code_k = (uint32_t)L.t_first[len_k] + (k - L.t_offs[len_k]);
+      const uint32_t code_k = (uint32_t)L.b.t_first[len_k] + (k - L.b.t_offs[len_k]);
       const uint32_t prefix = code_k >> (len_k - root_bits);
       uint32_t j = k + 1;
       int max_len = len_k;
       while (j < o) {
         const int sj = sorted[j];
         const int lj = lens[sj];
-        const uint32_t cj = (uint32_t)L.t_first[lj] + (j - L.t_offs[lj]);
+        const uint32_t cj = (uint32_t)L.b.t_first[lj] + (j - L.b.t_offs[lj]);
         if ((cj >> (lj - root_bits)) != prefix) break;
         max_len = lj;
         j++;
@@ -185,7 +196,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       for (uint32_t m = k; m < j; m++) {
         const int sm = sorted[m];
         const int lm = lens[sm];
-        const uint32_t cm = (uint32_t)L.t_first[lm] + (m - L.t_offs[lm]);
+        const uint32_t cm = (uint32_t)L.b.t_first[lm] + (m - L.b.t_offs[lm]);
         const uint32_t r = bitrev2(cm, lm) >> root_bits;  // bits after the root, LSB-first
         const uint32_t e = is_dist ? dist_entry(sm, lm) : lit_entry(sm, lm);
         for (uint32_t i = r; i < (1u << sbits); i += (1u << (lm - root_bits))) fast[next_free + i] = e;
@@ -193,16 +204,16 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       next_free += 1u << sbits;
       k = j;
     }
-    L.t_first[0] = (uint16_t)over;
+    L.b.t_first[0] = (uint16_t)over;
   }
   __syncthreads();
-  if (uni2(L.t_first[0])) return 1;
-  const uint32_t o = uni2(L.t_offs[0]);
+  if (uni2(L.b.t_first[0])) return 1;
+  const uint32_t o = uni2(L.b.t_offs[0]);
   for (uint32_t k = lane; k < o; k += WAVE) {
     int sym = sorted[k];
     int l = lens[sym];
     if (l <= root_bits) {
-      uint32_t c = (uint32_t)L.t_first[l] + (k - L.t_offs[l]);
+      uint32_t c = (uint32_t)L.b.t_first[l] + (k - L.b.t_offs[l]);
       uint32_t r = bitrev2(c, l);
       uint32_t e = is_dist ? dist_entry(sym, l) : lit_entry(sym, l);
       for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
@@ -221,7 +232,7 @@ template <int MODE>
 __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, uint32_t limit, uint32_t& end_out,
                                         uint32_t& nout, uint32_t& nmatch, uint32_t& flags, uint8_t* out, uint32_t opos,
                                         unsigned long long* mlist, uint32_t mpos, uint32_t win_base,
-                                        uint32_t count_from, uint32_t& first_out) {
+                                        uint32_t count_from, uint32_t& first_out, const uint32_t* __restrict__ gsrc) {
   constexpr bool WRITE = MODE != 0;
   uint32_t pos = start;
   uint32_t fl = 0, no = 0, nm = 0;
@@ -233,11 +244,18 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
   uint32_t wp = run ? (pos >> 5) : 0u;
   uint64_t bb;
   int bc;
+#if V2_GLOBAL_INPUT
+#define V2_SRC(i) gsrc[i]
+#else
+#define V2_SRC(i) L.stage[i]
+#endif
+  uint32_t nxt;  // prefetched dword wp
   {
-    const uint64_t lo = L.stage[wp], hi = L.stage[wp + 1];
+    const uint64_t lo = V2_SRC(wp), hi = V2_SRC(wp + 1);
     bb = ((hi << 32) | lo) >> (pos & 31);
     bc = 64 - (int)(pos & 31);
     wp += 2;
+    nxt = V2_SRC(wp);
   }
   while (__ballot(run) != 0ull) {
     if (MODE == 0) {
@@ -248,8 +266,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     // refill to >= 33 bits (reads of finished lanes stay inside the staged region: wp only moves while running)
     {
       const bool rf = run && bc <= 32;
-      const uint64_t w = L.stage[wp];
-      if (rf) { bb |= w << bc; bc += 32; wp++; }
+      if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
     }
     uint32_t e = L.lit_fast[(uint32_t)bb & ((1u << V2_LIT_BITS) - 1u)];
     {
@@ -278,8 +295,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       bb >>= ebv; bc -= (int)ebv; pos += ebv;
       {
         const bool rf = is_len && bc <= 32;
-        const uint64_t w = L.stage[wp];
-        if (rf) { bb |= w << bc; bc += 32; wp++; }
+        if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
       }
       uint32_t de = L.dist_fast[(uint32_t)bb & ((1u << V2_DIST_BITS) - 1u)];
       {
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         for (int i = lane; i < 320; i += WAVE) {
           uint8_t l;
           if (i < 144) l = 8; else if (i < 256) l = 9; else if (i < 280) l = 7; else if (i < 288) l = 8; else l = 5;
-          L.lens[i] = l;
+          L.b.lens[i] = l;
         }
         __syncthreads();
       } else {
@@ -565,31 +581,31 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         const uint32_t hdist = ub_take(in, 5) + 1;
         const uint32_t hclen = ub_take(in, 4) + 4;
         if (hlit > 286 || hdist > 30) { st = INF_BAD_CODE | (1u << 8); break; }
-        if (lane < 20) L.pre_lens[lane] = 0;
+        if (lane < 20) L.b.pre_lens[lane] = 0;
         __syncthreads();
         {
           const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
           for (uint32_t i = 0; i < hclen; i++) {
             ub_refill(in, lane);
             uint32_t v = ub_take(in, 3);
-            if (lane == 0) L.pre_lens[order[i]] = (uint8_t)v;
+            if (lane == 0) L.b.pre_lens[order[i]] = (uint8_t)v;
           }
         }
         __syncthreads();
-        for (int i = lane; i < 128; i += WAVE) L.pre_fast[i] = 0;
+        for (int i = lane; i < 128; i += WAVE) L.b.pre_fast[i] = 0;
         __syncthreads();
         if (lane == 0) {
           uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          for (int s = 0; s < 19; s++) cnt[L.pre_lens[s]]++;
+          for (int s = 0; s < 19; s++) cnt[L.b.pre_lens[s]]++;
           cnt[0] = 0;
           uint32_t next[8];
           uint32_t code = 0;
           for (int l = 1; l <= 7; l++) { code = (code + cnt[l - 1]) << 1; next[l] = code; }
           for (int s = 0; s < 19; s++) {
-            int l = L.pre_lens[s];
+            int l = L.b.pre_lens[s];
             if (!l) continue;
             uint32_t r = bitrev2(next[l]++, l);
-            for (uint32_t i = r; i < 128; i += (1u << l)) L.pre_fast[i] = (uint8_t)((s << 3) | l);
+            for (uint32_t i = r; i < 128; i += (1u << l)) L.b.pre_fast[i] = (uint8_t)((s << 3) | l);
           }
         }
         __syncthreads();
@@ -599,12 +615,12 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
           int bad = 0;
           while (i < total) {
             ub_refill(in, lane);
-            uint32_t e = uni2(L.pre_fast[(uint32_t)in.bb & 127]);
+            uint32_t e = uni2(L.b.pre_fast[(uint32_t)in.bb & 127]);
             uint32_t l = e & 7, sym = e >> 3;
             if (l == 0) { bad = 1; break; }
             ub_take(in, l);
             if (sym < 16) {
-              if (lane == 0) L.lens[i < hlit ? i : 288 + (i - hlit)] = (uint8_t)sym;
+              if (lane == 0) L.b.lens[i < hlit ? i : 288 + (i - hlit)] = (uint8_t)sym;
               prev = sym;
               i++;
             } else {
@@ -616,20 +632,20 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
               if (lane == 0)
                 for (uint32_t k = 0; k < rep; k++) {
                   uint32_t j = i + k;
-                  L.lens[j < hlit ? j : 288 + (j - hlit)] = (uint8_t)val;
+                  L.b.lens[j < hlit ? j : 288 + (j - hlit)] = (uint8_t)val;
                 }
               if (sym != 16) prev = 0;
               i += rep;
             }
           }
           if (bad) { st = INF_BAD_CODE | (2u << 8); break; }
-          for (uint32_t k = hlit + lane; k < 288; k += WAVE) L.lens[k] = 0;
-          for (uint32_t k = 288 + hdist + lane; k < 320; k += WAVE) L.lens[k] = 0;
+          for (uint32_t k = hlit + lane; k < 288; k += WAVE) L.b.lens[k] = 0;
+          for (uint32_t k = 288 + hdist + lane; k < 320; k += WAVE) L.b.lens[k] = 0;
           __syncthreads();
         }
       }
-      if (v2_build(L, L.lens, 288, L.lit_fast, V2_LIT_BITS, V2_LIT_SUB, L.lit_sorted, L.lit_count, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
-      if (v2_build(L, L.lens + 288, 32, L.dist_fast, V2_DIST_BITS, V2_DIST_SUB, L.dist_sorted, L.dist_count, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
+      if (v2_build(L, L.b.lens, 288, L.lit_fast, V2_LIT_BITS, V2_LIT_SUB, L.b.lit_sorted, L.b.lit_count, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
+      if (v2_build(L, L.b.lens + 288, 32, L.dist_fast, V2_DIST_BITS, V2_DIST_SUB, L.b.dist_sorted, L.b.dist_count, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
       P = ub_bitpos(in);
       TOCK(0);
 
@@ -646,7 +662,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         const uint64_t wb = P >> 5;
         const uint32_t nstage = 64 * sub_dw + 6;
         __syncthreads();
-        for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
+        if (!V2_GLOBAL_INPUT) for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
         __syncthreads();
         TOCK(1);
         const uint32_t rel0 = (uint32_t)(P & 31);
@@ -656,7 +672,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         {
           const uint32_t ov = lane == 0 ? 0u : (uint32_t)V2_OV_BITS;
           uint32_t first = bnd;
-          v2_pass<0>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first);
+          v2_pass<0>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first, base32 + wb);
           start = first;  // counts are valid from here
         }
         dbg_passes++;
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
           if (changed) start = pe;
           // a lane whose corrected start already lies beyond its limit owns no symbols
           if (changed && start >= limit) { end = start; nout = 0; nmatch = 0; flags = 0; }
-          { uint32_t f_ = 0; v2_pass<0>(L, changed && start < limit, start, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, 0, f_); }
+          { uint32_t f_ = 0; v2_pass<0>(L, changed && start < limit, start, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, 0, f_, base32 + wb); }
           dbg_passes++;
         }
         TOCK(2);
@@ -690,8 +706,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
           uint32_t e2 = 0, o2 = 0, m2 = 0, f2 = 0;
           if (!(ablate & 2u)) {
             uint32_t f_ = 0;
-            if (use_win) v2_pass<2>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_);
-            else v2_pass<1>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_);
+            if (use_win) v2_pass<2>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_, base32 + wb);
+            else v2_pass<1>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_, base32 + wb);
           }
           dbg_passes++;
           if (__ballot(valid && (f2 & F_BAD)) != 0ull) { st = INF_BAD_DIST; break; }
