@@ -25,6 +25,74 @@ DEFAULT_BLOCKS = 655360  # config 2: ~10 GiB compressed BGZF-BAM
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
+    """BGZF-FASTQ + GZI full scan (4 Utf8 columns), one partition per rank over its own file."""
+    synth = os.path.join(ROOT, "tools", "_build", "synth_fastq")
+    if not os.path.exists(synth):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.fastq.bgz")
+    ncpu = os.cpu_count() or 1
+    t0 = time.time()
+    meta = json.loads(subprocess.check_output([synth, path, str(args.blocks), str(42 + rank),
+                                               str(max(1, min(16, ncpu // max(1, world))))]).decode())
+    t_gen = time.time() - t0
+    prov = pkg.FastqTableProvider(path, None, device_id=local_rank)
+    plan = prov.scan(target_partitions=1)
+    assert plan.num_partitions() == 1
+    for p in (path, path + ".gzi"):
+        if not args.keep_file:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    st = None
+    for _ in range(args.warmup):
+        st = plan.execute_device(0, args.batch_size)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = plan.execute_device(0, args.batch_size)
+    sync()
+    elapsed = time.perf_counter() - t0
+    rows, ubytes = float(st["n_rows"]), float(st["inflated_bytes"])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rows, ubytes], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rows, ubytes = [float(x) for x in c.tolist()]
+    if rank == 0:
+        per_step = elapsed / args.steps
+        cu = float(st["compressed_bytes"]) + float(st["inflated_bytes"])
+        achieved = cu / (st["ms_inflate"] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "bgzf_fastq_full_scan_records_per_sec", "value": round(rows / per_step / 1e6, 3), "unit": "Mrec/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BGZF-FASTQ + GZI full scan, synthetic 101bp reads", "n_blocks_per_gpu": meta["n_blocks"],
+                       "records_per_gpu": meta["n_records"], "compressed_bytes_per_gpu": meta["compressed_bytes"],
+                       "inflated_bytes_per_gpu": meta["inflated_bytes"], "batch_size": args.batch_size},
+            "decoded_GB_s": round(ubytes / per_step / 1e9, 3),
+            "stage_ms": {"inflate": round(st["ms_inflate"], 3), "crc32": round(st["ms_crc"], 3),
+                         "newline_index": round(st["ms_chain"], 3), "extract": round(st["ms_extract"], 3)},
+            "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate_v2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+            "cpu_baseline": None,
+            "reference_published": {"source": "openspec/changes/refactor-single-thread-partition-reads/design.md:29-36",
+                                    "Mrec_s": {"1 thread": 1.49, "8 threads": 11.2, "8 partitions reader+consumer threads": 17.4},
+                                    "note": "different file (523 MB, 26.5 M reads) and unstated developer machine"},
+            "setup_s": {"generate": round(t_gen, 1)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -36,6 +104,9 @@ def main():
     ap.add_argument("--cpu-sample-blocks", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-file", action="store_true")
+    ap.add_argument("--format", default="bam", choices=["bam", "fastq"],
+                    help="bam (default, BASELINE.json config 2) or fastq (BGZF-FASTQ + GZI full scan: the only scan the "
+                         "reference publishes numbers for, openspec/.../design.md:29-36)")
     ap.add_argument("--mode", default="sequential", choices=["sequential", "indexed"],
                     help="sequential: each rank scans its own file as one partition (weak scaling, default). "
                          "indexed: every rank opens the SAME file, the BAI plan (target_partitions = 8 x ranks) is "
@@ -55,6 +126,8 @@ def main():
     import __graft_entry__ as ge
     pkg = ge._load_pkg()
     pkg.load_library()
+    if args.format == "fastq":
+        return bench_fastq(args, pkg, rank, local_rank, world, torch, dist)
 
     # ---- synthetic input (deterministic in (blocks, seed)) ----
     synth = os.path.join(ROOT, "tools", "_build", "synth_bam")

@@ -760,8 +760,10 @@ static void copy_result_to_host(Result& res, hipStream_t st) {
       col.h_off32.alloc(bytes);
       HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, st));
       col.h_batch_base.resize(nb);
-      for (uint64_t b = 0; b < nb; b++)
-        HIP_CHECK(hipMemcpyAsync(&col.h_batch_base[b], col.d_off64.p + b * batch_size, 8, hipMemcpyDeviceToHost, st));
+      DevBuf<uint64_t> d_base(nb);
+      launch_batch_bases(col.d_off64.p, nb, batch_size, d_base.p, st);
+      HIP_CHECK(hipMemcpyAsync(col.h_batch_base.data(), d_base.p, nb * 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));  // d_base is released at the end of this scope
     }
     if (col.d_valid.p && n) {
       col.h_valid.alloc(nwords * 8 + 8);

@@ -104,6 +104,7 @@ void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0,
                           const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
                           RowOverride ov, uint32_t* err, hipStream_t st);
 void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, int32_t* off32, hipStream_t st);
+void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint64_t* base, hipStream_t st);
 void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n,
                           const uint64_t* off_name, uint8_t* d_name,
                           const uint64_t* off_chrom, uint8_t* d_chrom,

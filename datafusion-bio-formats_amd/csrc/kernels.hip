@@ -523,6 +523,16 @@ void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch
   hipLaunchKernelGGL(k_batch_offsets, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, off64, n_rows, batch_size, off32);
 }
 
+// base[b] = off64[b * bs]: first byte / element of every batch (host export builds zero-copy windows from it)
+__global__ void k_batch_bases(const uint64_t* __restrict__ off64, uint64_t nb, uint32_t bs, uint64_t* __restrict__ base) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) base[b] = off64[b * bs];
+}
+void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint64_t* base, hipStream_t st) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_batch_bases, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, st, off64, nb, bs, base);
+}
+
 // =================================================================================================
 // K7a: short var-len columns, one record per lane (name, chrom, cigar, mate_chrom)
 // =================================================================================================

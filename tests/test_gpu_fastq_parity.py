@@ -168,3 +168,24 @@ def test_edge_cases(pkg, fo, tmp_path):
             # guaranteed complete.
             if target == 1:
                 assert n == 400, (p_, target, n)
+
+
+def test_synthetic_fastq_partitions(pkg, fo, tmp_path):
+    """medium scale: tools/synth_fastq (records straddle members), GPU == oracle per partition."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "_build", "synth_fastq")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    path = str(tmp_path / "s.fastq.bgz")
+    meta = json.loads(subprocess.check_output([exe, path, "200", "5", "8"]).decode())
+    orc = fo.FastqOracle(path)
+    for target in (1, 6):
+        strat, parts = orc.scan(target)
+        prov, plan, got = _run_gpu(pkg, path, target)
+        n = 0
+        for p, part in enumerate(parts):
+            _, want = orc.execute(strat, part)
+            _cmp(got[p], want, (target, p))
+            n += sum(b.num_rows for b in got[p])
+        assert n == meta["n_records"]
