@@ -150,9 +150,20 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
   for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = 0;
   if (lane < 16) count[lane] = 0;
   __syncthreads();
+  // 1. histogram of code lengths: 64 symbols per step, one ballot per length value; lane L keeps count[L]
+  uint32_t my_cnt = 0;
+  for (int c0 = 0; c0 < n; c0 += WAVE) {
+    const int sidx = c0 + lane;
+    const int l = sidx < n ? (int)lens[sidx] : 0;
+#pragma unroll
+    for (int Lk = 1; Lk <= 15; Lk++) {
+      const unsigned long long m = __ballot(l == Lk);
+      if (lane == Lk) my_cnt += (uint32_t)__popcll(m);
+    }
+  }
+  if (lane >= 1 && lane <= 15) count[lane] = (uint16_t)my_cnt;
+  __syncthreads();
   if (lane == 0) {
-    for (int s = 0; s < n; s++) count[lens[s]]++;
-    count[0] = 0;
     uint32_t o = 0, code = 0;
     int left = 1, over = 0;
     for (int l = 1; l <= 15; l++) {
@@ -160,7 +171,6 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       code <<= 1;
       L.b.t_first[l] = (uint16_t)code;
       L.b.t_offs[l] = (uint16_t)o;
-      L.b.t_w[l] = (uint16_t)o;
       o += c;
       code += c;
       left <<= 1;
@@ -168,10 +178,31 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       if (left < 0) over = 1;
     }
     L.b.t_offs[0] = (uint16_t)o;
-    for (int s = 0; s < n; s++) {
-      int l = lens[s];
-      if (l) sorted[L.b.t_w[l]++] = (uint16_t)s;
+    L.b.t_first[0] = (uint16_t)over;
+  }
+  __syncthreads();
+  // 2. canonical order (by length, then symbol): rank of a symbol inside its length class = symbols of
+  //    the same length with a smaller index -> per-chunk ballots with a running base per length
+  {
+    uint32_t run_base = (lane >= 1 && lane <= 15) ? (uint32_t)L.b.t_offs[lane] : 0u;  // lane L tracks length L
+    for (int c0 = 0; c0 < n; c0 += WAVE) {
+      const int sidx = c0 + lane;
+      const int l = sidx < n ? (int)lens[sidx] : 0;
+      uint32_t slot = 0;
+#pragma unroll
+      for (int Lk = 1; Lk <= 15; Lk++) {
+        const unsigned long long m = __ballot(l == Lk);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)run_base, Lk);
+        if (l == Lk) slot = b + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == Lk) run_base += (uint32_t)__popcll(m);
+      }
+      if (l) sorted[slot] = (uint16_t)sidx;
     }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    uint32_t o = L.b.t_offs[0];
+    int over = L.b.t_first[0];
     // sub-tables (serial: long codes are few)
     uint32_t k = root_bits < 15 ? L.b.t_offs[root_bits + 1] : o;
     uint32_t next_free = 1u << root_bits;
