@@ -837,14 +837,15 @@ def _num(v):
     return None
 
 
-def evaluate_record_filters(fields: dict, filters) -> bool:
+def evaluate_record_filters(fields: dict, filters, string_fields=("chrom",),
+                            num_fields=("start", "end", "mapping_quality", "flags")) -> bool:
     """record_filter.rs:57-283 with BamRecordFields (storage.rs:456-494): `chrom` is the only
     string field; start/end/mapping_quality/flags are u32 fields; anything else passes."""
     for col, op, val in filters:
         if op in ("=", "!=", "<", "<=", ">", ">="):
             if val is None:
                 return False
-            sv = fields.get("chrom") if col == "chrom" else None
+            sv = fields.get(col) if col in string_fields else None
             if sv is not None:
                 if not isinstance(val, str):
                     continue
@@ -853,7 +854,7 @@ def evaluate_record_filters(fields: dict, filters) -> bool:
                 if op == "!=" and not (sv != val):
                     return False
                 continue
-            nv = fields.get(col) if col in ("start", "end", "mapping_quality", "flags") else None
+            nv = fields.get(col) if col in num_fields else None
             if nv is None:
                 continue
             lv = _num(val)
@@ -867,7 +868,7 @@ def evaluate_record_filters(fields: dict, filters) -> bool:
             lo, hi = val
             if lo is None or hi is None:
                 return False
-            nv = fields.get(col) if col in ("start", "end", "mapping_quality", "flags") else None
+            nv = fields.get(col) if col in num_fields else None
             if nv is None:
                 continue
             l, h = _num(lo), _num(hi)
@@ -878,8 +879,8 @@ def evaluate_record_filters(fields: dict, filters) -> bool:
                 return False
         elif op in ("in", "not in"):
             neg = op == "not in"
-            sv = fields.get("chrom") if col == "chrom" else None
-            nv = fields.get(col) if col in ("start", "end", "mapping_quality", "flags") else None
+            sv = fields.get(col) if col in string_fields else None
+            nv = fields.get(col) if col in num_fields else None
             if sv is None and nv is None:
                 continue
             saw_null, hit = False, False
