@@ -1,0 +1,160 @@
+// bgzf_source.cpp -- see bgzf_source.h
+#include "bgzf_source.h"
+
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace bioscan {
+
+const char* inflate_status_str(uint32_t s) {
+  switch (s) {
+    case INF_BAD_HEADER: return "invalid BGZF header";
+    case INF_BAD_BTYPE: return "invalid DEFLATE block type";
+    case INF_BAD_CODE: return "invalid Huffman code";
+    case INF_BAD_DIST: return "invalid match distance";
+    case INF_OVERRUN: return "output overrun";
+    case INF_SIZE_MISMATCH: return "ISIZE mismatch";
+    case INF_BAD_STORED: return "invalid stored block";
+    case INF_CRC_MISMATCH: return "CRC32 mismatch";
+    default: return "unknown";
+  }
+}
+
+
+BgzfSource::~BgzfSource() {
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void BgzfSource::load_file() {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) throw Error(std::string("Failed to open ") + what + ": " + path + ": " + strerror(errno));
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  file_len = (size_t)sz;
+  file.alloc(file_len + 4096);
+  size_t got = 0;
+  while (got < file_len) {
+    size_t r = fread(file.p + got, 1, std::min<size_t>(file_len - got, 1u << 30), f);
+    if (r == 0) break;
+    got += r;
+  }
+  fclose(f);
+  if (got != file_len) throw Error("short read on " + path);
+  memset(file.p + file_len, 0, 4096);
+}
+
+void BgzfSource::frame() {
+  blk_coff.clear();
+  blk_uoff.clear();
+  uint64_t o = 0, uo = 0;
+  const uint8_t* d = file.p;
+  while (o < file_len) {
+    if (file_len - o < 18) throw Error("BGZF: truncated block header at offset " + std::to_string(o));
+    if (d[o] != 0x1f || d[o + 1] != 0x8b || d[o + 2] != 8 || !(d[o + 3] & 4))
+      throw Error("BGZF: invalid block header at offset " + std::to_string(o));
+    uint32_t xlen = d[o + 10] | (d[o + 11] << 8);
+    uint64_t p = o + 12, pe = o + 12 + xlen;
+    int64_t bsize = -1;
+    while (p + 4 <= pe) {
+      uint32_t slen = d[p + 2] | (d[p + 3] << 8);
+      if (d[p] == 66 && d[p + 1] == 67 && slen == 2) bsize = (int64_t)(d[p + 4] | (d[p + 5] << 8)) + 1;
+      p += 4 + slen;
+    }
+    if (bsize < 0 || o + (uint64_t)bsize > file_len || (uint64_t)bsize < 12 + xlen + 8)
+      throw Error("BGZF: invalid block size at offset " + std::to_string(o));
+    uint32_t isize;
+    memcpy(&isize, d + o + bsize - 4, 4);
+    if (isize > 65536) throw Error("BGZF: ISIZE > 64 KiB at offset " + std::to_string(o));
+    blk_coff.push_back(o);
+    blk_uoff.push_back(uo);
+    o += (uint64_t)bsize;
+    uo += isize;
+  }
+  blk_coff.push_back(o);
+  blk_uoff.push_back(uo);
+  ulen = uo;
+}
+
+void BgzfSource::make_resident() {
+  if (resident) return;
+  set_device();
+  if (!stream) HIP_CHECK(hipStreamCreate(&stream));
+  d_comp.alloc(file_len + 4096);
+  HIP_CHECK(hipMemcpyAsync(d_comp.p, file.p, file_len + 4096, hipMemcpyHostToDevice, stream));
+  d_coff.alloc(blk_coff.size());
+  d_uoff.alloc(blk_uoff.size());
+  HIP_CHECK(hipMemcpyAsync(d_coff.p, blk_coff.data(), blk_coff.size() * 8, hipMemcpyHostToDevice, stream));
+  HIP_CHECK(hipMemcpyAsync(d_uoff.p, blk_uoff.data(), blk_uoff.size() * 8, hipMemcpyHostToDevice, stream));
+  d_status.alloc(std::max<size_t>(n_blocks(), 1));
+  {
+    hipDeviceProp_t pr;
+    HIP_CHECK(hipGetDeviceProperties(&pr, device));
+    const char* g = getenv("BIOSCAN_V2_WG_PER_CU");
+    v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)(g ? atoi(g) : v2_resident_wg_per_cu());
+    v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
+    d_v2_ctr.alloc(32);
+    d_v2_scratch.alloc((size_t)v2_grid * V2_SCRATCH_STRIDE);
+  }
+  HIP_CHECK(hipStreamSynchronize(stream));
+  resident = true;
+}
+
+void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
+  uint8_t* base = dst - blk_uoff[b0];
+  if (getenv("BIOSCAN_INFLATE_V1")) {
+    launch_bgzf_inflate(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, stream);
+  } else {
+    HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
+    launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
+                           V2_SCRATCH_STRIDE, v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
+  }
+}
+
+void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
+  launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);
+}
+
+void BgzfSource::report_v2_debug(uint32_t nb) {
+  if (!getenv("BIOSCAN_DEBUG") || getenv("BIOSCAN_INFLATE_V1")) return;
+  uint32_t h[32];
+  HIP_CHECK(hipMemcpy(h, d_v2_ctr.p, 128, hipMemcpyDeviceToHost));
+  unsigned long long tc[5];
+  memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
+  fprintf(stderr, "[bioscan] inflate v2: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
+          h[2] ? (double)h[3] / h[2] : 0.0);
+  double tot = 0;
+  for (int i = 0; i < 5; i++) tot += (double)tc[i];
+  const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
+  for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+}
+
+void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {
+  if (getenv("BIOSCAN_V2_ABLATE")) return;  // timing-only ablation builds produce wrong bytes on purpose
+  std::vector<uint32_t> st(nb);
+  HIP_CHECK(hipMemcpy(st.data(), d_status.p + b0, nb * 4, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < nb; i++)
+    if (st[i] != INF_OK)
+      throw Error(std::string(what) + " read error: BGZF block " + std::to_string(b0 + i) + " at offset " +
+                  std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st[i] & 0xFF) + " (code " + std::to_string(st[i]) + ")");
+}
+
+std::vector<uint8_t> BgzfSource::inflate_prefix_to_host(uint32_t b1) {
+  make_resident();
+  b1 = std::min(b1, n_blocks());
+  uint64_t bytes = blk_uoff[b1];
+  DevBuf<uint8_t> tmp(bytes + 64);
+  launch_inflate(tmp.p, b1);
+  launch_crc(tmp.p, b1);
+  HIP_CHECK(hipStreamSynchronize(stream));
+  check_inflate_status(0, b1);
+  std::vector<uint8_t> out(bytes);
+  if (bytes) HIP_CHECK(hipMemcpy(out.data(), tmp.p, bytes, hipMemcpyDeviceToHost));
+  return out;
+}
+
+}  // namespace bioscan

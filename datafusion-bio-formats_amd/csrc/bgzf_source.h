@@ -1,0 +1,53 @@
+// bgzf_source.h -- a compressed (BGZF) or plain input file resident in HBM, shared by the BAM, FASTQ and
+// VCF scan paths: host framing of the member chain, upload, and launches of the inflate / CRC kernels.
+// Replaces noodles-bgzf's `io::Reader` (call sites bam/src/storage.rs:161-169, fastq/src/physical_exec.rs:482-491,
+// vcf/src/storage.rs:117-122, 766-776) at block granularity.
+#pragma once
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace bioscan {
+
+const char* inflate_status_str(uint32_t s);
+
+struct BgzfSource {
+  std::string path;
+  const char* what = "BAM";  // format name used in error messages
+  int device = 0;
+
+  HostBuf file;  // pinned copy of the file (+ slack)
+  size_t file_len = 0;
+  std::vector<uint64_t> blk_coff, blk_uoff;  // n_blocks + 1 entries each
+  uint64_t ulen = 0;
+
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  bool resident = false;
+  DevBuf<uint8_t> d_comp;
+  DevBuf<uint64_t> d_coff, d_uoff;
+  DevBuf<uint32_t> d_status;
+  DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..] debug counters
+  DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
+  uint32_t v2_grid = 0;
+  DevBuf<uint8_t> d_u;  // inflated bytes of the range decoded last
+
+  ~BgzfSource();
+  uint32_t n_blocks() const { return (uint32_t)(blk_coff.size() - 1); }
+  void set_device() { HIP_CHECK(hipSetDevice(device)); }
+  void load_file();
+  void frame();  // BGZF framing (SAM spec 4.1): walk the member chain; inflated offsets from the ISIZE trailers
+  void make_resident();
+  // Inflate members [b0, b0+nb) so that member b0's payload lands at dst[0].
+  void launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
+  void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
+  void report_v2_debug(uint32_t nb);
+  void check_inflate_status(uint32_t b0, uint32_t nb);
+  // Inflate blocks [0, b1) into a temporary device buffer and copy to the host (header / sampling).
+  std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1);
+};
+
+}  // namespace bioscan

@@ -21,6 +21,8 @@
 #include "bam_host.h"
 #include "common.h"
 #include "kernels.h"
+#include "bgzf_source.h"
+#include "vcf_api.h"
 
 using namespace bioscan;
 
@@ -90,20 +92,6 @@ struct StageTimer {
   }
 };
 
-static const char* inflate_status_str(uint32_t s) {
-  switch (s) {
-    case INF_BAD_HEADER: return "invalid BGZF header";
-    case INF_BAD_BTYPE: return "invalid DEFLATE block type";
-    case INF_BAD_CODE: return "invalid Huffman code";
-    case INF_BAD_DIST: return "invalid match distance";
-    case INF_OVERRUN: return "output overrun";
-    case INF_SIZE_MISMATCH: return "ISIZE mismatch";
-    case INF_BAD_STORED: return "invalid stored block";
-    case INF_CRC_MISMATCH: return "CRC32 mismatch";
-    default: return "unknown";
-  }
-}
-
 // members [b_lo, b_hi) + the record-aligned window of their inflated bytes that belongs to the caller
 struct DecodeRange {
   uint32_t b_lo = 0, b_hi = 0;
@@ -116,9 +104,7 @@ struct DecodeRange {
 // -------------------------------------------------------------------------------------------------
 // Provider
 // -------------------------------------------------------------------------------------------------
-struct Provider {
-  std::string path;
-  int device = 0;
+struct Provider : BgzfSource {
   int kind = 0;              // 0 = BAM, 1 = FASTQ
   int fq_compression = 0;    // FASTQ: 0 = none, 1 = BGZF
   bool fq_has_gzi = false;
@@ -128,11 +114,6 @@ struct Provider {
   std::vector<std::string> tag_fields;
   bool has_tag_fields = false;
 
-  HostBuf file;  // pinned copy of the compressed file (+ slack)
-  size_t file_len = 0;
-  std::vector<uint64_t> blk_coff, blk_uoff;  // n_blocks + 1 entries each
-  uint64_t ulen = 0;
-
   BamHeader hdr;
   std::vector<FieldDef> fields;  // full schema
   std::vector<std::pair<std::string, std::string>> metadata;
@@ -141,20 +122,9 @@ struct Provider {
   std::string index_path;
   Bai bai;
 
-  std::mutex mu;
-  hipStream_t stream = nullptr;
-  bool resident = false;
-  DevBuf<uint8_t> d_comp;
-  DevBuf<uint64_t> d_coff, d_uoff;
-  DevBuf<uint32_t> d_status;
-  DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..2] debug counters
-  DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
-  uint32_t v2_grid = 0;
-
   bool decoded = false;
   bool have_keys = false;
   DecodeRange dec_range;
-  DevBuf<uint8_t> d_u;
   DevBuf<uint64_t> d_rec_off;
   uint64_t n_rec = 0;
   DevBuf<int32_t> k_refid, k_pos, k_end1;
@@ -163,102 +133,11 @@ struct Provider {
   DevBuf<uint32_t> d_ref_name_off, d_ref_name_len;
   bioscan_scan_stats decode_stats{};
 
-  ~Provider() {
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-
-  uint32_t n_blocks() const { return (uint32_t)(blk_coff.size() - 1); }
   DecodeRange whole_file() const {
     DecodeRange r;
     r.b_lo = 0; r.b_hi = n_blocks();
     r.first_rel = hdr.first_record_offset; r.stop_rel = ulen;
     return r;
-  }
-
-  void set_device() { HIP_CHECK(hipSetDevice(device)); }
-
-  void load_file() {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) throw Error("Failed to open BAM: " + path + ": " + strerror(errno));
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    file_len = (size_t)sz;
-    file.alloc(file_len + 4096);
-    size_t got = 0;
-    while (got < file_len) {
-      size_t r = fread(file.p + got, 1, std::min<size_t>(file_len - got, 1u << 30), f);
-      if (r == 0) break;
-      got += r;
-    }
-    fclose(f);
-    if (got != file_len) throw Error("short read on " + path);
-    memset(file.p + file_len, 0, 4096);
-  }
-
-  // BGZF framing (SAM spec 4.1): walk the member chain; uoff from ISIZE trailers.
-  void frame() {
-    blk_coff.clear();
-    blk_uoff.clear();
-    uint64_t o = 0, uo = 0;
-    const uint8_t* d = file.p;
-    while (o < file_len) {
-      if (file_len - o < 18) throw Error("BGZF: truncated block header at offset " + std::to_string(o));
-      if (d[o] != 0x1f || d[o + 1] != 0x8b || d[o + 2] != 8 || !(d[o + 3] & 4))
-        throw Error("BGZF: invalid block header at offset " + std::to_string(o));
-      uint32_t xlen = d[o + 10] | (d[o + 11] << 8);
-      uint64_t p = o + 12, pe = o + 12 + xlen;
-      int64_t bsize = -1;
-      while (p + 4 <= pe) {
-        uint32_t slen = d[p + 2] | (d[p + 3] << 8);
-        if (d[p] == 66 && d[p + 1] == 67 && slen == 2) bsize = (int64_t)(d[p + 4] | (d[p + 5] << 8)) + 1;
-        p += 4 + slen;
-      }
-      if (bsize < 0 || o + (uint64_t)bsize > file_len || (uint64_t)bsize < 12 + xlen + 8)
-        throw Error("BGZF: invalid block size at offset " + std::to_string(o));
-      uint32_t isize;
-      memcpy(&isize, d + o + bsize - 4, 4);
-      if (isize > 65536) throw Error("BGZF: ISIZE > 64 KiB at offset " + std::to_string(o));
-      blk_coff.push_back(o);
-      blk_uoff.push_back(uo);
-      o += (uint64_t)bsize;
-      uo += isize;
-    }
-    blk_coff.push_back(o);
-    blk_uoff.push_back(uo);
-    ulen = uo;
-  }
-
-  void make_resident() {
-    if (resident) return;
-    set_device();
-    if (!stream) HIP_CHECK(hipStreamCreate(&stream));
-    d_comp.alloc(file_len + 4096);
-    HIP_CHECK(hipMemcpyAsync(d_comp.p, file.p, file_len + 4096, hipMemcpyHostToDevice, stream));
-    d_coff.alloc(blk_coff.size());
-    d_uoff.alloc(blk_uoff.size());
-    HIP_CHECK(hipMemcpyAsync(d_coff.p, blk_coff.data(), blk_coff.size() * 8, hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipMemcpyAsync(d_uoff.p, blk_uoff.data(), blk_uoff.size() * 8, hipMemcpyHostToDevice, stream));
-    d_status.alloc(std::max<size_t>(n_blocks(), 1));
-    {
-      hipDeviceProp_t pr;
-      HIP_CHECK(hipGetDeviceProperties(&pr, device));
-      const char* g = getenv("BIOSCAN_V2_WG_PER_CU");
-      v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)(g ? atoi(g) : v2_resident_wg_per_cu());
-      v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
-      d_v2_ctr.alloc(32);
-      d_v2_scratch.alloc((size_t)v2_grid * V2_SCRATCH_STRIDE);
-    }
-    // reference-name LUT
-    std::vector<uint32_t> off{0}, len;
-    std::string blob;
-    for (auto& n : hdr.ref_names) {
-      blob += n;
-      off.push_back((uint32_t)blob.size());
-      len.push_back((uint32_t)n.size());
-    }
-    HIP_CHECK(hipStreamSynchronize(stream));
-    resident = true;
   }
 
   void upload_ref_names() {
@@ -275,60 +154,6 @@ struct Provider {
     if (!blob.empty()) HIP_CHECK(hipMemcpy(d_ref_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_ref_name_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (!len.empty()) HIP_CHECK(hipMemcpy(d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
-  }
-
-  // Inflate members [b0, b0+nb) so that member b0's payload lands at dst[0]: the kernels index the
-  // output by absolute inflated offsets, so they get the base pointer shifted back by blk_uoff[b0].
-  void launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0 = 0) {
-    uint8_t* base = dst - blk_uoff[b0];
-    if (getenv("BIOSCAN_INFLATE_V1")) {
-      launch_bgzf_inflate(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, stream);
-    } else {
-      HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
-      launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
-                             V2_SCRATCH_STRIDE, v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
-    }
-  }
-  void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0) {
-    launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);
-  }
-  void report_v2_debug(uint32_t nb) {
-    if (!getenv("BIOSCAN_DEBUG") || getenv("BIOSCAN_INFLATE_V1")) return;
-    uint32_t h[32];
-    HIP_CHECK(hipMemcpy(h, d_v2_ctr.p, 128, hipMemcpyDeviceToHost));
-    unsigned long long tc[5];
-    memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
-    fprintf(stderr, "[bioscan] inflate v2: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
-            h[2] ? (double)h[3] / h[2] : 0.0);
-    double tot = 0;
-    for (int i = 0; i < 5; i++) tot += (double)tc[i];
-    const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
-    for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
-  }
-
-  void check_inflate_status(uint32_t b0, uint32_t nb) {
-    if (getenv("BIOSCAN_V2_ABLATE")) return;  // timing-only ablation builds produce wrong bytes on purpose
-    std::vector<uint32_t> st(nb);
-    HIP_CHECK(hipMemcpy(st.data(), d_status.p + b0, nb * 4, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < nb; i++)
-      if (st[i] != INF_OK)
-        throw Error(std::string("BAM read error: BGZF block ") + std::to_string(b0 + i) + " at offset " +
-                    std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st[i] & 0xFF) + " (code " + std::to_string(st[i]) + ")");
-  }
-
-  // Inflate blocks [b0, b1) into a temporary device buffer and copy to the host (header / sampling).
-  std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1) {
-    make_resident();
-    b1 = std::min(b1, n_blocks());
-    uint64_t bytes = blk_uoff[b1];
-    DevBuf<uint8_t> tmp(bytes + 64);
-    launch_inflate(tmp.p, b1);
-    launch_crc(tmp.p, b1);
-    HIP_CHECK(hipStreamSynchronize(stream));
-    check_inflate_status(0, b1);
-    std::vector<uint8_t> out(bytes);
-    if (bytes) HIP_CHECK(hipMemcpy(out.data(), tmp.p, bytes, hipMemcpyDeviceToHost));
-    return out;
   }
 
   // Full decode: inflate every block, find every record, build the key table.  Cached.
@@ -1444,9 +1269,9 @@ static bool file_exists(const std::string& s) {
 // =================================================================================================
 // C ABI
 // =================================================================================================
-struct bioscan_provider { Provider p; };
-struct bioscan_plan { Plan pl; };
-struct bioscan_stream { Stream s; };
+struct bioscan_provider { Provider p; std::unique_ptr<VcfProviderI> vcf; };
+struct bioscan_plan { Plan pl; std::unique_ptr<VcfPlanI> vcf; };
+struct bioscan_stream { Stream s; std::unique_ptr<VcfStreamI> vcf; };
 
 #define API_BEGIN try {
 #define API_END                                     \
@@ -1593,14 +1418,64 @@ int bioscan_fastq_open(const char* path, int32_t device_id, bioscan_provider** o
   API_END
 }
 
+void bioscan_vcf_options_default(bioscan_vcf_options* o) {
+  memset(o, 0, sizeof(*o));
+  o->coordinate_system_zero_based = 1;
+}
+
+int bioscan_vcf_open(const char* path, const bioscan_vcf_options* opts, bioscan_provider** out) {
+  API_BEGIN
+  bioscan_vcf_options o;
+  if (opts) o = *opts; else bioscan_vcf_options_default(&o);
+  {
+    char nm[8];
+    if (bioscan_device_check(o.device_id, nm, sizeof nm)) throw Error(g_err);
+  }
+  std::unique_ptr<bioscan_provider> bp(new bioscan_provider);
+  bp->vcf.reset(vcf_open(path, &o));
+  *out = bp.release();
+  API_END
+}
+
+int bioscan_udf_list_avg(const struct ArrowArray* in, const struct ArrowSchema* in_schema, int32_t device_id,
+                         struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  API_BEGIN
+  {
+    char nm[8];
+    if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(g_err);
+  }
+  udf_list_avg_host(in, in_schema, device_id, out, out_schema);
+  API_END
+}
+int bioscan_udf_list_cmp(const struct ArrowArray* in, const struct ArrowSchema* in_schema, int32_t op, double threshold,
+                         int32_t device_id, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  API_BEGIN
+  {
+    char nm[8];
+    if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(g_err);
+  }
+  if (op != 0 && op != 1) throw Error("list comparison op must be 0 (list_gte) or 1 (list_lte)");
+  udf_list_cmp_host(in, in_schema, op, threshold, device_id, out, out_schema);
+  API_END
+}
+int bioscan_stream_list_udf(bioscan_stream* s, const char* field, int32_t udf, double threshold, bioscan_udf_stats* out) {
+  API_BEGIN
+  if (!s->vcf) throw Error("list UDFs apply to VCF streams");
+  if (udf < 0 || udf > 2) throw Error("udf must be 0 (list_avg), 1 (list_gte) or 2 (list_lte)");
+  s->vcf->list_udf(field, udf, threshold, out);
+  API_END
+}
+
 int bioscan_schema(const bioscan_provider* p, struct ArrowSchema* out) {
   API_BEGIN
+  if (p->vcf) { p->vcf->schema(out); return 0; }
   export_schema(p->p.fields, p->p.metadata, out);
   API_END
 }
 
 int bioscan_supports_filters_pushdown(const bioscan_provider* p, const bioscan_filter* filters, int32_t n, int32_t* out) {
   API_BEGIN
+  if (p->vcf) { p->vcf->supports_filters_pushdown(filters, n, out); return 0; }
   auto fs = copy_filters(filters, n);
   for (int32_t i = 0; i < n; i++) {
     if (p->p.has_index && is_genomic_coordinate_filter(fs[i])) out[i] = 1;
@@ -1613,6 +1488,12 @@ int bioscan_supports_filters_pushdown(const bioscan_provider* p, const bioscan_f
 int bioscan_scan(const bioscan_provider* cp, const int32_t* projection, int32_t n_projection, const bioscan_filter* filters,
                  int32_t n_filters, int64_t limit, int32_t target_partitions, bioscan_plan** out) {
   API_BEGIN
+  if (cp->vcf) {
+    std::unique_ptr<bioscan_plan> vp(new bioscan_plan);
+    vp->vcf.reset(const_cast<bioscan_provider*>(cp)->vcf->scan(projection, n_projection, filters, n_filters, limit, target_partitions));
+    *out = vp.release();
+    return 0;
+  }
   Provider& p = const_cast<Provider&>(cp->p);
   std::unique_ptr<bioscan_plan> bp(new bioscan_plan);
   Plan& pl = bp->pl;
@@ -1694,15 +1575,21 @@ int bioscan_scan(const bioscan_provider* cp, const int32_t* projection, int32_t 
   API_END
 }
 
-int32_t bioscan_plan_num_partitions(const bioscan_plan* plan) { return plan->pl.n_partitions(); }
+int32_t bioscan_plan_num_partitions(const bioscan_plan* plan) { return plan->vcf ? plan->vcf->n_partitions() : plan->pl.n_partitions(); }
 
 int bioscan_plan_schema(const bioscan_plan* plan, struct ArrowSchema* out) {
   API_BEGIN
+  if (plan->vcf) { plan->vcf->schema(out); return 0; }
   export_schema(plan->pl.out_fields, plan->pl.prov->metadata, out);
   API_END
 }
 
 int32_t bioscan_plan_display(const bioscan_plan* plan, char* buf, int32_t cap) {
+  if (plan->vcf) {
+    std::string v = plan->vcf->display();
+    if (buf && cap > 0) snprintf(buf, cap, "%s", v.c_str());
+    return (int32_t)v.size();
+  }
   std::string s = plan->pl.prov->kind == 1 ? "FastqExec: projection=[" : "BamExec: projection=[";
   if (plan->pl.has_projection) {
     for (size_t i = 0; i < plan->pl.out_fields.size(); i++) {
@@ -1719,7 +1606,9 @@ int32_t bioscan_plan_display(const bioscan_plan* plan, char* buf, int32_t cap) {
 
 int32_t bioscan_plan_partition_desc(const bioscan_plan* plan, int32_t partition, char* buf, int32_t cap) {
   std::string s;
-  if (plan->pl.indexed && partition >= 0 && (size_t)partition < plan->pl.assignments.size())
+  if (plan->vcf) {
+    try { s = plan->vcf->partition_desc(partition); } catch (...) { s = "sequential"; }
+  } else if (plan->pl.indexed && partition >= 0 && (size_t)partition < plan->pl.assignments.size())
     s = describe_partition(plan->pl.assignments[partition]);
   else s = "sequential";
   if (buf && cap > 0) snprintf(buf, cap, "%s", s.c_str());
@@ -1729,6 +1618,12 @@ int32_t bioscan_plan_partition_desc(const bioscan_plan* plan, int32_t partition,
 static int execute_impl(const bioscan_plan* plan, int32_t partition, int32_t batch_size, bool device_only, bioscan_scan_stats* stats,
                         bioscan_stream** out) {
   API_BEGIN
+  if (plan->vcf) {
+    std::unique_ptr<bioscan_stream> vs(new bioscan_stream);
+    vs->vcf.reset(plan->vcf->execute(partition, batch_size, device_only, stats));
+    *out = vs.release();
+    return 0;
+  }
   if (partition < 0 || partition >= plan->pl.n_partitions()) throw Error("partition index out of range");
   if (batch_size <= 0) throw Error("batch_size must be positive");
   std::unique_ptr<bioscan_stream> bs(new bioscan_stream);
@@ -1749,6 +1644,10 @@ int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t 
 
 int bioscan_next(bioscan_stream* s, struct ArrowArray* out, int32_t* has_batch) {
   API_BEGIN
+  if (s->vcf) {
+    *has_batch = s->vcf->next(out) ? 1 : 0;
+    return 0;
+  }
   Stream& st = s->s;
   if (!st.res->on_host) throw Error("stream was executed device-only; no host batches to export");
   if (st.next >= st.res->n_batches()) {
@@ -1770,7 +1669,7 @@ void bioscan_provider_close(bioscan_provider* p) {
 
 int bioscan_provider_make_resident(bioscan_provider* p) {
   API_BEGIN
-  p->p.make_resident();
+  if (p->vcf) p->vcf->make_resident(); else p->p.make_resident();
   API_END
 }
 

@@ -1,0 +1,101 @@
+// vcf_kernels.h -- launch wrappers of the VCF text-path kernels (vcf_kernels.hip).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bioscan.h"
+
+namespace bioscan {
+
+enum VcfDevError : uint32_t {
+  VERR_NONE = 0, VERR_BLANK_LINE = 1, VERR_SHORT_RECORD = 2, VERR_BAD_POS = 3, VERR_MISSING_START = 4, VERR_BAD_END = 5,
+  VERR_BAD_QUAL = 6, VERR_FLOAT_PRECISION = 7, VERR_DUP_INFO_KEY = 8, VERR_BAD_INT = 9, VERR_BAD_FLOAT = 10,
+  VERR_INVALID_FLAG = 11, VERR_PERCENT = 12, VERR_BAD_GT = 13
+};
+
+// delimiter index over u[lo, hi): positions of '\n' and '\t', and for each newline the number of tabs before it
+uint64_t vcf_delim_chunks(uint64_t lo, uint64_t hi);
+void launch_vcf_delim_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt_nl, uint32_t* cnt_tab, hipStream_t st);
+void launch_vcf_delim_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base_nl, const uint64_t* base_tab,
+                            uint64_t* nl, uint64_t* nl_tabs, uint64_t* tab, hipStream_t st);
+
+struct VcfLines {
+  const uint64_t* nl;       // [n_nl] newline positions >= x0
+  const uint64_t* nl_tabs;  // [n_nl] tabs in [x0, nl[j])
+  const uint64_t* tab;      // [n_tab]
+  uint64_t n_nl, n_tab;
+  uint64_t x0, hi;          // first line start, end of the decoded bytes
+  uint64_t n_lines;         // n_nl (+1 for an unterminated last line at the end of the data)
+};
+void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, uint32_t* err,
+                     hipStream_t st);
+
+struct VcfFilterTerm {
+  int32_t field;     // 0 chrom, 1 start, 2 end, 3 id
+  int32_t op;        // bioscan_filter_op
+  int32_t n_vals;
+  int32_t has_null;
+  double vals[8];
+  uint32_t str_off[8], str_len[8];  // into the string blob (string fields)
+};
+struct VcfRowSelect {
+  int32_t mode;              // 0 every line, 1 region query
+  int32_t n_chunks;
+  uint64_t i_lo, i_hi;       // line range examined
+  uint32_t chrom_off, chrom_len;  // region chrom in the string blob
+  int64_t q_start1, q_end1;  // noodles interval (1-based inclusive)
+  int64_t start1, end1;      // reference's start filter; <= 0 = unbounded
+  int32_t zero_based;
+  int32_t n_terms;
+};
+void launch_vcf_row_flags(const uint8_t* u, VcfLines L, const uint32_t* pos, const uint32_t* vend, const uint8_t* flags,
+                          VcfRowSelect S, const uint64_t* chunks, const VcfFilterTerm* terms, const uint8_t* strs, uint32_t* keep,
+                          hipStream_t st);
+void launch_vcf_compact(const uint32_t* keep, const uint64_t* scan, uint64_t n, uint64_t i_lo, uint64_t* rows, uint64_t row_base,
+                        uint64_t cap, hipStream_t st);
+void launch_vcf_line_lower_bound(VcfLines L, uint64_t off, unsigned long long* result, hipStream_t st);
+void launch_vcf_iota_rows(uint64_t* rows, uint64_t n, hipStream_t st);
+
+struct VcfCoreCols {  // nullptr = not projected
+  uint64_t* src_chrom; uint32_t* len_chrom;
+  uint32_t* start; uint32_t* end;
+  uint64_t* src_id; uint32_t* len_id;
+  uint64_t* src_ref; uint32_t* len_ref;
+  uint64_t* src_alt; uint32_t* len_alt;
+  double* qual; uint64_t* v_qual;
+  uint64_t* src_filter; uint32_t* len_filter;
+};
+void launch_vcf_core(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint32_t* pos, const uint32_t* vend,
+                     const uint8_t* flags, VcfCoreCols C, int zero_based, uint32_t* err, hipStream_t st);
+void launch_replace_byte(uint8_t* d, uint64_t n, uint8_t from, uint8_t to, hipStream_t st);
+
+void launch_vcf_info_locate(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
+                            int K, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state, uint32_t* err, hipStream_t st);
+
+// typed span kernels: span c = u[off[c], off[c]+len[c]) with state[c] (0 absent, 1 value, 2 bare key)
+void launch_span_num(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, int kind,
+                     uint32_t* values, uint64_t* valid, uint32_t* err, hipStream_t st);
+void launch_span_flag(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint64_t* bits,
+                      uint32_t* err, hipStream_t st);
+void launch_span_str(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* out_len,
+                     uint64_t* valid, uint32_t* err, hipStream_t st);
+void launch_span_list_count(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* cnt,
+                            uint64_t* valid, hipStream_t st);
+void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N,
+                            const uint64_t* eoff, int kind, uint32_t* values, uint64_t* esrc, uint32_t* elen, uint8_t* evalid,
+                            uint32_t* err, hipStream_t st);
+void launch_pack_bits(const uint8_t* bytes, uint64_t n, uint64_t* words, hipStream_t st);
+void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st);
+
+void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
+                            int S, int16_t* fpos, hipStream_t st);
+void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
+                             const int16_t* fpos, int S, int gt_field, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state,
+                             uint32_t* err, hipStream_t st);
+
+// list UDFs: off = u64 list offsets (n+1), values = 32-bit elements, evalid / lvalid = validity words or nullptr
+void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t* evalid, const uint64_t* lvalid, uint64_t n,
+                     int is_float, double* out, uint8_t* out_valid, hipStream_t st);
+void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st);
+
+}  // namespace bioscan

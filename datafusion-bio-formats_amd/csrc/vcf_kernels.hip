@@ -1,0 +1,914 @@
+// vcf_kernels.hip -- gfx950 kernels of the VCF text path (K9 in DESIGN.md): delimiter index, line keys,
+// row selection, core / INFO / FORMAT field extraction into Arrow buffers, list UDFs.
+//
+// Replaces, per record, noodles-vcf's lazy `Record` accessors driven by
+// bio-format-vcf/src/physical_exec.rs:991-1116 (sequential) / :2858-2999 (indexed), load_infos_single_pass
+// :544-640, MultiSampleFormatBuilder::append_record :1634-1828, load_formats_single_pass :2265-2443 and the
+// list UDFs udfs.rs:67-110, :606-650.
+//
+// Text layout: `u` holds the decoded bytes of the scanned range; every offset below is relative to u.
+// The delimiter index is two sorted position arrays ('\n' and '\t') plus, for every newline, the number
+// of tabs before it, so field f of line i is found with two loads instead of a byte scan.
+#include "vcf_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace bioscan {
+
+constexpr int WAVE = 64;
+constexpr int DL_CHUNK = 16384;
+constexpr int DL_PER_THREAD = 64;
+struct __attribute__((packed, aligned(1))) dl_u64 { uint64_t v; };
+
+// bit 8k+7 of the result is set iff byte k of w equals c (c replicated in `pat`)
+__device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t pat) {
+  const uint64_t x = w ^ pat;
+  const uint64_t t = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+  return ~(t | x | 0x7F7F7F7F7F7F7F7Full);
+}
+__device__ __forceinline__ void dl_thread_masks(const uint8_t* __restrict__ u, uint64_t a, uint64_t hi, uint64_t mn[8], uint64_t mt[8],
+                                                uint32_t* n_nl, uint32_t* n_tab) {
+  uint32_t cn = 0, ct = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint64_t p = a + 8 * k;
+    uint64_t w = 0;
+    if (p + 8 <= hi) w = ((const dl_u64*)(u + p))->v;
+    else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
+    uint64_t a_n = 0, a_t = 0;
+    if (p < hi) {
+      a_n = eq_mask8(w, 0x0A0A0A0A0A0A0A0Aull);
+      a_t = eq_mask8(w, 0x0909090909090909ull);
+      if (p + 8 > hi) {  // bytes past hi read as 0: never '\n' or '\t'
+      }
+    }
+    mn[k] = a_n;
+    mt[k] = a_t;
+    cn += (uint32_t)__popcll(a_n);
+    ct += (uint32_t)__popcll(a_t);
+  }
+  *n_nl = cn;
+  *n_tab = ct;
+}
+
+__global__ __launch_bounds__(256) void k_delim_count(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi,
+                                                      uint32_t* __restrict__ cnt_nl, uint32_t* __restrict__ cnt_tab) {
+  __shared__ uint32_t s_n[4], s_t[4];
+  const uint64_t a = lo + (uint64_t)blockIdx.x * DL_CHUNK + (uint64_t)threadIdx.x * DL_PER_THREAD;
+  uint64_t mn[8], mt[8];
+  uint32_t n = 0, t = 0;
+  if (a < hi) dl_thread_masks(u, a, hi, mn, mt, &n, &t);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    n += __shfl_down(n, d, 64);
+    t += __shfl_down(t, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { s_n[threadIdx.x >> 6] = n; s_t[threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cnt_nl[blockIdx.x] = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+    cnt_tab[blockIdx.x] = s_t[0] + s_t[1] + s_t[2] + s_t[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_delim_write(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi,
+                                                      const uint64_t* __restrict__ base_nl, const uint64_t* __restrict__ base_tab,
+                                                      uint64_t* __restrict__ nl, uint64_t* __restrict__ nl_tabs,
+                                                      uint64_t* __restrict__ tab) {
+  __shared__ uint32_t s_n[4], s_t[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint64_t a = lo + (uint64_t)blockIdx.x * DL_CHUNK + (uint64_t)threadIdx.x * DL_PER_THREAD;
+  uint64_t mn[8], mt[8];
+  uint32_t n = 0, t = 0;
+  if (a < hi) dl_thread_masks(u, a, hi, mn, mt, &n, &t);
+  uint32_t in_n = n, in_t = t;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t on = __shfl_up(in_n, d, 64), ot = __shfl_up(in_t, d, 64);
+    if (lane >= d) { in_n += on; in_t += ot; }
+  }
+  if (lane == 63) { s_n[wv] = in_n; s_t[wv] = in_t; }
+  __syncthreads();
+  uint32_t wb_n = 0, wb_t = 0;
+  for (int i = 0; i < wv; i++) { wb_n += s_n[i]; wb_t += s_t[i]; }
+  uint64_t on = base_nl[blockIdx.x] + wb_n + (in_n - n);
+  uint64_t ot = base_tab[blockIdx.x] + wb_t + (in_t - t);
+  if (n | t) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint64_t mk = mn[k];
+      while (mk) {
+        const int bit = __builtin_ctzll(mk);
+        nl[on] = a + 8 * k + (uint64_t)(bit >> 3);
+        nl_tabs[on] = ot + (uint64_t)__popcll(mt[k] & ((1ull << bit) - 1ull));
+        on++;
+        mk &= mk - 1;
+      }
+      uint64_t tk = mt[k];
+      while (tk) {
+        const int bit = __builtin_ctzll(tk);
+        tab[ot++] = a + 8 * k + (uint64_t)(bit >> 3);
+        tk &= tk - 1;
+      }
+    }
+  }
+}
+
+uint64_t vcf_delim_chunks(uint64_t lo, uint64_t hi) { return hi > lo ? (hi - lo + DL_CHUNK - 1) / DL_CHUNK : 0; }
+void launch_vcf_delim_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt_nl, uint32_t* cnt_tab, hipStream_t st) {
+  const uint64_t n = vcf_delim_chunks(lo, hi);
+  if (!n) return;
+  hipLaunchKernelGGL(k_delim_count, dim3((uint32_t)n), dim3(256), 0, st, u, lo, hi, cnt_nl, cnt_tab);
+}
+void launch_vcf_delim_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base_nl, const uint64_t* base_tab,
+                            uint64_t* nl, uint64_t* nl_tabs, uint64_t* tab, hipStream_t st) {
+  const uint64_t n = vcf_delim_chunks(lo, hi);
+  if (!n) return;
+  hipLaunchKernelGGL(k_delim_write, dim3((uint32_t)n), dim3(256), 0, st, u, lo, hi, base_nl, base_tab, nl, nl_tabs, tab);
+}
+
+// ---- line table -----------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t line_start(const VcfLines& L, uint64_t i) { return i == 0 ? L.x0 : L.nl[i - 1] + 1; }
+__device__ __forceinline__ uint64_t line_end_raw(const VcfLines& L, uint64_t i) { return i < L.n_nl ? L.nl[i] : L.hi; }
+__device__ __forceinline__ uint64_t line_tb(const VcfLines& L, uint64_t i) { return i == 0 ? 0 : L.nl_tabs[i - 1]; }
+__device__ __forceinline__ uint64_t line_te(const VcfLines& L, uint64_t i) { return i < L.n_nl ? L.nl_tabs[i] : L.n_tab; }
+// span of field f of line i; false when the line has fewer fields
+__device__ __forceinline__ bool field_span(const VcfLines& L, const uint8_t* u, uint64_t i, uint32_t f, uint64_t* a, uint64_t* b) {
+  const uint64_t tb = line_tb(L, i), te = line_te(L, i);
+  const uint64_t nt = te - tb;
+  if (f > nt) return false;
+  *a = f == 0 ? line_start(L, i) : L.tab[tb + f - 1] + 1;
+  if (f < nt) *b = L.tab[tb + f];
+  else {
+    uint64_t e = line_end_raw(L, i);
+    if (e > *a && u[e - 1] == '\r') e--;
+    *b = e;
+  }
+  return true;
+}
+
+// ---- number parsing ---------------------------------------------------------------------------------------
+// i32 from [+-]?[0-9]+ ; 0 ok, 1 malformed / out of range
+__device__ int parse_i32_text(const uint8_t* p, uint32_t len, int32_t* out) {
+  uint32_t i = 0;
+  bool neg = false;
+  if (i < len && (p[i] == '+' || p[i] == '-')) { neg = p[i] == '-'; i++; }
+  if (i >= len) return 1;
+  int64_t v = 0;
+  for (; i < len; i++) {
+    const uint32_t d = (uint32_t)p[i] - '0';
+    if (d > 9) return 1;
+    v = v * 10 + d;
+    if (v > 2147483648ll) return 1;
+  }
+  if (neg) v = -v;
+  if (v > 2147483647ll) return 1;
+  *out = (int32_t)v;
+  return 0;
+}
+__device__ int parse_u32_pos(const uint8_t* p, uint32_t len, uint32_t* out) {
+  if (len == 0) return 1;
+  uint64_t v = 0;
+  for (uint32_t i = 0; i < len; i++) {
+    const uint32_t d = (uint32_t)p[i] - '0';
+    if (d > 9) return 1;
+    v = v * 10 + d;
+    if (v > 0xFFFFFFFFull) return 1;
+  }
+  *out = (uint32_t)v;
+  return 0;
+}
+
+__device__ const double P10D[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+__device__ const uint64_t P10U[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull,
+                                      100000000ull, 1000000000ull, 10000000000ull, 100000000000ull, 1000000000000ull,
+                                      10000000000000ull, 100000000000000ull, 1000000000000000ull, 10000000000000000ull,
+                                      100000000000000000ull, 1000000000000000000ull, 10000000000000000000ull};
+__device__ __forceinline__ bool ci_eq(const uint8_t* p, uint32_t len, const char* s) {
+  uint32_t i = 0;
+  for (; s[i]; i++) {
+    if (i >= len) return false;
+    uint8_t c = p[i];
+    if (c >= 'A' && c <= 'Z') c += 32;
+    if (c != (uint8_t)s[i]) return false;
+  }
+  return i == len;
+}
+// Correctly rounded decimal -> f32 (what Rust's `str::parse::<f32>` returns).  0 ok; 1 malformed;
+// 2 needs arbitrary precision (reported as an error, never guessed).
+__device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
+  uint32_t i = 0;
+  bool neg = false;
+  if (i < len && (p[i] == '+' || p[i] == '-')) { neg = p[i] == '-'; i++; }
+  if (ci_eq(p + i, len - i, "inf") || ci_eq(p + i, len - i, "infinity")) { *out = neg ? -__builtin_huge_valf() : __builtin_huge_valf(); return 0; }
+  if (ci_eq(p + i, len - i, "nan")) { *out = __builtin_nanf(""); return 0; }
+  uint64_t m = 0;
+  int nd = 0;
+  int64_t e10 = 0;
+  bool any = false, dot = false, sticky = false;
+  for (; i < len; i++) {
+    const uint8_t c = p[i];
+    const uint32_t d = (uint32_t)c - '0';
+    if (d <= 9) {
+      any = true;
+      if (nd < 19) {
+        m = m * 10 + d;
+        if (m) nd++;
+        if (dot) e10--;
+      } else {
+        if (d) sticky = true;
+        if (!dot) e10++;
+      }
+    } else if (c == '.') {
+      if (dot) return 1;
+      dot = true;
+    } else break;
+  }
+  if (!any) return 1;
+  if (i < len && (p[i] == 'e' || p[i] == 'E')) {
+    i++;
+    bool eneg = false;
+    if (i < len && (p[i] == '+' || p[i] == '-')) { eneg = p[i] == '-'; i++; }
+    if (i >= len) return 1;
+    int64_t ex = 0;
+    for (; i < len; i++) {
+      const uint32_t d = (uint32_t)p[i] - '0';
+      if (d > 9) return 1;
+      if (ex < 100000) ex = ex * 10 + d;
+    }
+    e10 += eneg ? -ex : ex;
+  }
+  if (i != len) return 1;
+  float r;
+  if (m == 0) r = 0.0f;
+  else if (e10 + nd > 40) r = __builtin_huge_valf();
+  else if (e10 + nd < -50) r = 0.0f;
+  else if (!sticky && e10 >= 0 && e10 <= 19 && m <= 0xFFFFFFFFFFFFFFFFull / P10U[e10]) {
+    // exact integer: one rounding, by the u64 -> f32 conversion
+    r = (float)(m * P10U[e10]);
+  } else if (e10 < 0 && e10 >= -19) {
+    // exact quotient m / 10^k: 33 quotient bits by restoring division on normalised operands, sticky remainder
+    const int lz = __builtin_clzll(m);
+    const uint64_t mn = m << lz;
+    const uint64_t d = P10U[-e10];
+    const int dz = __builtin_clzll(d);
+    const uint64_t dn = d << dz;
+    uint64_t q = mn >= dn ? 1 : 0;
+    uint64_t rem = mn >= dn ? mn - dn : mn;
+    for (int k = 0; k < 32; k++) {
+      const bool top = rem >> 63;
+      rem <<= 1;
+      q <<= 1;
+      if (top || rem >= dn) { rem -= dn; q |= 1; }
+    }
+    if (sticky && (q & 0x7F) == 0x7F) return 2;  // dropped digits could carry into the rounding position
+    if (rem || sticky) q |= 1ull;
+    r = ldexpf((float)q, dz - lz - 32);
+    if (r != 0.0f && fabsf(r) < 1.1754944e-38f) return 2;  // subnormal result: not handled
+  } else {
+    double d = (double)m;
+    int64_t e = e10;
+    double kerr = sticky || m >= (1ull << 53) ? 2.0 : 0.5;
+    while (e > 22) { d *= 1e22; e -= 22; kerr += 1.0; }
+    while (e < -22) { d /= 1e22; e += 22; kerr += 1.0; }
+    if (e >= 0) d *= P10D[e]; else d /= P10D[-e];
+    kerr += 0.5;
+    const double eps = (kerr + 0.5) * 2.220446049250313e-16;
+    const float flo = (float)(d * (1.0 - eps)), fhi = (float)(d * (1.0 + eps));
+    if (flo != fhi) return 2;
+    if (fhi != 0.0f && fabsf(fhi) < 1.1754944e-38f) return 2;  // subnormal result: not handled
+    r = fhi;
+  }
+  *out = neg ? -r : r;
+  return 0;
+}
+
+__device__ __forceinline__ void set_err(uint32_t* err, uint32_t code) { atomicCAS(err, 0u, code); }
+
+// ---- line keys ----------------------------------------------------------------------------------------------
+// pos = POS; vend = noodles variant_end (INFO END, else POS + len(REF) - 1); flags bit0 = single-base ACGT SNV
+// (get_variant_end's fast path, physical_exec.rs:646-667), bit1 = blank line.
+__global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u, VcfLines L, uint32_t* __restrict__ pos,
+                                                   uint32_t* __restrict__ vend, uint8_t* __restrict__ flags, int need_end,
+                                                   uint32_t* __restrict__ err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= L.n_lines) return;
+  uint64_t a, b;
+  const uint64_t s = line_start(L, i);
+  uint64_t e = line_end_raw(L, i);
+  if (e > s && u[e - 1] == '\r') e--;
+  if (e == s) { flags[i] = 2; pos[i] = 0; vend[i] = 0; set_err(err, VERR_BLANK_LINE); return; }
+  if (line_te(L, i) - line_tb(L, i) < 7) { set_err(err, VERR_SHORT_RECORD); flags[i] = 2; return; }
+  field_span(L, u, i, 1, &a, &b);
+  uint32_t p = 0;
+  if (parse_u32_pos(u + a, (uint32_t)(b - a), &p)) { set_err(err, VERR_BAD_POS); p = 0; }
+  if (p == 0) set_err(err, VERR_MISSING_START);
+  pos[i] = p;
+  uint64_t ra, rb, aa, ab;
+  field_span(L, u, i, 3, &ra, &rb);
+  field_span(L, u, i, 4, &aa, &ab);
+  const uint32_t rl = (uint32_t)(rb - ra);
+  uint8_t fl = 0;
+  if (rl == 1 && ab - aa == 1) {
+    const uint8_t r = u[ra], al = u[aa];
+    const bool rok = r == 'A' || r == 'C' || r == 'G' || r == 'T';
+    const bool aok = al == 'A' || al == 'C' || al == 'G' || al == 'T';
+    if (rok && aok) fl = 1;
+  }
+  flags[i] = fl;
+  uint32_t ve = p + rl - 1;
+  if (need_end) {
+    uint64_t ia, ib;
+    field_span(L, u, i, 7, &ia, &ib);
+    uint64_t q = ia;
+    while (q + 4 <= ib) {
+      if (u[q] == 'E' && u[q + 1] == 'N' && u[q + 2] == 'D' && u[q + 3] == '=') {
+        uint64_t v0 = q + 4, v1 = v0;
+        while (v1 < ib && u[v1] != ';') v1++;
+        int32_t ev;
+        if (!(v1 - v0 == 1 && u[v0] == '.')) {
+          if (parse_i32_text(u + v0, (uint32_t)(v1 - v0), &ev) || ev <= 0) set_err(err, VERR_BAD_END);
+          else ve = (uint32_t)ev;
+        }
+        break;
+      }
+      while (q < ib && u[q] != ';') q++;
+      q++;
+    }
+  }
+  vend[i] = ve;
+}
+void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, uint32_t* err,
+                     hipStream_t st) {
+  if (!L.n_lines) return;
+  hipLaunchKernelGGL(k_vcf_keys, dim3((uint32_t)((L.n_lines + 255) / 256)), dim3(256), 0, st, u, L, pos, vend, flags, need_end, err);
+}
+
+// ---- row selection ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bytes_eq(const uint8_t* a, uint32_t la, const uint8_t* b, uint32_t lb) {
+  if (la != lb) return false;
+  for (uint32_t k = 0; k < la; k++) if (a[k] != b[k]) return false;
+  return true;
+}
+__device__ bool eval_terms(const VcfFilterTerm* __restrict__ terms, int n_terms, const uint8_t* __restrict__ strs,
+                           const uint8_t* chrom, uint32_t lchrom, const uint8_t* id, uint32_t lid, double start, double end) {
+  for (int t = 0; t < n_terms; t++) {
+    const VcfFilterTerm& T = terms[t];
+    const bool is_str = T.field == 0 || T.field == 3;
+    const uint8_t* sv = T.field == 0 ? chrom : id;
+    const uint32_t sl = T.field == 0 ? lchrom : lid;
+    const double nv = T.field == 1 ? start : end;
+    bool ok = true;
+    if (T.op <= BIOSCAN_OP_GE) {
+      if (is_str) {
+        const bool eq = bytes_eq(sv, sl, strs + T.str_off[0], T.str_len[0]);
+        ok = T.op == BIOSCAN_OP_EQ ? eq : (T.op == BIOSCAN_OP_NE ? !eq : true);
+      } else {
+        const double lv = T.vals[0];
+        switch (T.op) {
+          case BIOSCAN_OP_EQ: ok = nv == lv; break;
+          case BIOSCAN_OP_NE: ok = nv != lv; break;
+          case BIOSCAN_OP_LT: ok = nv < lv; break;
+          case BIOSCAN_OP_LE: ok = nv <= lv; break;
+          case BIOSCAN_OP_GT: ok = nv > lv; break;
+          default: ok = nv >= lv; break;
+        }
+      }
+    } else if (T.op == BIOSCAN_OP_BETWEEN || T.op == BIOSCAN_OP_NOT_BETWEEN) {
+      const bool bt = nv >= T.vals[0] && nv <= T.vals[1];
+      ok = T.op == BIOSCAN_OP_BETWEEN ? bt : !bt;
+    } else {
+      const bool neg = T.op == BIOSCAN_OP_NOT_IN;
+      bool hit = false;
+      for (int k = 0; k < T.n_vals && !hit; k++)
+        hit = is_str ? bytes_eq(sv, sl, strs + T.str_off[k], T.str_len[k]) : nv == T.vals[k];
+      ok = hit ? !neg : (!T.has_null && neg);
+    }
+    if (!ok) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_vcf_row_flags(const uint8_t* __restrict__ u, VcfLines L, const uint32_t* __restrict__ pos,
+                                                        const uint32_t* __restrict__ vend, const uint8_t* __restrict__ flags,
+                                                        VcfRowSelect S, const uint64_t* __restrict__ chunks,
+                                                        const VcfFilterTerm* __restrict__ terms, const uint8_t* __restrict__ strs,
+                                                        uint32_t* __restrict__ keep) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i = S.i_lo + k;
+  if (i >= S.i_hi) return;
+  uint32_t kp = 0;
+  do {
+    if (flags[i] & 2) break;
+    const uint64_t s = line_start(L, i);
+    if (S.mode == 1) {
+      bool in = false;
+      for (int c = 0; c < S.n_chunks && !in; c++) in = s >= chunks[2 * c] && s < chunks[2 * c + 1];
+      if (!in) break;
+    }
+    uint64_t ca, cb;
+    field_span(L, u, i, 0, &ca, &cb);
+    const uint32_t p = pos[i];
+    if (S.mode == 1) {
+      if (!bytes_eq(u + ca, (uint32_t)(cb - ca), strs + S.chrom_off, S.chrom_len)) break;
+      if (!((int64_t)p <= S.q_end1 && (int64_t)vend[i] >= S.q_start1)) break;   // noodles intersects()
+      if (S.start1 > 0 && (int64_t)p < S.start1) break;                           // physical_exec.rs:2886-2895
+      if (S.end1 > 0 && (int64_t)p > S.end1) break;
+    }
+    if (S.n_terms) {
+      uint64_t ia, ib;
+      field_span(L, u, i, 2, &ia, &ib);
+      uint32_t lid = (uint32_t)(ib - ia);
+      if (lid == 1 && u[ia] == '.') lid = 0;
+      const uint32_t endcol = (flags[i] & 1) ? p : vend[i];
+      const double st = (double)(S.zero_based ? p - 1 : p);
+      if (!eval_terms(terms, S.n_terms, strs, u + ca, (uint32_t)(cb - ca), u + ia, lid, st, (double)endcol)) break;
+    }
+    kp = 1;
+  } while (false);
+  keep[k] = kp;
+}
+void launch_vcf_row_flags(const uint8_t* u, VcfLines L, const uint32_t* pos, const uint32_t* vend, const uint8_t* flags,
+                          VcfRowSelect S, const uint64_t* chunks, const VcfFilterTerm* terms, const uint8_t* strs, uint32_t* keep,
+                          hipStream_t st) {
+  if (S.i_hi <= S.i_lo) return;
+  const uint64_t n = S.i_hi - S.i_lo;
+  hipLaunchKernelGGL(k_vcf_row_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, pos, vend, flags, S, chunks, terms,
+                     strs, keep);
+}
+__global__ __launch_bounds__(256) void k_vcf_compact(const uint32_t* __restrict__ keep, const uint64_t* __restrict__ scan, uint64_t n,
+                                                      uint64_t i_lo, uint64_t* __restrict__ rows, uint64_t row_base, uint64_t cap) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n || !keep[k]) return;
+  const uint64_t o = scan[k];
+  if (o < cap) rows[row_base + o] = i_lo + k;
+}
+void launch_vcf_compact(const uint32_t* keep, const uint64_t* scan, uint64_t n, uint64_t i_lo, uint64_t* rows, uint64_t row_base,
+                        uint64_t cap, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_vcf_compact, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, keep, scan, n, i_lo, rows, row_base, cap);
+}
+// first line whose start is >= off (lines are sorted): used to bound a region's line range
+__global__ void k_vcf_line_lower_bound(VcfLines L, uint64_t off, unsigned long long* result) {
+  uint64_t lo = 0, hi = L.n_lines;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (line_start(L, mid) < off) lo = mid + 1; else hi = mid;
+  }
+  result[0] = lo;
+}
+void launch_vcf_line_lower_bound(VcfLines L, uint64_t off, unsigned long long* result, hipStream_t st) {
+  hipLaunchKernelGGL(k_vcf_line_lower_bound, dim3(1), dim3(1), 0, st, L, off, result);
+}
+__global__ __launch_bounds__(256) void k_iota_rows(uint64_t* rows, uint64_t n) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) rows[k] = k;
+}
+void launch_vcf_iota_rows(uint64_t* rows, uint64_t n, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_iota_rows, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, rows, n);
+}
+
+// ---- core columns -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_vcf_core(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+                                                   uint64_t n, const uint32_t* __restrict__ pos, const uint32_t* __restrict__ vend,
+                                                   const uint8_t* __restrict__ flags, VcfCoreCols C, int zero_based,
+                                                   uint32_t* __restrict__ err) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool act = r < n;
+  const uint64_t i = act ? rows[r] : 0;
+  uint64_t a = 0, b = 0;
+  if (act) {
+    if (C.src_chrom) { field_span(L, u, i, 0, &a, &b); C.src_chrom[r] = a; C.len_chrom[r] = (uint32_t)(b - a); }
+    const uint32_t p = pos[i];
+    if (C.start) C.start[r] = zero_based ? p - 1 : p;
+    if (C.end) C.end[r] = (flags[i] & 1) ? p : vend[i];
+    if (C.src_id) {
+      field_span(L, u, i, 2, &a, &b);
+      uint32_t l = (uint32_t)(b - a);
+      if (l == 1 && u[a] == '.') l = 0;
+      C.src_id[r] = a; C.len_id[r] = l;
+    }
+    if (C.src_ref) { field_span(L, u, i, 3, &a, &b); C.src_ref[r] = a; C.len_ref[r] = (uint32_t)(b - a); }
+    if (C.src_alt) {
+      field_span(L, u, i, 4, &a, &b);
+      uint32_t l = (uint32_t)(b - a);
+      if (l == 1 && u[a] == '.') l = 0;
+      C.src_alt[r] = a; C.len_alt[r] = l;
+    }
+    if (C.src_filter) {
+      field_span(L, u, i, 6, &a, &b);
+      uint32_t l = (uint32_t)(b - a);
+      if (l == 1 && u[a] == '.') l = 0;
+      C.src_filter[r] = a; C.len_filter[r] = l;
+    }
+  }
+  if (C.qual) {
+    bool valid = false;
+    if (act) {
+      field_span(L, u, i, 5, &a, &b);
+      double q = 0.0;
+      if (!(b - a == 1 && u[a] == '.')) {
+        float f;
+        const int rc = parse_f32_text(u + a, (uint32_t)(b - a), &f);
+        if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_QUAL);
+        else { q = (double)f; valid = true; }
+      }
+      C.qual[r] = q;
+    }
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && (r & ~63ull) < n) C.v_qual[r >> 6] = m;
+  }
+}
+void launch_vcf_core(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint32_t* pos, const uint32_t* vend,
+                     const uint8_t* flags, VcfCoreCols C, int zero_based, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_vcf_core, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, pos, vend, flags, C, zero_based, err);
+}
+__global__ __launch_bounds__(256) void k_replace_byte(uint8_t* __restrict__ d, uint64_t n, uint8_t from, uint8_t to) {
+  const uint64_t k = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  for (uint64_t j = k; j < n && j < k + 16; j++) if (d[j] == from) d[j] = to;
+}
+void launch_replace_byte(uint8_t* d, uint64_t n, uint8_t from, uint8_t to, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_replace_byte, dim3((uint32_t)((n + 4095) / 4096)), dim3(256), 0, st, d, n, from, to);
+}
+
+// ---- INFO ---------------------------------------------------------------------------------------------------
+// One pass over the INFO field of each row: for every selected key k, sp_off/sp_len/sp_state[k*n + r]
+// (state 0 absent, 1 `key=value`, 2 bare key).  A selected key that occurs twice is an error (the reference
+// would append twice and misalign the column).
+__global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+                                                          uint64_t n, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                          int K, uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
+                                                          uint8_t* __restrict__ sp_state, uint32_t* __restrict__ err) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t i = rows[r];
+  for (int k = 0; k < K; k++) sp_state[(uint64_t)k * n + r] = 0;
+  uint64_t a, b;
+  field_span(L, u, i, 7, &a, &b);
+  if (b - a == 1 && u[a] == '.') return;
+  uint64_t q = a;
+  while (q < b) {
+    uint64_t ke = q;
+    while (ke < b && u[ke] != '=' && u[ke] != ';') ke++;
+    uint64_t ve = ke;
+    const bool has_val = ke < b && u[ke] == '=';
+    if (has_val) { ve = ke + 1; while (ve < b && u[ve] != ';') ve++; }
+    const uint32_t kl = (uint32_t)(ke - q);
+    if (kl) {
+      for (int k = 0; k < K; k++) {
+        const uint32_t ko = key_off[k], kn = key_off[k + 1] - ko;
+        if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) {
+          const uint64_t o = (uint64_t)k * n + r;
+          if (sp_state[o]) set_err(err, VERR_DUP_INFO_KEY);
+          sp_state[o] = has_val ? 1 : 2;
+          sp_off[o] = has_val ? ke + 1 : ke;
+          sp_len[o] = has_val ? (uint32_t)(ve - ke - 1) : 0;
+          break;
+        }
+      }
+    }
+    q = ve + 1;
+  }
+}
+void launch_vcf_info_locate(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
+                            int K, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state, uint32_t* err, hipStream_t st) {
+  if (!n || !K) return;
+  hipLaunchKernelGGL(k_vcf_info_locate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off, K, sp_off,
+                     sp_len, sp_state, err);
+}
+
+// ---- typed span kernels (shared by INFO and FORMAT cells) -----------------------------------------------------
+// kind: 0 Int32, 1 Float32.  A span holding "." is NULL; state 0 / 2 (absent / bare non-flag key) is NULL.
+__global__ __launch_bounds__(256) void k_span_num(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
+                                                   const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
+                                                   int kind, uint32_t* __restrict__ values, uint64_t* __restrict__ valid,
+                                                   uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool v = false;
+  if (c < N) {
+    uint32_t out = 0;
+    if (state[c] == 1) {
+      const uint8_t* p = u + off[c];
+      const uint32_t l = len[c];
+      if (!(l == 1 && p[0] == '.')) {
+        if (kind == 0) {
+          int32_t x;
+          if (parse_i32_text(p, l, &x)) set_err(err, VERR_BAD_INT); else { out = (uint32_t)x; v = true; }
+        } else {
+          float f;
+          const int rc = parse_f32_text(p, l, &f);
+          if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT); else { out = __float_as_uint(f); v = true; }
+        }
+      }
+    }
+    values[c] = out;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) valid[c >> 6] = m;
+}
+void launch_span_num(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, int kind,
+                     uint32_t* values, uint64_t* valid, uint32_t* err, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_span_num, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, kind, values, valid, err);
+}
+// Flag: present (bare) -> true; absent -> false; `key=.` -> false; any other value is an error
+__global__ __launch_bounds__(256) void k_span_flag(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
+                                                    const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
+                                                    uint64_t* __restrict__ bits, uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool v = false;
+  if (c < N) {
+    if (state[c] == 2) v = true;
+    else if (state[c] == 1 && !(len[c] == 1 && u[off[c]] == '.')) set_err(err, VERR_INVALID_FLAG);
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) bits[c >> 6] = m;
+}
+void launch_span_flag(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint64_t* bits,
+                      uint32_t* err, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_span_flag, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, bits, err);
+}
+// Utf8: out_len = span length (0 when NULL), validity; '%' (percent-encoding) is rejected, not decoded
+__global__ __launch_bounds__(256) void k_span_str(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
+                                                   const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
+                                                   uint32_t* __restrict__ out_len, uint64_t* __restrict__ valid, uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool v = false;
+  if (c < N) {
+    uint32_t l = 0;
+    if (state[c] == 1) {
+      const uint8_t* p = u + off[c];
+      l = len[c];
+      if (l == 1 && p[0] == '.') l = 0;
+      else {
+        v = true;
+        for (uint32_t k = 0; k < l; k++) if (p[k] == '%') { set_err(err, VERR_PERCENT); break; }
+      }
+    }
+    out_len[c] = l;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) valid[c >> 6] = m;
+}
+void launch_span_str(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* out_len,
+                     uint64_t* valid, uint32_t* err, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_span_str, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, out_len, valid, err);
+}
+// list element count: "." / absent -> NULL list (0 elements); else commas + 1
+__global__ __launch_bounds__(256) void k_span_list_count(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
+                                                          uint32_t* __restrict__ cnt, uint64_t* __restrict__ valid) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool v = false;
+  if (c < N) {
+    uint32_t k = 0;
+    if (state[c] == 1) {
+      const uint8_t* p = u + off[c];
+      const uint32_t l = len[c];
+      if (!(l == 1 && p[0] == '.')) {
+        v = true;
+        k = 1;
+        for (uint32_t j = 0; j < l; j++) k += p[j] == ',';
+      }
+    }
+    cnt[c] = k;
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) valid[c >> 6] = m;
+}
+void launch_span_list_count(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* cnt,
+                            uint64_t* valid, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_span_list_count, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, cnt, valid);
+}
+// list elements: kind 0 Int32, 1 Float32 -> values + per-element validity bytes; kind 2 Utf8 -> element
+// source offsets / lengths + validity bytes.  eoff = exclusive scan of the counts.
+__global__ __launch_bounds__(256) void k_span_list_elems(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
+                                                          const uint64_t* __restrict__ eoff, int kind, uint32_t* __restrict__ values,
+                                                          uint64_t* __restrict__ esrc, uint32_t* __restrict__ elen,
+                                                          uint8_t* __restrict__ evalid, uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  uint64_t o = eoff[c];
+  const uint64_t oe = eoff[c + 1];
+  if (o == oe) return;
+  const uint64_t base = off[c];
+  const uint8_t* p = u + base;
+  const uint32_t l = len[c];
+  uint32_t a = 0;
+  for (uint32_t j = 0; j <= l; j++) {
+    if (j == l || p[j] == ',') {
+      const uint32_t el = j - a;
+      const bool miss = el == 1 && p[a] == '.';
+      if (kind == 2) {
+        esrc[o] = base + a;
+        elen[o] = miss ? 0 : el;
+        if (!miss) for (uint32_t k = a; k < j; k++) if (p[k] == '%') { set_err(err, VERR_PERCENT); break; }
+      } else {
+        uint32_t out = 0;
+        if (!miss) {
+          if (kind == 0) {
+            int32_t x;
+            if (parse_i32_text(p + a, el, &x)) set_err(err, VERR_BAD_INT); else out = (uint32_t)x;
+          } else {
+            float f;
+            const int rc = parse_f32_text(p + a, el, &f);
+            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT); else out = __float_as_uint(f);
+          }
+        }
+        values[o] = out;
+      }
+      evalid[o] = miss ? 0 : 1;
+      o++;
+      a = j + 1;
+    }
+  }
+}
+void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N,
+                            const uint64_t* eoff, int kind, uint32_t* values, uint64_t* esrc, uint32_t* elen, uint8_t* evalid,
+                            uint32_t* err, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_span_list_elems, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, eoff, kind, values,
+                     esrc, elen, evalid, err);
+}
+__global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ bytes, uint64_t n, uint64_t* __restrict__ words) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool v = c < n && bytes[c];
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < n) words[c >> 6] = m;
+}
+void launch_pack_bits(const uint8_t* bytes, uint64_t n, uint64_t* words, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_pack_bits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, bytes, n, words);
+}
+__global__ __launch_bounds__(256) void k_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k <= n) off[k] = k * stride;
+}
+void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st) {
+  hipLaunchKernelGGL(k_stride_offsets, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, st, off, n, stride);
+}
+
+// ---- FORMAT -------------------------------------------------------------------------------------------------
+// fpos[r*S + s] = index of selected FORMAT key s among the ':'-separated keys of row r's FORMAT column (-1 absent)
+__global__ __launch_bounds__(256) void k_vcf_format_keys(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+                                                          uint64_t n, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
+                                                          int S, int16_t* __restrict__ fpos) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  for (int s = 0; s < S; s++) fpos[r * S + s] = -1;
+  uint64_t a, b;
+  if (!field_span(L, u, rows[r], 8, &a, &b)) return;
+  if (b == a || (b - a == 1 && u[a] == '.')) return;
+  int j = 0;
+  uint64_t q = a;
+  while (q <= b) {
+    uint64_t e = q;
+    while (e < b && u[e] != ':') e++;
+    const uint32_t kl = (uint32_t)(e - q);
+    for (int s = 0; s < S; s++) {
+      const uint32_t ko = key_off[s], kn = key_off[s + 1] - ko;
+      if (kn == kl && fpos[r * S + s] < 0 && bytes_eq(u + q, kl, keys + ko, kn)) fpos[r * S + s] = (int16_t)j;
+    }
+    j++;
+    q = e + 1;
+  }
+}
+void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
+                            int S, int16_t* fpos, hipStream_t st) {
+  if (!n || !S) return;
+  hipLaunchKernelGGL(k_vcf_format_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off, S, fpos);
+}
+// One thread per (row, selected sample) cell c = r*NS + os: the ':'-separated value of each selected FORMAT
+// key -> sp_*[s*N + c] (N = n*NS).  gt_field = index of GT among the selected keys (-1 none): its span drops
+// a leading phasing character and is validated (alleles are digits or '.', separators '/' or '|').
+__global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+                                                           uint64_t n, const int32_t* __restrict__ sample_col, int NS,
+                                                           const int16_t* __restrict__ fpos, int S, int gt_field,
+                                                           uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
+                                                           uint8_t* __restrict__ sp_state, uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t N = n * (uint64_t)NS;
+  if (c >= N) return;
+  const uint64_t r = c / NS;
+  const int os = (int)(c - r * NS);
+  for (int s = 0; s < S; s++) sp_state[(uint64_t)s * N + c] = 0;
+  uint64_t a, b;
+  if (!field_span(L, u, rows[r], 9 + (uint32_t)sample_col[os], &a, &b)) return;
+  if (b == a || (b - a == 1 && u[a] == '.')) return;
+  int j = 0;
+  uint64_t q = a;
+  while (q <= b) {
+    uint64_t e = q;
+    while (e < b && u[e] != ':') e++;
+    for (int s = 0; s < S; s++) {
+      if (fpos[r * S + s] == j) {
+        const uint64_t o = (uint64_t)s * N + c;
+        uint64_t x = q;
+        if (s == gt_field && !(e - q == 1 && u[q] == '.')) {
+          if (x < e && (u[x] == '/' || u[x] == '|')) x++;
+          bool ok = x < e, isdot = false, lead0 = false;
+          uint32_t tl = 0;
+          for (uint64_t k = x; k <= e && ok; k++) {
+            const uint8_t ch = k < e ? u[k] : '/';
+            if (ch == '/' || ch == '|') {
+              if (tl == 0 || (!isdot && lead0 && tl > 1)) ok = false;
+              tl = 0; isdot = false; lead0 = false;
+            } else if (ch == '.') {
+              if (tl) ok = false;
+              isdot = true; tl = 1;
+            } else if (ch >= '0' && ch <= '9') {
+              if (isdot) ok = false;
+              if (tl == 0) lead0 = ch == '0';
+              tl++;
+            } else ok = false;
+          }
+          if (!ok) set_err(err, VERR_BAD_GT);
+        }
+        sp_state[o] = 1;
+        sp_off[o] = x;
+        sp_len[o] = (uint32_t)(e - x);
+      }
+    }
+    j++;
+    q = e + 1;
+  }
+}
+void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
+                             const int16_t* fpos, int S, int gt_field, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state,
+                             uint32_t* err, hipStream_t st) {
+  const uint64_t N = n * (uint64_t)NS;
+  if (!N || !S) return;
+  hipLaunchKernelGGL(k_vcf_format_cells, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, L, rows, n, sample_col, NS, fpos, S,
+                     gt_field, sp_off, sp_len, sp_state, err);
+}
+
+// ---- list UDFs (udfs.rs) ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bit_at(const uint64_t* w, uint64_t i) { return w == nullptr || ((w[i >> 6] >> (i & 63)) & 1ull); }
+// list_avg: one wave per row.  Int32: exact integer sum (every partial f64 sum of the reference is an exact
+// integer below 2^53, so the order of additions cannot change the result).  Float32: lane 0 adds in order.
+__global__ __launch_bounds__(256) void k_list_avg(const uint64_t* __restrict__ off, const uint32_t* __restrict__ values,
+                                                   const uint64_t* __restrict__ evalid, const uint64_t* __restrict__ lvalid, uint64_t n,
+                                                   int is_float, double* __restrict__ out, uint8_t* __restrict__ out_valid) {
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const uint64_t a = off[r], b = off[r + 1];
+  double sum = 0.0;
+  unsigned long long cnt = 0;
+  if (!bit_at(lvalid, r)) {
+    if (lane == 0) { out[r] = 0.0; out_valid[r] = 0; }
+    return;
+  }
+  if (!is_float) {
+    long long s = 0;
+    for (uint64_t k = a + lane; k < b; k += WAVE)
+      if (bit_at(evalid, k)) { s += (int32_t)values[k]; cnt++; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { s += __shfl_down(s, d, 64); cnt += __shfl_down(cnt, d, 64); }
+    sum = (double)s;
+  } else if (lane == 0) {
+    for (uint64_t k = a; k < b; k++)
+      if (bit_at(evalid, k)) { sum += (double)__uint_as_float(values[k]); cnt++; }
+  }
+  if (lane == 0) {
+    out[r] = cnt ? sum / (double)cnt : 0.0;
+    out_valid[r] = cnt ? 1 : 0;
+  }
+}
+void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t* evalid, const uint64_t* lvalid, uint64_t n,
+                     int is_float, double* out, uint8_t* out_valid, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_list_avg, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, off, values, evalid, lvalid, n, is_float, out,
+                     out_valid);
+}
+// list_gte / list_lte: element-wise compare -> Boolean value bits (element validity and list offsets are the input's)
+__global__ __launch_bounds__(256) void k_list_cmp(const uint32_t* __restrict__ values, uint64_t n_elems, int is_float, int op,
+                                                   uint32_t thr_bits, uint64_t* __restrict__ out_bits) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool v = false;
+  if (c < n_elems) {
+    if (is_float) {
+      const float x = __uint_as_float(values[c]), t = __uint_as_float(thr_bits);
+      v = op == 0 ? x >= t : x <= t;
+    } else {
+      const int32_t x = (int32_t)values[c], t = (int32_t)thr_bits;
+      v = op == 0 ? x >= t : x <= t;
+    }
+  }
+  const unsigned long long m = __ballot(v);
+  if ((threadIdx.x & 63) == 0 && (c & ~63ull) < n_elems) out_bits[c >> 6] = m;
+}
+void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st) {
+  if (!n_elems) return;
+  hipLaunchKernelGGL(k_list_cmp, dim3((uint32_t)((n_elems + 255) / 256)), dim3(256), 0, st, values, n_elems, is_float, op, thr_bits, out_bits);
+}
+
+}  // namespace bioscan

@@ -43,6 +43,22 @@ class _Filter(C.Structure):
     _fields_ = [("column", C.c_char_p), ("op", C.c_int32), ("values", C.POINTER(_Literal)), ("n_values", C.c_int32)]
 
 
+class _VcfOptions(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("coordinate_system_zero_based", C.c_int32),
+                ("has_info_fields", C.c_int32), ("info_fields", C.POINTER(C.c_char_p)), ("n_info_fields", C.c_int32),
+                ("has_format_fields", C.c_int32), ("format_fields", C.POINTER(C.c_char_p)), ("n_format_fields", C.c_int32),
+                ("has_samples", C.c_int32), ("samples", C.POINTER(C.c_char_p)), ("n_samples", C.c_int32),
+                ("index_path", C.c_char_p)]
+
+
+class UdfStats(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_elements", C.c_uint64), ("count_a", C.c_uint64), ("count_b", C.c_uint64),
+                ("sum", C.c_double), ("ms_kernel", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class ScanStats(C.Structure):
     _fields_ = [("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64),
                 ("arrow_bytes", C.c_uint64), ("n_records", C.c_uint64), ("n_rows", C.c_uint64),
@@ -62,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
+    "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf",
 ]
 
 
@@ -95,6 +112,10 @@ def load_library():
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
     lib.bioscan_free.argtypes = [C.c_void_p]
     lib.bioscan_device_check.argtypes = [C.c_int32, C.c_char_p, C.c_int32]
+    lib.bioscan_vcf_open.argtypes = [C.c_char_p, C.POINTER(_VcfOptions), C.POINTER(C.c_void_p)]
+    lib.bioscan_udf_list_avg.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.bioscan_udf_list_cmp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.bioscan_stream_list_udf.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_double, C.POINTER(UdfStats)]
     _lib = lib
     return lib
 
@@ -369,3 +390,127 @@ class FastqTableProvider:
         _check(load_library().bioscan_scan(self._h, proj, nproj, None, 0, -1 if limit is None else limit, target_partitions,
                                            C.byref(plan)))
         return FastqExec(self, plan)
+
+
+class VcfExec(BamExec):
+    """Mirror of VcfExec (bio-format-vcf/src/physical_exec.rs:2539-2690)."""
+
+    def name(self) -> str:
+        return "VCFExec"
+
+    def execute_device_udf(self, partition: int, field: str, udf: str, threshold: float = 0.0, batch_size: int = 8192) -> dict:
+        """Runs the partition on the GPU and applies a list UDF (`list_avg`, `list_gte`, `list_lte`) to
+        `genotypes.<field>` without leaving HBM; returns scan stats + the UDF's checksums and kernel time."""
+        lib = load_library()
+        st = C.c_void_p()
+        stats = ScanStats()
+        _check(lib.bioscan_execute_device(self._h, partition, batch_size, C.byref(stats), C.byref(st)))
+        try:
+            us = UdfStats()
+            code = {"list_avg": 0, "list_gte": 1, "list_lte": 2}[udf]
+            _check(lib.bioscan_stream_list_udf(st, field.encode(), code, float(threshold), C.byref(us)))
+        finally:
+            lib.bioscan_stream_close(st)
+        return {"scan": stats.as_dict(), "udf": us.as_dict()}
+
+
+def _str_array(values):
+    if values is None:
+        return 0, None, 0, None
+    enc = [v.encode() for v in values]
+    arr = (C.c_char_p * max(len(enc), 1))(*enc)
+    return 1, arr, len(enc), enc
+
+
+class VcfTableProvider:
+    """Mirror of VcfTableProvider::new / new_with_samples(file_path, info_fields, format_fields, samples_to_include,
+    object_storage_options, coordinate_system_zero_based) (bio-format-vcf/src/table_provider.rs:752-814); local
+    files only.  `None` selects every header INFO / FORMAT tag / sample, a list (possibly empty) is explicit."""
+
+    def __init__(self, file_path: str, info_fields=None, format_fields=None, object_storage_options=None,
+                 coordinate_system_zero_based: bool = True, samples_to_include=None, index_path: Optional[str] = None,
+                 device_id: int = 0):
+        lib = load_library()
+        o = _VcfOptions()
+        o.device_id = device_id
+        o.coordinate_system_zero_based = 1 if coordinate_system_zero_based else 0
+        o.has_info_fields, a1, o.n_info_fields, k1 = _str_array(info_fields)
+        o.has_format_fields, a2, o.n_format_fields, k2 = _str_array(format_fields)
+        o.has_samples, a3, o.n_samples, k3 = _str_array(samples_to_include)
+        if a1 is not None:
+            o.info_fields = a1
+        if a2 is not None:
+            o.format_fields = a2
+        if a3 is not None:
+            o.samples = a3
+        o.index_path = index_path.encode() if index_path is not None else None
+        self._h = C.c_void_p()
+        _check(lib.bioscan_vcf_open(file_path.encode(), C.byref(o), C.byref(self._h)))
+        self.file_path = file_path
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            load_library().bioscan_provider_close(h)
+            self._h = None
+
+    def schema(self) -> pa.Schema:
+        s = _ArrowSchema()
+        _check(load_library().bioscan_schema(self._h, C.addressof(s)))
+        return pa.Schema._import_from_c(C.addressof(s))
+
+    def supports_filters_pushdown(self, filters):
+        arr, keep = _make_filters(filters)
+        out = (C.c_int32 * max(len(filters), 1))()
+        _check(load_library().bioscan_supports_filters_pushdown(self._h, arr, len(filters), out))
+        return ["Inexact" if out[i] else "Unsupported" for i in range(len(filters))]
+
+    def make_resident(self):
+        _check(load_library().bioscan_provider_make_resident(self._h))
+
+    def scan(self, projection: Optional[Sequence[int]] = None, filters=(), limit: Optional[int] = None,
+             target_partitions: int = 1) -> VcfExec:
+        if projection is None:
+            proj, nproj = None, 0
+        else:
+            proj = (C.c_int32 * max(len(projection), 1))(*projection)
+            nproj = len(projection)
+        arr, keep = _make_filters(filters)
+        plan = C.c_void_p()
+        _check(load_library().bioscan_scan(self._h, proj, nproj, arr, len(filters), -1 if limit is None else limit,
+                                           target_partitions, C.byref(plan)))
+        return VcfExec(self, plan)
+
+
+def _export_array(arr: pa.Array):
+    a, s = _ArrowArray(), _ArrowSchema()
+    arr._export_to_c(C.addressof(a), C.addressof(s))
+    return a, s
+
+
+def list_avg(arr: pa.Array, device_id: int = 0) -> pa.Array:
+    """`list_avg` UDF (bio-format-vcf/src/udfs.rs:24-115) on the GPU: List<Int32|Float32> -> Float64."""
+    lib = load_library()
+    a, s = _export_array(arr)
+    oa, os_ = _ArrowArray(), _ArrowSchema()
+    _check(lib.bioscan_udf_list_avg(C.addressof(a), C.addressof(s), device_id, C.addressof(oa), C.addressof(os_)))
+    return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
+
+
+def _list_cmp(arr: pa.Array, threshold, op: int, device_id: int) -> pa.Array:
+    lib = load_library()
+    a, s = _export_array(arr)
+    oa, os_ = _ArrowArray(), _ArrowSchema()
+    _check(lib.bioscan_udf_list_cmp(C.addressof(a), C.addressof(s), op, float(threshold), device_id, C.addressof(oa),
+                                    C.addressof(os_)))
+    return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
+
+
+def list_gte(arr: pa.Array, threshold, device_id: int = 0) -> pa.Array:
+    """`list_gte` UDF (udfs.rs:561-656)."""
+    return _list_cmp(arr, threshold, 0, device_id)
+
+
+def list_lte(arr: pa.Array, threshold, device_id: int = 0) -> pa.Array:
+    """`list_lte` UDF (udfs.rs:663-760)."""
+    return _list_cmp(arr, threshold, 1, device_id)

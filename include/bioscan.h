@@ -60,6 +60,58 @@ int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_
  * -> block-range partitions, plain file -> byte ranges, BGZF without index -> one partition. */
 int bioscan_fastq_open(const char* path, int32_t device_id, bioscan_provider** out);
 
+/* ---- VcfTableProvider::new_with_samples (bio-format-vcf/src/table_provider.rs:796-814, 849-1097) --------
+ * Text VCF, BGZF-compressed (`.vcf.gz` / `.vcf.bgz`) or uncompressed.  Schema = 8 core columns + one column per
+ * INFO tag + FORMAT columns (single-sample source: top-level columns; multi-sample source: one
+ * `genotypes: Struct<tag: List<T>>` column), determine_schema_from_header (table_provider.rs:91-338).
+ * `has_*` = 0 means "None" in the reference (all header INFO / FORMAT tags, all samples); with has_* = 1 the
+ * array (possibly empty) is the explicit selection.  `index_path` NULL = auto-discover `<path>.tbi`
+ * (bio-format-core/src/index_utils.rs:85-100); "" = no index.  The handle is used with the same
+ * bioscan_scan / bioscan_execute / bioscan_next entry points (VcfTableProvider::scan table_provider.rs:1225-1462,
+ * VcfExec::execute physical_exec.rs:2612-2690).  `limit` stops each partition after `limit` rows
+ * (physical_exec.rs:1114-1116, 2997-2999); limit 0 gives an empty plan (table_provider.rs:1265-1269). */
+typedef struct bioscan_vcf_options {
+  int32_t device_id;
+  int32_t coordinate_system_zero_based; /* default 1 */
+  int32_t has_info_fields;
+  const char* const* info_fields;
+  int32_t n_info_fields;
+  int32_t has_format_fields;
+  const char* const* format_fields;
+  int32_t n_format_fields;
+  int32_t has_samples;
+  const char* const* samples;
+  int32_t n_samples;
+  const char* index_path;
+} bioscan_vcf_options;
+void bioscan_vcf_options_default(bioscan_vcf_options* o);
+int bioscan_vcf_open(const char* path, const bioscan_vcf_options* opts, bioscan_provider** out);
+
+/* ---- list UDFs (bio-format-vcf/src/udfs.rs) ----------------------------------------------------------------
+ * list_avg  :67-110  List<Int32|Float32> -> Float64 (mean of the non-null elements; NULL list / no element -> NULL)
+ * list_gte  :606-650 List<Int32|Float32>, threshold -> List<Boolean> (element NULLs kept, NULL list -> NULL list)
+ * list_lte  same loop with <=.
+ * Host form: Arrow C Data in (a List array + its schema), Arrow C Data out; the arithmetic runs on `device_id`.
+ * op: 0 = list_gte, 1 = list_lte.  The threshold is an Int32 for Int32 lists and is rounded to f32 for Float32 lists. */
+int bioscan_udf_list_avg(const struct ArrowArray* in, const struct ArrowSchema* in_schema, int32_t device_id,
+                         struct ArrowArray* out, struct ArrowSchema* out_schema);
+int bioscan_udf_list_cmp(const struct ArrowArray* in, const struct ArrowSchema* in_schema, int32_t op, double threshold,
+                         int32_t device_id, struct ArrowArray* out, struct ArrowSchema* out_schema);
+/* Device-resident form for a stream returned by bioscan_execute_device: applies the UDF to `genotypes.<field>` (or a
+ * top-level List column named `field`) of the whole partition without leaving HBM.  udf: 0 list_avg, 1 list_gte,
+ * 2 list_lte.  Reports the kernel time and two checksums the caller can compare with an oracle: for list_avg the
+ * number of non-NULL results and their f64 sum (added in row order on the host); for the comparisons the number of
+ * true and of NULL elements. */
+typedef struct bioscan_udf_stats {
+  uint64_t n_rows;
+  uint64_t n_elements;
+  uint64_t count_a;   /* list_avg: non-NULL results;  cmp: true elements  */
+  uint64_t count_b;   /* list_avg: NULL results;      cmp: NULL elements  */
+  double sum;         /* list_avg: sum of the results */
+  double ms_kernel;
+} bioscan_udf_stats;
+int bioscan_stream_list_udf(bioscan_stream* s, const char* field, int32_t udf, double threshold, bioscan_udf_stats* out);
+
 /* TableProvider::schema (table_provider.rs:933-935); caller releases the ArrowSchema. */
 int bioscan_schema(const bioscan_provider* p, struct ArrowSchema* out);
 

@@ -1,0 +1,296 @@
+"""GPU parity for the VCF path: HIP scan (through the C ABI) vs oracle/vcf_oracle.py -- schema (with metadata),
+partition plans, per-partition batches -- on the reference's fixtures, the inline inputs of the reference's own
+tests (with the values those tests assert), synthetic config-3 / config-4 style files, and the list UDFs."""
+import json
+import os
+import random
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vcf_cases as C  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def vo():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vcf_oracle
+    return vcf_oracle
+
+
+def bgzf_compress(data: bytes, block: int = 65280) -> bytes:
+    out = []
+    for a in range(0, len(data), block):
+        raw = data[a:a + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(raw) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(c) + 25) + c
+                   + struct.pack("<II", zlib.crc32(raw) & 0xFFFFFFFF, len(raw)))
+    out.append(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+    return b"".join(out)
+
+
+class GpuTable:
+    def __init__(self, pkg, path, info_fields=None, format_fields=None, samples=None, zero_based=True, index_path=None):
+        self.p = pkg.VcfTableProvider(path, info_fields, format_fields, None, zero_based, samples, index_path)
+        self.schema = self.p.schema()
+
+    def column_names(self):
+        return self.schema.names
+
+    def read(self, names=None, filters=(), target_partitions=1, limit=None, batch_size=8192):
+        proj = None if names is None else [self.schema.get_field_index(n) for n in names]
+        plan = self.p.scan(projection=proj, filters=list(filters), limit=limit, target_partitions=target_partitions)
+        cols = {n: [] for n in (names if names is not None else self.schema.names)}
+        self.rows = 0
+        for p in range(plan.num_partitions()):
+            for b in plan.execute(p, batch_size):
+                self.rows += b.num_rows
+                for n in cols:
+                    cols[n].extend(b.column(b.schema.get_field_index(n)).to_pylist())
+        return cols
+
+
+def _schema_equal(a: pa.Schema, b: pa.Schema):
+    assert a.names == b.names
+    for fa, fb in zip(a, b):
+        assert fa.equals(fb, check_metadata=True), (fa, fa.metadata, fb, fb.metadata)
+    ma = {k: v for k, v in (a.metadata or {}).items()}
+    mb = {k: v for k, v in (b.metadata or {}).items()}
+    assert ma.keys() == mb.keys(), (ma.keys(), mb.keys())
+    for k in ma:
+        va, vb = ma[k], mb[k]
+        try:
+            assert json.loads(va) == json.loads(vb), k
+        except ValueError:
+            assert va == vb, k
+
+
+def _cmp_partition(got, want, ctx, exact_batches=True):
+    if exact_batches:
+        assert [b.num_rows for b in got] == [b.num_rows for b in want], (ctx, [b.num_rows for b in got][:5], [b.num_rows for b in want][:5])
+    tg = pa.Table.from_batches(got) if got else None
+    tw = pa.Table.from_batches(want) if want else None
+    if tw is None or tg is None:
+        assert (tg.num_rows if tg is not None else 0) == (tw.num_rows if tw is not None else 0), ctx
+        return
+    assert tg.num_rows == tw.num_rows, (ctx, tg.num_rows, tw.num_rows)
+    for n in tw.schema.names:
+        a, b = tg.column(n).combine_chunks(), tw.column(n).combine_chunks()
+        if not a.equals(b):
+            la, lb = a.to_pylist(), b.to_pylist()
+            for i, (x, y) in enumerate(zip(la, lb)):
+                assert x == y or (x != x and y != y), (ctx, n, i, x, y)
+            assert a.type == b.type, (ctx, n, a.type, b.type)
+
+
+def _parity(pkg, vo, path, kw, names=None, filters=(), target=1, limit=None, bs=8192, exact_batches=True):
+    okw = dict(kw)
+    o = vo.VcfOracle(path, **okw)
+    g = pkg.VcfTableProvider(path, kw.get("info_fields"), kw.get("format_fields"), None, kw.get("zero_based", True), kw.get("samples"))
+    _schema_equal(g.schema(), o.schema)
+    proj = None if names is None else [o.schema.get_field_index(n) for n in names]
+    oplan = o.scan(projection=proj, filters=list(filters), limit=limit, target_partitions=target)
+    gplan = g.scan(projection=proj, filters=list(filters), limit=limit, target_partitions=target)
+    assert gplan.num_partitions() == o.num_partitions(oplan), (gplan.num_partitions(), o.num_partitions(oplan))
+    total = 0
+    for p in range(gplan.num_partitions()):
+        if oplan["kind"] == "indexed":
+            a = oplan["assignments"][p]
+            desc = f"{a.total_estimated_bytes}|" + ";".join(
+                f"{r.chrom}:{r.start if r.start is not None else ''}-{r.end if r.end is not None else ''}" for r in a.regions)
+            assert gplan.partition_desc(p) == desc, (gplan.partition_desc(p), desc)
+        got = list(gplan.execute(p, bs))
+        osch, want = o.execute(oplan, p, bs)
+        if got:
+            _schema_equal(got[0].schema, osch)
+        _cmp_partition(got, want, (path, names, filters, target, p), exact_batches)
+        total += sum(b.num_rows for b in got)
+    return total
+
+
+def test_reference_kats(pkg, tmp_path):
+    for mode in ("plain", "bgzf"):
+        k = [0]
+
+        def make(text, **kw):
+            k[0] += 1
+            if mode == "plain":
+                p = tmp_path / f"case{k[0]}.vcf"
+                p.write_text(text)
+            else:
+                p = tmp_path / f"case{k[0]}.vcf.gz"
+                p.write_bytes(bgzf_compress(text.encode(), 97))   # tiny blocks: lines span BGZF members
+            return GpuTable(pkg, str(p), **kw)
+        C.check_reference_kats(make)
+
+
+@pytest.mark.parametrize("name,per", [("multi_chrom.vcf.gz", 500), ("multi_chrom_large.vcf.gz", 5000)])
+def test_fixture_indexed_parity(pkg, vo, name, per):
+    path = os.path.join(G, name)
+    for tp in (1, 2, 3, 4, 8):
+        assert _parity(pkg, vo, path, {}, target=tp) == 2 * per                                  # indexed_read_test.rs:136-152
+        assert _parity(pkg, vo, path, {}, names=["chrom"], filters=[("chrom", "=", "21")], target=tp) == per   # :99-112
+        assert _parity(pkg, vo, path, {}, names=["chrom", "start"], filters=[("chrom", "in", ["21", "22"])], target=tp) == 2 * per
+    n = _parity(pkg, vo, path, {}, names=["chrom"], target=4,
+                filters=[("chrom", "=", "21"), ("start", ">=", 5009999), ("start", "<=", 5029999)])           # :197-216
+    assert 0 < n < per
+    _parity(pkg, vo, path, {}, names=[], target=3, filters=[("chrom", "=", "22")])
+    _parity(pkg, vo, path, {}, names=["qual", "filter", "AF", "DB", "DP", "end", "id", "alt", "ref"], target=2, bs=100)
+    _parity(pkg, vo, path, {}, names=["chrom", "qual"], filters=[("qual", ">=", 50.0)], target=2)            # :156-170 (qual passes through)
+    _parity(pkg, vo, path, {}, filters=[("chrom", "=", "21"), ("end", "<=", 5010000), ("id", "!=", "rs3")], target=2)
+    _parity(pkg, vo, path, {}, filters=[("chrom", "=", "nope")], target=2)
+    assert _parity(pkg, vo, path, {}, names=["chrom"], filters=[("chrom", "=", "21")], limit=5) == 5          # limit tests :233-262
+    assert _parity(pkg, vo, path, {}, names=["chrom", "start"], filters=[("chrom", "=", "22")], limit=1) == 1
+    assert _parity(pkg, vo, path, {}, names=["chrom"], filters=[("chrom", "=", "21")], limit=9999) == per
+    assert _parity(pkg, vo, path, {"zero_based": False, "info_fields": []}, names=[], target=4,
+                   filters=[("chrom", "=", "21"), ("start", "=", 5000100)]) == 1                              # :222-232
+    g = pkg.VcfTableProvider(path)
+    assert g.scan(filters=[("chrom", "=", "21"), ("start", "=", 5000100), ("start", ">", 5000100)]).num_partitions() == 0
+    assert g.scan(limit=0).num_partitions() == 0
+    assert g.supports_filters_pushdown([("chrom", "=", "21"), ("qual", ">=", 5.0), ("DB", "=", 1), ("AF", "=", 1.0)]) == \
+        ["Inexact", "Inexact", "Unsupported", "Unsupported"]
+    assert g.scan(projection=[0, 1]).display() == "VcfExec: projection=[chrom, start]"
+
+
+def test_fixture_sequential_parity(pkg, vo, tmp_path):
+    # no index -> one sequential partition (table_provider.rs:1410-1462)
+    src = os.path.join(G, "multi_chrom.vcf.gz")
+    dst = tmp_path / "noindex.vcf.gz"
+    dst.write_bytes(open(src, "rb").read())
+    assert _parity(pkg, vo, str(dst), {}, target=4) == 1000
+    assert _parity(pkg, vo, str(dst), {}, names=["chrom", "start"], limit=3, target=4) == 3
+    plain = tmp_path / "plain.vcf"
+    plain.write_bytes(vo.bgzf_decompress(open(src, "rb").read()))
+    assert _parity(pkg, vo, str(plain), {}, target=2, bs=77) == 1000
+
+
+def test_real_multisample_fixture(pkg, vo):
+    # format_columns_test.rs:378-398: 2504 samples, AD (Number=.) and PL (Number=G) -> List<List<Int32>>
+    path = os.path.join(G, "head_106667_tail_6.vcf")
+    kw = {"info_fields": [], "format_fields": ["GT", "AD", "DP", "GQ", "PL"]}
+    assert _parity(pkg, vo, path, kw, names=["chrom", "start", "genotypes"], exact_batches=False) == 6
+    kw = {"format_fields": ["GT", "DP"], "samples": ["HG00100", "HG00096", "nobody"]}
+    assert _parity(pkg, vo, path, kw, exact_batches=False) == 6
+
+
+def _synth(tmp_path, *args):
+    exe = os.path.join(ROOT, "tools", "_build", "synth_vcf")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")], stdout=subprocess.DEVNULL)
+    out = subprocess.check_output([exe] + [str(a) for a in args])
+    return json.loads(out)
+
+
+def test_synth_sites_parity(pkg, vo, tmp_path):
+    path = str(tmp_path / "sites.vcf.gz")
+    meta = _synth(tmp_path, "sites", path, 20000, 11)
+    for tp in (1, 4, 16):
+        assert _parity(pkg, vo, path, {}, target=tp, bs=1000) == 20000
+    n = _parity(pkg, vo, path, {}, filters=[("chrom", "=", "chr1")], target=8)                   # config 3 predicate
+    assert n == meta["n_lines_chr1"]
+    _parity(pkg, vo, path, {"zero_based": False}, names=["chrom", "start", "end", "AF", "RSRC", "DB", "VQSLOD"],
+            filters=[("chrom", "in", ["chr2", "chr21"]), ("start", ">", 1000000)], target=5)
+    _parity(pkg, vo, path, {"info_fields": ["AF", "VT"]}, filters=[("chrom", "=", "chr7"), ("start", "between", (20000000, 90000000))], target=3)
+
+
+def test_synth_samples_parity(pkg, vo, tmp_path):
+    path = str(tmp_path / "samples.vcf.gz")
+    _synth(tmp_path, "samples", path, 400, 70, 5)
+    assert _parity(pkg, vo, path, {}, target=1, exact_batches=True) == 400
+    assert _parity(pkg, vo, path, {}, target=6) == 400
+    _parity(pkg, vo, path, {"format_fields": ["GQ", "GT"], "samples": ["S00070", "S00001", "S00033"]}, names=["start", "genotypes"],
+            filters=[("chrom", "=", "chr2")], target=2)
+    _parity(pkg, vo, path, {}, names=["chrom", "AF"], target=2)   # FORMAT not projected: plain batch size
+
+
+def test_list_udfs_host(pkg, vo):
+    rnd = random.Random(3)
+    L = pa.list_(pa.field("item", pa.int32(), True))
+    rows = []
+    for _ in range(3000):
+        r = rnd.random()
+        if r < 0.05:
+            rows.append(None)
+        else:
+            rows.append([None if rnd.random() < 0.1 else rnd.randint(-50, 300) for _ in range(rnd.randint(0, 40))])
+    a = pa.array(rows, type=L)
+    assert pkg.list_avg(a).equals(vo.list_avg(a))
+    assert pkg.list_gte(a, 20).equals(vo.list_gte(a, 20))
+    assert pkg.list_lte(a, 100).equals(vo.list_lte(a, 100))
+    assert pkg.list_avg(a.slice(17, 1000)).equals(vo.list_avg(a.slice(17, 1000)))
+    F = pa.list_(pa.field("item", pa.float32(), True))
+    fr = [None if rnd.random() < 0.05 else [None if rnd.random() < 0.1 else rnd.uniform(-1e3, 1e3) * 10 ** rnd.randint(-6, 6)
+                                             for _ in range(rnd.randint(0, 30))] for _ in range(2000)]
+    f = pa.array(fr, type=F)
+    assert pkg.list_avg(f).equals(vo.list_avg(f))
+    assert pkg.list_gte(f, 0.5).equals(vo.list_gte(f, 0.5))
+    # udfs.rs:1063-1110 vectors
+    gq = pa.array([[30, 20, 10], [5, None, 15]], type=L)
+    assert pkg.list_avg(gq).to_pylist() == [20.0, 10.0]
+    assert pkg.list_gte(gq, 15).to_pylist() == [[True, True, False], [False, None, True]]
+
+
+def test_list_udfs_device_resident(pkg, vo, tmp_path):
+    path = str(tmp_path / "samples.vcf.gz")
+    _synth(tmp_path, "samples", path, 300, 120, 9)
+    o = vo.VcfOracle(path)
+    g = pkg.VcfTableProvider(path)
+    gi = o.schema.get_field_index("genotypes")
+    oplan = o.scan(projection=[gi])
+    gplan = g.scan(projection=[gi])
+    _, want = o.execute(oplan, 0)
+    t = pa.Table.from_batches(want)
+    geno = t.column("genotypes").combine_chunks()
+    gq, dp = geno.field("GQ"), geno.field("DP")
+    avg = vo.list_avg(gq)
+    r = gplan.execute_device_udf(0, "GQ", "list_avg")["udf"]
+    assert r["n_rows"] == 300 and r["count_a"] == len(avg) - avg.null_count
+    assert r["sum"] == sum(v for v in avg.to_pylist() if v is not None)
+    ge = vo.list_gte(dp, 100)
+    r = gplan.execute_device_udf(0, "DP", "list_gte", 100)["udf"]
+    flat = [x for row in ge.to_pylist() for x in row]
+    assert r["count_a"] == sum(1 for x in flat if x) and r["count_b"] == sum(1 for x in flat if x is None)
+    r = gplan.execute_device_udf(0, "DP", "list_lte", 30)["udf"]
+    flat = [x for row in vo.list_lte(dp, 30).to_pylist() for x in row]
+    assert r["count_a"] == sum(1 for x in flat if x)
+
+
+def test_float_parse_fuzz(pkg, tmp_path):
+    """decimal -> f32 on the device must equal the correctly rounded value (Rust `str::parse::<f32>`)."""
+    rnd = random.Random(12)
+    vals = ["0", "0.0", "1", "-1", "0.1", "0.3", "1e-5", "1E5", "3.4028235e38", "1.17549435e-38", "16777217", "0.998595",
+            "1e39", "1e-60", "123456789012345678901234567890", "0.000000000000000000001", "+5.5", "5.", ".5", "nan", "inf", "-Infinity"]
+    for _ in range(6000):
+        kind = rnd.random()
+        if kind < 0.4:
+            vals.append(f"{rnd.uniform(0, 1):.{rnd.randint(1, 9)}g}")
+        elif kind < 0.7:
+            vals.append(f"{rnd.uniform(-1e4, 1e4) * 10 ** rnd.randint(-12, 12):.{rnd.randint(1, 17)}e}")
+        elif kind < 0.85:
+            vals.append(repr(float(np.float32(rnd.uniform(-10, 10)))))
+        else:
+            vals.append(repr(rnd.uniform(-1, 1) * 10 ** rnd.randint(-30, 30)))
+    lines = ["##fileformat=VCFv4.3", "##INFO=<ID=X,Number=1,Type=Float,Description=\"x\">",
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for i, v in enumerate(vals):
+        lines.append(f"c\t{i + 1}\t.\tA\tT\t{v}\t.\tX={v}")
+    p = tmp_path / "floats.vcf"
+    p.write_text("\n".join(lines) + "\n")
+    t = GpuTable(pkg, str(p))
+    r = t.read(["qual", "X"])
+    want = [float(np.float32(v)) for v in vals]
+    for v, q, x, w in zip(vals, r["qual"], r["X"], want):
+        if w != w:
+            assert q != q and x != x, v
+        else:
+            assert q == w and x == w, (v, q, x, w)
