@@ -93,6 +93,102 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
         dist.destroy_process_group()
 
 
+def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
+    """BASELINE.json configs 3 and 4.
+    vcf-sites:   sites-only VCF.bgz + TBI, predicate chrom='chr1' -> TBI region pruning, then scan of every column.
+    vcf-samples: N-sample VCF.bgz, full scan of every column incl. `genotypes: Struct<GT,GQ,DP: List<..>>`, then the
+                 list UDFs of benchmarks/vcf/vcf_multisample_bench.rs:46-59 restricted to list_avg / list_gte / list_lte."""
+    synth = os.path.join(ROOT, "tools", "_build", "synth_vcf")
+    if not os.path.exists(synth):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.vcf.gz")
+    ncpu = os.cpu_count() or 1
+    thr = str(max(1, min(16, ncpu // max(1, world))))
+    sites = args.format == "vcf-sites"
+    n_lines = args.lines if args.lines else (60_000_000 if sites else 200_000)
+    t0 = time.time()
+    cmd = [synth, "sites", path, str(n_lines), str(42 + rank), thr] if sites else \
+          [synth, "samples", path, str(n_lines), str(args.samples), str(42 + rank), thr]
+    meta = json.loads(subprocess.check_output(cmd).decode())
+    t_gen = time.time() - t0
+    prov = pkg.VcfTableProvider(path, device_id=local_rank)
+    prov.make_resident()
+    filters = [("chrom", "=", "chr1")] if sites else []
+    plan = prov.scan(filters=filters, target_partitions=1)
+    assert plan.num_partitions() == 1
+    for p in (path, path + ".tbi"):
+        if not args.keep_file:
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
+    udfs = [("GQ", "list_avg", 0.0), ("DP", "list_avg", 0.0), ("GQ", "list_gte", 10), ("DP", "list_gte", 10), ("DP", "list_lte", 200)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        if sites:
+            return plan.execute_device(0, args.batch_size), []
+        ds = plan.execute_device_stream(0, args.batch_size)
+        us = [ds.list_udf(f, u, t) for f, u, t in udfs]
+        st = ds.stats
+        ds.close()
+        return st, us
+    st, us = None, []
+    for _ in range(args.warmup):
+        st, us = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, us = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    rows, ubytes = float(st["n_rows"]), float(st["inflated_bytes"])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rows, ubytes], dtype=torch.float64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rows, ubytes = [float(x) for x in c.tolist()]
+    if rank == 0:
+        per_step = elapsed / args.steps
+        # algorithmic bytes of the text stage (SURVEY 8d): decoded text read once by the delimiter index + once by the
+        # extract kernels, Arrow buffers written once
+        text_bytes = float(st["inflated_bytes"])
+        alg = float(st["compressed_bytes"]) + 3 * text_bytes + float(st["arrow_bytes"])
+        gpu_ms = st["ms_total_gpu"] + sum(u["ms_kernel"] for u in us)
+        achieved = alg / (gpu_ms * 1e-3) / 1e9 if gpu_ms else 0.0
+        out = {
+            "metric": "vcf_bgz_tbi_region_scan_rows_per_sec" if sites else "vcf_multisample_genotypes_scan_rows_per_sec",
+            "value": round(rows / per_step / 1e6, 4), "unit": "Mrows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": ("VCF.bgz + TBI region-predicate scan (chrom='chr1'), sites-only, gnomAD-like INFO" if sites else
+                                    f"{args.samples}-sample VCF.bgz genotypes Struct<List> scan + list_avg/list_gte/list_lte"),
+                       "n_lines_per_gpu": meta["n_lines"], "n_lines_chr1": meta["n_lines_chr1"], "n_samples": meta["n_samples"],
+                       "n_blocks_file": meta["n_blocks"], "n_blocks_decoded": st["n_blocks"],
+                       "compressed_bytes_per_gpu": meta["compressed_bytes"], "inflated_bytes_file": meta["inflated_bytes"],
+                       "batch_size": args.batch_size},
+            "decoded_GB_s": round(ubytes / per_step / 1e9, 3),
+            "cells_per_sec_G": None if sites else round(rows * meta["n_samples"] * 3 / per_step / 1e9, 3),
+            "stage_ms": {"inflate": round(st["ms_inflate"], 3), "crc32": round(st["ms_crc"], 3),
+                         "delimiter_index+keys": round(st["ms_chain"], 3), "select": round(st["ms_select"], 3),
+                         "extract": round(st["ms_extract"], 3), "udfs": [round(u["ms_kernel"], 3) for u in us]},
+            "arrow_bytes": st["arrow_bytes"], "scan_wall_ms": round(st["ms_wall"], 3), "gpu_ms": round(gpu_ms, 3),
+            "roofline": {"bound": "hbm", "kernel": "VCF pipeline (inflate + text kernels)", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+            "cpu_baseline": None,
+            "setup_s": {"generate": round(t_gen, 1)}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +200,9 @@ def main():
     ap.add_argument("--cpu-sample-blocks", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep-file", action="store_true")
-    ap.add_argument("--format", default="bam", choices=["bam", "fastq"],
+    ap.add_argument("--lines", type=int, default=0, help="vcf-*: number of VCF lines (default 60 M sites / 200 k multi-sample)")
+    ap.add_argument("--samples", type=int, default=1000, help="vcf-samples: number of samples")
+    ap.add_argument("--format", default="bam", choices=["bam", "fastq", "vcf-sites", "vcf-samples"],
                     help="bam (default, BASELINE.json config 2) or fastq (BGZF-FASTQ + GZI full scan: the only scan the "
                          "reference publishes numbers for, openspec/.../design.md:29-36)")
     ap.add_argument("--mode", default="sequential", choices=["sequential", "indexed"],
@@ -128,6 +226,8 @@ def main():
     pkg.load_library()
     if args.format == "fastq":
         return bench_fastq(args, pkg, rank, local_rank, world, torch, dist)
+    if args.format.startswith("vcf"):
+        return bench_vcf(args, pkg, rank, local_rank, world, torch, dist)
 
     # ---- synthetic input (deterministic in (blocks, seed)) ----
     synth = os.path.join(ROOT, "tools", "_build", "synth_bam")

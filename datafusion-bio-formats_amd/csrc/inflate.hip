@@ -426,7 +426,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_inflate(const uint8_t* __restrict
 
 // ---- K2: CRC32 (IEEE 802.3, reflected) of each inflated member vs its BGZF trailer ----------------
 // noodles-bgzf verifies every block's CRC32 after inflating it; this is the same check.
-// One lane per member (64 members per wave): slice-by-4 tables live in LDS (4 KiB per
+// One lane per member (64 members per wave): slice-by-16 tables live in LDS (16 KiB per
 // workgroup, built by the workgroup itself), each lane streams its member with aligned dword
 // loads.  No cross-lane combine is needed, so the kernel is a plain table-driven CRC whose
 // throughput comes from having ~650 k members in flight.
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
                                                        const uint64_t* __restrict__ blk_uoff,
                                                        const uint8_t* __restrict__ out_all, uint32_t n_blocks,
                                                        uint32_t* status) {
-  __shared__ uint32_t T[4][256];
+  __shared__ uint32_t T[16][256];
   {
     uint32_t c = threadIdx.x;
 #pragma unroll
@@ -446,9 +446,8 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
   __syncthreads();
   {
     uint32_t c = T[0][threadIdx.x];
-    c = (c >> 8) ^ T[0][c & 0xFF]; T[1][threadIdx.x] = c;
-    c = (c >> 8) ^ T[0][c & 0xFF]; T[2][threadIdx.x] = c;
-    c = (c >> 8) ^ T[0][c & 0xFF]; T[3][threadIdx.x] = c;
+#pragma unroll
+    for (int k = 1; k < 16; k++) { c = (c >> 8) ^ T[0][c & 0xFF]; T[k][threadIdx.x] = c; }
   }
   __syncthreads();
   const uint32_t b = blockIdx.x * CRC_T + threadIdx.x;
@@ -458,15 +457,20 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
   const uint8_t* tr = comp + blk_coff[b + 1] - 8;
   const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
   uint32_t c = 0xFFFFFFFFu;
-  while (n && ((uintptr_t)p & 3)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF]; n--; }
-  const uint32_t* w = (const uint32_t*)p;
-  uint32_t nw = n >> 2;
-  for (uint32_t k = 0; k < nw; k++) {
-    c ^= w[k];
-    c = T[3][c & 0xFF] ^ T[2][(c >> 8) & 0xFF] ^ T[1][(c >> 16) & 0xFF] ^ T[0][c >> 24];
+  while (n && ((uintptr_t)p & 15)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF]; n--; }
+  // slice-by-16: one 16-byte load per step, 16 table lookups of which only 4 depend on the running CRC
+  const uint4* w = (const uint4*)p;
+  const uint32_t nq = n >> 4;
+  for (uint32_t k = 0; k < nq; k++) {
+    const uint4 v = w[k];
+    const uint32_t a0 = c ^ v.x, a1 = v.y, a2 = v.z, a3 = v.w;
+    c = T[15][a0 & 0xFF] ^ T[14][(a0 >> 8) & 0xFF] ^ T[13][(a0 >> 16) & 0xFF] ^ T[12][a0 >> 24] ^
+        T[11][a1 & 0xFF] ^ T[10][(a1 >> 8) & 0xFF] ^ T[9][(a1 >> 16) & 0xFF] ^ T[8][a1 >> 24] ^
+        T[7][a2 & 0xFF] ^ T[6][(a2 >> 8) & 0xFF] ^ T[5][(a2 >> 16) & 0xFF] ^ T[4][a2 >> 24] ^
+        T[3][a3 & 0xFF] ^ T[2][(a3 >> 8) & 0xFF] ^ T[1][(a3 >> 16) & 0xFF] ^ T[0][a3 >> 24];
   }
-  p += (size_t)nw * 4;
-  n &= 3;
+  p += (size_t)nq * 16;
+  n &= 15;
   while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
   c ^= 0xFFFFFFFFu;
   if (c != want && status[b] == INF_OK) status[b] = INF_CRC_MISMATCH;

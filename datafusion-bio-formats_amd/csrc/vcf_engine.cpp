@@ -1020,17 +1020,14 @@ void VcfStream::list_udf(const char* field, int32_t udf, double threshold, biosc
     t.start();
     launch_list_cmp((const uint32_t*)ch.d_values.p, E, is_float, udf == 1 ? 0 : 1, thr_bits, bits.p, st);
     out->ms_kernel = t.stop();
-    std::vector<uint64_t> hb(ew), hvld(ew, ~0ull);
-    if (ew) {
-      HIP_CHECK(hipMemcpy(hb.data(), bits.p, ew * 8, hipMemcpyDeviceToHost));
-      if (!ch.all_valid) HIP_CHECK(hipMemcpy(hvld.data(), ch.d_valid.p, ew * 8, hipMemcpyDeviceToHost));
-    }
-    for (uint64_t w = 0; w < ew; w++) {
-      uint64_t mask = ~0ull;
-      if (w == ew - 1 && (E & 63)) mask = (1ull << (E & 63)) - 1;
-      out->count_a += (uint64_t)__builtin_popcountll(hb[w] & hvld[w] & mask);
-      out->count_b += (uint64_t)__builtin_popcountll(~hvld[w] & mask);
-    }
+    DevBuf<unsigned long long> cnt(2);
+    HIP_CHECK(hipMemsetAsync(cnt.p, 0, 16, st));
+    launch_count_bits(bits.p, ch.all_valid ? nullptr : ch.d_valid.p, E, cnt.p, st);
+    unsigned long long h2[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(h2, cnt.p, 16, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    out->count_a = h2[0];
+    out->count_b = h2[1];
   }
 }
 

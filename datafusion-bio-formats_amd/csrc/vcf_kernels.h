@@ -96,6 +96,7 @@ void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows,
 // list UDFs: off = u64 list offsets (n+1), values = 32-bit elements, evalid / lvalid = validity words or nullptr
 void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t* evalid, const uint64_t* lvalid, uint64_t n,
                      int is_float, double* out, uint8_t* out_valid, hipStream_t st);
+void launch_count_bits(const uint64_t* bits, const uint64_t* valid, uint64_t n_elems, unsigned long long* counts, hipStream_t st);
 void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st);
 
 }  // namespace bioscan

@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace bioscan {
 
 constexpr int WAVE = 64;
@@ -905,6 +907,28 @@ __global__ __launch_bounds__(256) void k_list_cmp(const uint32_t* __restrict__ v
   }
   const unsigned long long m = __ballot(v);
   if ((threadIdx.x & 63) == 0 && (c & ~63ull) < n_elems) out_bits[c >> 6] = m;
+}
+// counts[0] += popcount(bits & valid), counts[1] += popcount(~valid) over n_elems bits (valid == nullptr: all valid)
+__global__ __launch_bounds__(256) void k_count_bits(const uint64_t* __restrict__ bits, const uint64_t* __restrict__ valid, uint64_t n_elems,
+                                                     unsigned long long* __restrict__ counts) {
+  const uint64_t nw = (n_elems + 63) / 64;
+  unsigned long long a = 0, b = 0;
+  for (uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x; w < nw; w += (uint64_t)gridDim.x * 256) {
+    uint64_t mask = ~0ull;
+    if (w == nw - 1 && (n_elems & 63)) mask = (1ull << (n_elems & 63)) - 1;
+    const uint64_t v = valid ? valid[w] : ~0ull;
+    a += (unsigned long long)__popcll(bits[w] & v & mask);
+    b += (unsigned long long)__popcll(~v & mask);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { a += __shfl_down(a, d, 64); b += __shfl_down(b, d, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[0], a); atomicAdd(&counts[1], b); }
+}
+void launch_count_bits(const uint64_t* bits, const uint64_t* valid, uint64_t n_elems, unsigned long long* counts, hipStream_t st) {
+  if (!n_elems) return;
+  const uint64_t nw = (n_elems + 63) / 64;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((nw + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_count_bits, dim3(grid), dim3(256), 0, st, bits, valid, n_elems, counts);
 }
 void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st) {
   if (!n_elems) return;

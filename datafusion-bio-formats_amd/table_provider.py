@@ -398,6 +398,14 @@ class VcfExec(BamExec):
     def name(self) -> str:
         return "VCFExec"
 
+    def execute_device_stream(self, partition: int, batch_size: int = 8192) -> "VcfDeviceStream":
+        """Runs the partition on the GPU and keeps its Arrow buffers in HBM for device-resident list UDFs."""
+        lib = load_library()
+        st = C.c_void_p()
+        stats = ScanStats()
+        _check(lib.bioscan_execute_device(self._h, partition, batch_size, C.byref(stats), C.byref(st)))
+        return VcfDeviceStream(st, stats.as_dict())
+
     def execute_device_udf(self, partition: int, field: str, udf: str, threshold: float = 0.0, batch_size: int = 8192) -> dict:
         """Runs the partition on the GPU and applies a list UDF (`list_avg`, `list_gte`, `list_lte`) to
         `genotypes.<field>` without leaving HBM; returns scan stats + the UDF's checksums and kernel time."""
@@ -412,6 +420,28 @@ class VcfExec(BamExec):
         finally:
             lib.bioscan_stream_close(st)
         return {"scan": stats.as_dict(), "udf": us.as_dict()}
+
+
+class VcfDeviceStream:
+    """A partition result resident in HBM (bioscan_execute_device) + bioscan_stream_list_udf."""
+
+    def __init__(self, handle, stats):
+        self._h = handle
+        self.stats = stats
+
+    def list_udf(self, field: str, udf: str, threshold: float = 0.0) -> dict:
+        us = UdfStats()
+        code = {"list_avg": 0, "list_gte": 1, "list_lte": 2}[udf]
+        _check(load_library().bioscan_stream_list_udf(self._h, field.encode(), code, float(threshold), C.byref(us)))
+        return us.as_dict()
+
+    def close(self):
+        if self._h:
+            load_library().bioscan_stream_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
 
 
 def _str_array(values):
