@@ -698,9 +698,13 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
                            p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(), p.binary_cigar ? 1 : 0, ov, st);
     DevBuf<uint32_t> wide(1);
     HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    if (core_col[9] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(9), dat_of(9), 0, wide.p, st);
+    if (getenv("BIOSCAN_SEQQUAL_V1")) {
+      if (core_col[9] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(9), dat_of(9), 0, wide.p, st);
+      if (core_col[10] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(10), dat_of(10), 1, wide.p, st);
+    } else {
+      launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), wide.p, st);
+    }
     if (core_col[10] >= 0) {
-      launch_scatter_seqqual(p.d_u.p, rows, n, off_of(10), dat_of(10), 1, wide.p, st);
       if (read_err(wide, st)) {
         // exact path for qualities >= 95 (two-byte UTF-8 chars)
         Column& col = res->cols[core_col[10]];

@@ -707,6 +707,110 @@ void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, 
                      which, qual_wide);
 }
 
+// K7c: sequence + quality in ONE pass, one wave per row (8 rows per wave, grid-stride free): the packed
+// bases and the qualities of a record are adjacent (225 contiguous bytes for a 150 bp read), so the wave
+// reads them once with 2- and 4-byte lane accesses and writes both Arrow value buffers with 4-byte stores
+// to consecutive addresses.  Replaces two output-centric k_scatter_seqqual launches (which re-read most of
+// d_u twice and paid a binary search per 16 output bytes).
+constexpr int SQR_ROWS_PER_WAVE = 16;
+struct __attribute__((packed, aligned(1))) u16u { uint16_t v; };
+struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
+__device__ __forceinline__ uint32_t qual_swar(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x21212121u) ^ (w & 0x80808080u); }  // (q + 33) mod 256 per byte
+__global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
+                                                               uint64_t n, const uint64_t* __restrict__ off_seq,
+                                                               uint8_t* __restrict__ d_seq, const uint64_t* __restrict__ off_qual,
+                                                               uint8_t* __restrict__ d_qual, uint32_t* qual_wide) {
+  __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first), little-endian u16
+  {
+    const char* L = "=ACMGRSVTWYHKDBN";
+    s_pair[threadIdx.x] = (uint16_t)((uint8_t)L[threadIdx.x >> 4] | ((uint16_t)(uint8_t)L[threadIdx.x & 15] << 8));
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, sl = lane & 15;  // four 16-lane groups, each works on its own row: 4 rows in flight per wave
+  const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const uint64_t r_lo = wave * SQR_ROWS_PER_WAVE;
+  if (r_lo >= n) return;
+  // lanes 0..15 fetch the metadata of the wave's 16 rows in parallel (one dependent-load chain for all of
+  // them); the row loop broadcasts it with shuffles
+  uint64_t m_sp = 0, m_os = 0, m_oq = 0;
+  uint32_t m_lseq = 0;
+  if (lane < SQR_ROWS_PER_WAVE && r_lo + lane < n) {
+    const uint64_t ro = rows[r_lo + lane];
+    const uint8_t* rec = u + ro;
+    const uint32_t lrn = rec[12];
+    const uint32_t ncig = ld_u16(rec + 16);
+    m_lseq = (uint32_t)ld_i32(rec + 20);
+    m_sp = ro + 36 + lrn + 4ull * ncig;
+    if (d_seq) m_os = off_seq[r_lo + lane];
+    if (d_qual) m_oq = off_qual[r_lo + lane];
+  }
+  bool wide = false;
+  const int nrow = (int)((n - r_lo) < SQR_ROWS_PER_WAVE ? (n - r_lo) : SQR_ROWS_PER_WAVE);
+#pragma unroll
+  for (int it = 0; it < SQR_ROWS_PER_WAVE / 4; it++) {
+    const int k = it * 4 + g;
+    const uint32_t lseq = __shfl(m_lseq, k, 64);
+    const uint64_t spo = __shfl(m_sp, k, 64), oso = __shfl(m_os, k, 64), oqo = __shfl(m_oq, k, 64);
+    if (k >= nrow) continue;
+    const uint8_t* sp = u + spo;
+    const uint8_t* qp = sp + ((lseq + 1) >> 1);
+    if (d_seq) {
+      uint8_t* o = d_seq + oso;
+      for (uint32_t c = (uint32_t)sl * 16; c < lseq; c += 256) {
+        const uint32_t rem = lseq - c;
+        if (rem >= 16) {
+          const uint64_t pk = ((const u64u*)(sp + (c >> 1)))->v;  // 8 packed bytes -> 16 bases
+          u32x4u v;
+          v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
+          v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
+          v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
+          v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
+          *(u32x4u*)(o + c) = v;
+        } else {
+          for (uint32_t j = 0; j < rem; j += 2) {
+            const uint16_t pr = s_pair[sp[(c + j) >> 1]];
+            o[c + j] = (uint8_t)pr;
+            if (j + 1 < rem) o[c + j + 1] = (uint8_t)(pr >> 8);
+          }
+        }
+      }
+    }
+    if (d_qual) {
+      uint8_t* o = d_qual + oqo;
+      for (uint32_t c = (uint32_t)sl * 16; c < lseq; c += 256) {
+        const uint32_t rem = lseq - c;
+        if (rem >= 16) {
+          u32x4u v = *(const u32x4u*)(qp + c);
+          v.x = qual_swar(v.x); v.y = qual_swar(v.y); v.z = qual_swar(v.z); v.w = qual_swar(v.w);
+          wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
+          *(u32x4u*)(o + c) = v;
+        } else {
+          uint32_t j = 0;
+          for (; j + 4 <= rem; j += 4) {
+            const uint32_t res = qual_swar(((const u32u*)(qp + c + j))->v);
+            wide = wide || (res & 0x80808080u);
+            ((u32u*)(o + c + j))->v = res;
+          }
+          for (; j < rem; j++) {
+            const uint32_t q = ((uint32_t)qp[c + j] + 33u) & 0xFFu;
+            wide = wide || q >= 128u;
+            o[c + j] = (uint8_t)q;
+          }
+        }
+      }
+    }
+  }
+  if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
+}
+void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
+                                 const uint64_t* off_qual, uint8_t* d_qual, uint32_t* qual_wide, hipStream_t st) {
+  if (!n || (!d_seq && !d_qual)) return;
+  const uint64_t waves = (n + SQR_ROWS_PER_WAVE - 1) / SQR_ROWS_PER_WAVE;
+  hipLaunchKernelGGL(k_scatter_seqqual_rows, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, u, rows, n, off_seq, d_seq, off_qual,
+                     d_qual, qual_wide);
+}
+
 // exact wide-quality path: `char::from(q + 33)` pushed into a String -> chars >= U+0080 take two UTF-8 bytes
 __global__ void k_qual_wide_len(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
                                 uint32_t* __restrict__ len_qual) {
