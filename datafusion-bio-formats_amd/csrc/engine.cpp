@@ -693,16 +693,19 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
     for (int k : var_idx) if (core_col[k] >= 0) finish_var(res->cols[core_col[k]], 1);
     auto off_of = [&](int idx) -> const uint64_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_off64.p : nullptr; };
     auto dat_of = [&](int idx) -> uint8_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_values.p : nullptr; };
-    if (core_col[0] >= 0 || core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
-      launch_scatter_small(p.d_u.p, rows, 0, n, off_of(0), dat_of(0), off_of(1), dat_of(1), off_of(5), dat_of(5), off_of(7), dat_of(7),
-                           p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(), p.binary_cigar ? 1 : 0, ov, st);
+    const bool v1 = getenv("BIOSCAN_SEQQUAL_V1") != nullptr;
+    // name rides with sequence / quality in the row-centric kernel; chrom, cigar, mate_chrom stay one row per lane
+    if ((v1 && core_col[0] >= 0) || core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
+      launch_scatter_small(p.d_u.p, rows, 0, n, v1 ? off_of(0) : nullptr, v1 ? dat_of(0) : nullptr, off_of(1), dat_of(1), off_of(5),
+                           dat_of(5), off_of(7), dat_of(7), p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(),
+                           p.binary_cigar ? 1 : 0, ov, st);
     DevBuf<uint32_t> wide(1);
     HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    if (getenv("BIOSCAN_SEQQUAL_V1")) {
+    if (v1) {
       if (core_col[9] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(9), dat_of(9), 0, wide.p, st);
       if (core_col[10] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(10), dat_of(10), 1, wide.p, st);
     } else {
-      launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), wide.p, st);
+      launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
     }
     if (core_col[10] >= 0) {
       if (read_err(wide, st)) {

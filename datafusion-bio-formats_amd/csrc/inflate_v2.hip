@@ -288,9 +288,18 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     wp += 2;
     nxt = V2_SRC(wp);
   }
+  // One table lookup per iteration.  A lane is a small state machine: `tb/sh/mb` describe its next lookup
+  // (table base, bits to skip, index width) and `st` says whether it is decoding a literal/length symbol
+  // (0) or the distance of a pending match (1).  A sub-table pointer only re-targets the next lookup, a
+  // length symbol switches the lane to the distance table: lanes in different states share the same
+  // instructions, so a wave never pays for a path only one lane needs.
+  const uint32_t* __restrict__ T = L.lit_fast;  // dist_fast follows lit_fast in LDS
+  constexpr uint32_t DIST_BASE = (1u << V2_LIT_BITS) + V2_LIT_SUB;
+  uint32_t st = 0, tb = 0, sh = 0, mb = V2_LIT_BITS, mlen = 0;
   while (__ballot(run) != 0ull) {
+    const bool at_start = st == 0 && sh == 0;
     if (MODE == 0) {
-      const bool cross = run && !seen && pos >= count_from;
+      const bool cross = run && at_start && !seen && pos >= count_from;
       if (cross) { first = pos; no = 0; nm = 0; }
       seen = seen || cross;
     }
@@ -299,65 +308,46 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       const bool rf = run && bc <= 32;
       if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
     }
-    uint32_t e = L.lit_fast[(uint32_t)bb & ((1u << V2_LIT_BITS) - 1u)];
-    {
-      const bool need2 = (e & 15u) == 0;
-      if (__ballot(run && need2) != 0ull) {
-        const uint32_t idx = ((e >> 8) & 0x7FFu) + ((uint32_t)(bb >> V2_LIT_BITS) & ((1u << ((e >> 4) & 15u)) - 1u));
-        const uint32_t e2 = L.lit_fast[(need2 && (e & E_SUB)) ? idx : 0u];
-        e = need2 ? ((e & E_SUB) ? e2 : 0u) : e;
-      }
-    }
-    uint32_t l = e & 15u;                    // 0 => no such code (F_BAD)
-    const bool is_len = run && (e & E_LEN) != 0;
-    const bool is_eob = run && (e & E_EOB) != 0;
-    const bool is_lit = run && l != 0 && !(e & (E_LEN | E_EOB));
-    uint32_t bad = (run && l == 0) ? F_BAD : 0u;
-    if (!run) l = 0;
-    bb >>= l; bc -= (int)l; pos += l;
+    const uint32_t e = T[tb + ((uint32_t)(bb >> sh) & ((1u << mb) - 1u))];
+    const uint32_t l = e & 15u;
+    const bool sym = run && l != 0;                       // a real table entry (code length l)
+    const bool sub = run && l == 0 && (e & E_SUB) != 0;   // pointer to a second-level table
+    uint32_t bad = (run && l == 0 && !(e & E_SUB)) ? F_BAD : 0u;
+    const bool in_lit = st == 0;
+    const bool is_len = sym && in_lit && (e & E_LEN) != 0;
+    const bool is_eob = sym && in_lit && (e & E_EOB) != 0;
+    const bool is_lit = sym && in_lit && !(e & (E_LEN | E_EOB));
+    const bool is_dist = sym && !in_lit;
+    const uint32_t eb = (e >> 4) & 15u;                   // extra bits (length or distance), 15 = invalid symbol
+    const uint32_t ebv = (is_len || is_dist) ? (eb == 15u ? 0u : eb) : 0u;
+    const uint32_t extra = (uint32_t)(bb >> l) & ((1u << ebv) - 1u);
+    const uint32_t adv = sym ? l + ebv : 0u;
+    bb >>= adv; bc -= (int)adv; pos += adv;
+    if ((is_len || is_dist) && eb == 15u) bad = F_BAD;
     if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)(e >> 8); }
     if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 8); }
-    opos += is_lit ? 1u : 0u;
-    no += is_lit ? 1u : 0u;
-    if (__ballot(is_len) != 0ull) {
-      const uint32_t eb = is_len ? ((e >> 4) & 15u) : 0u;
-      const uint32_t ebv = eb == 15u ? 0u : eb;           // invalid length symbol: flagged below
-      const uint32_t mlen = ((e >> 8) & 511u) + ((uint32_t)bb & ((1u << ebv) - 1u));
-      bb >>= ebv; bc -= (int)ebv; pos += ebv;
-      {
-        const bool rf = is_len && bc <= 32;
-        if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
-      }
-      uint32_t de = L.dist_fast[(uint32_t)bb & ((1u << V2_DIST_BITS) - 1u)];
-      {
-        const bool need2 = is_len && (de & 15u) == 0;
-        if (__ballot(need2) != 0ull) {
-          const uint32_t idx = ((de >> 8) & 0x7FFu) + ((uint32_t)(bb >> V2_DIST_BITS) & ((1u << ((de >> 4) & 15u)) - 1u));
-          const uint32_t d2 = L.dist_fast[(need2 && (de & E_SUB)) ? idx : 0u];
-          de = need2 ? ((de & E_SUB) ? d2 : 0u) : de;
-        }
-      }
-      const uint32_t dl = is_len ? (de & 15u) : 0u;
-      const uint32_t deb = is_len ? ((de >> 4) & 15u) : 0u;
-      const uint32_t debv = deb == 15u ? 0u : deb;
-      const uint32_t dist = (de >> 8) + ((uint32_t)(bb >> dl) & ((1u << debv) - 1u));
-      const uint32_t adv = dl + debv;
-      bb >>= adv; bc -= (int)adv; pos += adv;
-      uint32_t mbad = (is_len && (eb == 15u || dl == 0u || deb == 15u)) ? F_BAD : 0u;
-      if (WRITE) {
-        if (is_len && dist > opos) mbad = F_BAD;
-        if (is_len && !mbad)
-          mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)dist << 44);
-        mpos += (is_len && !mbad) ? 1u : 0u;
-      }
-      const bool ok = is_len && !mbad;
-      opos += ok ? mlen : 0u;
-      no += ok ? mlen : 0u;
-      nm += ok ? 1u : 0u;
-      bad |= mbad;
+    if (is_len) mlen = ((e >> 8) & 511u) + extra;
+    const uint32_t dist = (e >> 8) + extra;
+    bool okm = is_dist && !bad;
+    if (WRITE) {
+      if (okm && dist > opos) { bad = F_BAD; okm = false; }
+      if (okm) mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)dist << 44);
+      mpos += okm ? 1u : 0u;
+    }
+    const uint32_t produced = is_lit ? 1u : (okm ? mlen : 0u);
+    opos += produced;
+    no += produced;
+    nm += okm ? 1u : 0u;
+    // next lookup
+    if (sub) { tb = (in_lit ? 0u : DIST_BASE) + ((e >> 8) & 0x7FFu); sh = in_lit ? V2_LIT_BITS : V2_DIST_BITS; mb = (e >> 4) & 15u; }
+    if (sym) {
+      st = is_len ? 1u : 0u;
+      tb = is_len ? DIST_BASE : 0u;
+      sh = 0;
+      mb = is_len ? V2_DIST_BITS : V2_LIT_BITS;
     }
     fl |= bad | (is_eob ? F_EOB : 0u);
-    run = run && fl == 0 && pos < limit;
+    run = run && fl == 0 && (st != 0 || sh != 0 || pos < limit);
   }
   if (active) {
     // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no

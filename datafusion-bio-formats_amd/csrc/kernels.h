@@ -117,7 +117,8 @@ void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0,
 void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst,
                             int which, uint32_t* qual_wide, hipStream_t st);
 void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
-                                 const uint64_t* off_qual, uint8_t* d_qual, uint32_t* qual_wide, hipStream_t st);
+                                 const uint64_t* off_qual, uint8_t* d_qual, const uint64_t* off_name, uint8_t* d_name,
+                                 uint32_t* qual_wide, hipStream_t st);
 void launch_qual_wide_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, uint32_t* len_qual, hipStream_t st);
 void launch_qual_wide_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
 

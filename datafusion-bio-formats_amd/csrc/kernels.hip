@@ -719,7 +719,8 @@ __device__ __forceinline__ uint32_t qual_swar(uint32_t w) { return ((w & 0x7F7F7
 __global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
                                                                uint64_t n, const uint64_t* __restrict__ off_seq,
                                                                uint8_t* __restrict__ d_seq, const uint64_t* __restrict__ off_qual,
-                                                               uint8_t* __restrict__ d_qual, uint32_t* qual_wide) {
+                                                               uint8_t* __restrict__ d_qual, const uint64_t* __restrict__ off_name,
+                                                               uint8_t* __restrict__ d_name, uint32_t* qual_wide) {
   __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first), little-endian u16
   {
     const char* L = "=ACMGRSVTWYHKDBN";
@@ -733,17 +734,18 @@ __global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __r
   if (r_lo >= n) return;
   // lanes 0..15 fetch the metadata of the wave's 16 rows in parallel (one dependent-load chain for all of
   // them); the row loop broadcasts it with shuffles
-  uint64_t m_sp = 0, m_os = 0, m_oq = 0;
-  uint32_t m_lseq = 0;
+  uint64_t m_sp = 0, m_os = 0, m_oq = 0, m_on = 0;
+  uint32_t m_lseq = 0, m_lrn = 0, m_ncig = 0;
   if (lane < SQR_ROWS_PER_WAVE && r_lo + lane < n) {
     const uint64_t ro = rows[r_lo + lane];
     const uint8_t* rec = u + ro;
-    const uint32_t lrn = rec[12];
-    const uint32_t ncig = ld_u16(rec + 16);
+    m_lrn = rec[12];
+    m_ncig = ld_u16(rec + 16);
     m_lseq = (uint32_t)ld_i32(rec + 20);
-    m_sp = ro + 36 + lrn + 4ull * ncig;
+    m_sp = ro + 36 + m_lrn + 4ull * m_ncig;
     if (d_seq) m_os = off_seq[r_lo + lane];
     if (d_qual) m_oq = off_qual[r_lo + lane];
+    if (d_name) m_on = off_name[r_lo + lane];
   }
   bool wide = false;
   const int nrow = (int)((n - r_lo) < SQR_ROWS_PER_WAVE ? (n - r_lo) : SQR_ROWS_PER_WAVE);
@@ -752,9 +754,21 @@ __global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __r
     const int k = it * 4 + g;
     const uint32_t lseq = __shfl(m_lseq, k, 64);
     const uint64_t spo = __shfl(m_sp, k, 64), oso = __shfl(m_os, k, 64), oqo = __shfl(m_oq, k, 64);
+    const uint32_t lrn = __shfl(m_lrn, k, 64), ncig = __shfl(m_ncig, k, 64);
+    const uint64_t ono = __shfl(m_on, k, 64);
     if (k >= nrow) continue;
     const uint8_t* sp = u + spo;
     const uint8_t* qp = sp + ((lseq + 1) >> 1);
+    if (d_name && lrn > 1) {
+      const uint8_t* np = sp - 4ull * ncig - lrn;  // read_name starts 36 bytes into the record
+      uint8_t* o = d_name + ono;
+      const uint32_t l = lrn - 1;
+      for (uint32_t c = (uint32_t)sl * 16; c < l; c += 256) {
+        const uint32_t rem = l - c;
+        if (rem >= 16) *(u32x4u*)(o + c) = *(const u32x4u*)(np + c);
+        else for (uint32_t j = 0; j < rem; j++) o[c + j] = np[c + j];
+      }
+    }
     if (d_seq) {
       uint8_t* o = d_seq + oso;
       for (uint32_t c = (uint32_t)sl * 16; c < lseq; c += 256) {
@@ -804,11 +818,12 @@ __global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __r
   if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
 }
 void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
-                                 const uint64_t* off_qual, uint8_t* d_qual, uint32_t* qual_wide, hipStream_t st) {
-  if (!n || (!d_seq && !d_qual)) return;
+                                 const uint64_t* off_qual, uint8_t* d_qual, const uint64_t* off_name, uint8_t* d_name,
+                                 uint32_t* qual_wide, hipStream_t st) {
+  if (!n || (!d_seq && !d_qual && !d_name)) return;
   const uint64_t waves = (n + SQR_ROWS_PER_WAVE - 1) / SQR_ROWS_PER_WAVE;
   hipLaunchKernelGGL(k_scatter_seqqual_rows, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, u, rows, n, off_seq, d_seq, off_qual,
-                     d_qual, qual_wide);
+                     d_qual, off_name, d_name, qual_wide);
 }
 
 // exact wide-quality path: `char::from(q + 33)` pushed into a String -> chars >= U+0080 take two UTF-8 bytes
