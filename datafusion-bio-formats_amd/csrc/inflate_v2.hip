@@ -772,7 +772,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
       if (bfinal) break;
     }
     if (st == INF_OK && opos != isize) st = INF_SIZE_MISMATCH;
-    if (ablate) st = INF_OK;
+    if (ablate & 0xFFu) st = INF_OK;
     if (lane == 0) status[b] = st;
   }
   if (dbg && lane == 0) {
@@ -793,7 +793,8 @@ void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const
                             uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st) {
   if (!n_blocks) return;
   const char* ab = getenv("BIOSCAN_V2_ABLATE");
-  const uint32_t ablate = (ab && n_blocks > 64) ? (uint32_t)atoi(ab) : 0u;
+  const char* off = getenv("BIOSCAN_V2_OFF");  // bit mask of optional fast paths to switch off (A/B measurements)
+  const uint32_t ablate = ((ab && n_blocks > 64) ? ((uint32_t)atoi(ab) & 0xFFu) : 0u) | (off ? ((uint32_t)atoi(off) << 8) : 0u);
   const char* db = getenv("BIOSCAN_DBG_BLOCK");
   const uint32_t dbg_block = db ? (uint32_t)atoi(db) : 0xFFFFFFFFu;
   (void)g_v2_grid;
