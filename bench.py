@@ -117,6 +117,46 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
     filters = [("chrom", "=", "chr1")] if sites else []
     plan = prov.scan(filters=filters, target_partitions=1)
     assert plan.num_partitions() == 1
+    cpu_in = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # inputs of the CPU baseline (C oracle on the same bytes): file image + the member / text range of the scan
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import struct
+        import vcf_oracle
+        data = open(path, "rb").read()
+        b0 = b1 = x0 = x1 = 0
+        coffs, uoffs, o, uo = [], [], 0, 0
+        while o + 28 <= len(data):
+            bs = struct.unpack_from("<H", data, o + 16)[0] + 1
+            coffs.append(o)
+            uoffs.append(uo)
+            uo += struct.unpack_from("<I", data, o + bs - 4)[0]
+            o += bs
+        coffs.append(o)
+        uoffs.append(uo)
+        if sites:
+            tbi = vcf_oracle.parse_tbi(open(path + ".tbi", "rb").read())
+            ch = vcf_oracle.tbi_query_chunks(tbi, tbi.names.index("chr1"), None, None)
+            import bisect
+            b0 = bisect.bisect_left(coffs, ch[0][0] >> 16)
+            be = bisect.bisect_left(coffs, ch[-1][1] >> 16)
+            b1 = min(be + 2, len(coffs) - 1)
+            x0 = ch[0][0] & 0xFFFF
+            x1 = uoffs[be] - uoffs[b0] + (ch[-1][1] & 0xFFFF)
+        else:
+            # header length: decode the leading members until the #CHROM line is complete
+            import zlib
+            txt, k = b"", 0
+            while True:
+                xl = struct.unpack_from("<H", data, coffs[k] + 10)[0]
+                txt += zlib.decompress(data[coffs[k] + 12 + xl:coffs[k + 1] - 8], -15)
+                k += 1
+                i = txt.find(b"\n#CHROM")
+                j = txt.find(b"\n", i + 1) if i >= 0 else -1
+                if j >= 0:
+                    x0 = j + 1
+                    break
+        cpu_in = (data, b0, b1, x0, x1)
     for p in (path, path + ".tbi"):
         if not args.keep_file:
             try:
@@ -155,6 +195,29 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
         c = torch.tensor([rows, ubytes], dtype=torch.float64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rows, ubytes = [float(x) for x in c.tolist()]
+    cpu = None
+    if cpu_in is not None:
+        import c_oracle
+        data, b0, b1, x0, x1 = cpu_in
+        cores = min(16, ncpu)
+        info = [("AC", "list_int"), ("AN", "int"), ("AF", "list_float"), ("DP", "int")]
+        if sites:
+            info += [("DB", "flag"), ("SEGDUP", "flag"), ("LCR", "flag"), ("VT", "string"), ("RSRC", "list_string"),
+                     ("CULPRIT", "string"), ("VQSLOD", "float")]
+        r = c_oracle.vcf_scan(data, info, 0 if sites else args.samples, True, cores, b0, b1, x0, x1)
+        del data, cpu_in
+        if int(r["n_rows"]) != int(st["n_rows"]):
+            raise SystemExit(f"CPU baseline decoded {r['n_rows']} rows, GPU {st['n_rows']}")
+        cpu = {"value": round(r["n_rows"] / r["seconds_total"] / 1e6, 4), "unit": "Mrows/s", "cores": cores, "kind": "port",
+               "sample": ("the same scan: the members of the chr1 tabix chunks" if sites else "the same scan: every member of the file")
+                         + f" ({r['n_blocks']} BGZF members, {r['inflated_bytes'] / 1e9:.2f} GB text, {r['n_rows']} rows), every column"
+                         + ("" if sites else " + the five list UDF results")
+                         + f", {'libdeflate' if r['used_libdeflate'] else 'zlib'} inflate, {cores} threads (oracle/bioscan_oracle.c)",
+               "seconds": round(r["seconds_total"], 3), "seconds_inflate": round(r["seconds_inflate"], 3)}
+        if not sites:
+            # the UDF checksums of the two implementations must agree
+            assert int(r["avg_gq_valid"]) == us[0]["count_a"] and int(r["gq_gte_true"]) == us[2]["count_a"], (r, us)
+            assert int(r["dp_gte_true"]) == us[3]["count_a"] and int(r["dp_lte_true"]) == us[4]["count_a"], (r, us)
     if rank == 0:
         per_step = elapsed / args.steps
         # algorithmic bytes of the text stage: decoded text read once by the delimiter index + once by the
@@ -182,7 +245,7 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
             "arrow_bytes": st["arrow_bytes"], "scan_wall_ms": round(st["ms_wall"], 3), "gpu_ms": round(gpu_ms, 3),
             "roofline": {"bound": "hbm", "kernel": "VCF pipeline (inflate + text kernels)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
-            "cpu_baseline": None,
+            "cpu_baseline": cpu,
             "setup_s": {"generate": round(t_gen, 1)}}
         print(json.dumps(out))
     if world > 1:

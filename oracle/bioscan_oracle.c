@@ -399,3 +399,281 @@ int oracle_bam_scan(const char* path, int zero_based, int threads, uint64_t max_
   free(d);
   return rc;
 }
+
+/* =================================================================================================
+ * VCF (oracle/vcf_oracle.py restated in C for medium-scale checks and as the CPU baseline of the VCF
+ * bench lines).  Decodes BGZF members [b0, b1) with libdeflate/zlib, splits the text [x0, x1) of that
+ * range into lines, and builds every column of the scan into per-thread growable buffers: the 8 core
+ * columns (bio-format-vcf/src/physical_exec.rs:1043-1093), the INFO columns given by `info_names` /
+ * `info_kinds` (load_infos_single_pass :544-640) and, when n_samples > 0, the FORMAT keys GT/GQ/DP of every
+ * sample (MultiSampleFormatBuilder::append_record :1634-1828) followed by the list UDFs of the config-4
+ * query (udfs.rs:67-110, 606-650).  The result carries row counts and checksums of every column so the
+ * Python oracle (and the GPU path) can be compared against it without shipping the columns.
+ * ================================================================================================= */
+typedef struct {
+  uint64_t n_rows, n_blocks, compressed_bytes, inflated_bytes;
+  uint64_t sum_start, sum_end, core_str_bytes, n_qual_valid;
+  double sum_qual;
+  uint64_t info_int_sum, info_valid, info_float_valid, info_str_bytes, info_flag_true, info_list_elems;
+  double info_float_sum;
+  uint64_t cells, gt_bytes, gt_valid, gq_sum, gq_valid, dp_sum, dp_valid;
+  double avg_gq_sum, avg_dp_sum;
+  uint64_t avg_gq_valid, avg_dp_valid, gq_gte_true, dp_gte_true, dp_lte_true;
+  double seconds_inflate, seconds_parse, seconds_total;
+  int threads, used_libdeflate;
+  char error[256];
+} oracle_vcf_result;
+
+typedef struct { uint8_t* p; size_t n, cap; } gbuf;
+static inline void gb_put(gbuf* g, const void* src, size_t k) {
+  if (g->cap - g->n < k) { g->cap = (g->cap + k) * 2 + 4096; g->p = (uint8_t*)realloc(g->p, g->cap); }
+  memcpy(g->p + g->n, src, k);
+  g->n += k;
+}
+static inline void gb_u32(gbuf* g, uint32_t v) { gb_put(g, &v, 4); }
+static inline void gb_f64(gbuf* g, double v) { gb_put(g, &v, 8); }
+
+typedef struct {
+  const uint8_t* u;
+  uint64_t a, b;             /* this thread's text range (line aligned) */
+  int zero_based, n_info, n_samples;
+  const char* const* info_names;
+  const int* info_kinds;     /* 0 int, 1 float, 2 flag, 3 string, 4 list<int>, 5 list<float>, 6 list<string> */
+  oracle_vcf_result r;       /* per-thread partial sums */
+  gbuf cols[40];             /* column bytes: the work a builder does; freed at the end */
+  int err;
+} vcf_job;
+
+static inline const uint8_t* find_byte(const uint8_t* p, const uint8_t* e, int c) {
+  const uint8_t* q = (const uint8_t*)memchr(p, c, (size_t)(e - p));
+  return q ? q : e;
+}
+static void* vcf_worker(void* arg) {
+  vcf_job* j = (vcf_job*)arg;
+  const uint8_t* u = j->u;
+  oracle_vcf_result* r = &j->r;
+  const uint8_t* p = u + j->a;
+  const uint8_t* end = u + j->b;
+  int32_t* gq = j->n_samples ? (int32_t*)malloc(sizeof(int32_t) * (size_t)j->n_samples * 2) : NULL;
+  int32_t* dp = gq ? gq + j->n_samples : NULL;
+  while (p < end) {
+    const uint8_t* le = find_byte(p, end, '\n');
+    const uint8_t* lend = le;
+    if (lend > p && lend[-1] == '\r') lend--;
+    const uint8_t* f[10];
+    const uint8_t* fe[10];
+    const uint8_t* q = p;
+    int nf = 0;
+    while (nf < 9) {
+      const uint8_t* t = find_byte(q, lend, '\t');
+      f[nf] = q; fe[nf] = t; nf++;
+      if (t == lend) break;
+      q = t + 1;
+    }
+    if (nf < 8) { j->err = 1; break; }
+    const uint8_t* samples = (nf == 9 && fe[8] < lend) ? fe[8] + 1 : lend;
+    /* core */
+    uint64_t pos = 0;
+    for (const uint8_t* c = f[1]; c < fe[1]; c++) pos = pos * 10 + (uint64_t)(*c - '0');
+    const size_t rl = (size_t)(fe[3] - f[3]);
+    int n_alt = (fe[4] - f[4] == 1 && f[4][0] == '.') ? 0 : 1;
+    for (const uint8_t* c = f[4]; c < fe[4]; c++) n_alt += *c == ',';
+    int snv = rl == 1 && n_alt == 1 && fe[4] - f[4] == 1 && strchr("ACGT", f[3][0]) && strchr("ACGT", f[4][0]);
+    uint64_t vend = pos + rl - 1;
+    gb_put(&j->cols[0], f[0], (size_t)(fe[0] - f[0]));
+    r->core_str_bytes += (uint64_t)(fe[0] - f[0]);
+    for (int k = 2; k <= 6; k++) {
+      if (k == 5) continue;
+      size_t l = (size_t)(fe[k] - f[k]);
+      if (l == 1 && f[k][0] == '.' && k != 3) l = 0;
+      if (k == 4) {  /* alleles re-joined with '|' */
+        size_t o = j->cols[k].n;
+        gb_put(&j->cols[k], f[k], l);
+        for (size_t x = 0; x < l; x++) if (j->cols[k].p[o + x] == ',') j->cols[k].p[o + x] = '|';
+      } else gb_put(&j->cols[k], f[k], l);
+      gb_u32(&j->cols[k + 10], (uint32_t)j->cols[k].n);
+      r->core_str_bytes += l;
+    }
+    if (!(fe[5] - f[5] == 1 && f[5][0] == '.')) {
+      char tmp[64];
+      size_t l = (size_t)(fe[5] - f[5]);
+      if (l > 63) l = 63;
+      memcpy(tmp, f[5], l); tmp[l] = 0;
+      const double qv = (double)strtof(tmp, NULL);
+      gb_f64(&j->cols[5], qv);
+      r->sum_qual += qv; r->n_qual_valid++;
+    } else gb_f64(&j->cols[5], 0.0);
+    /* INFO: one pass, keys matched against the selected names */
+    if (!(fe[7] - f[7] == 1 && f[7][0] == '.')) {
+      const uint8_t* e7 = fe[7];
+      for (const uint8_t* k0 = f[7]; k0 < e7;) {
+        const uint8_t* ke = find_byte(k0, e7, ';');
+        const uint8_t* eq = find_byte(k0, ke, '=');
+        const size_t kl = (size_t)(eq - k0);
+        if (kl == 3 && memcmp(k0, "END", 3) == 0 && eq < ke) vend = strtoull((const char*)eq + 1, NULL, 10);
+        for (int x = 0; x < j->n_info; x++) {
+          if (strlen(j->info_names[x]) != kl || memcmp(j->info_names[x], k0, kl) != 0) continue;
+          const int kind = j->info_kinds[x];
+          gbuf* g = &j->cols[20 + (x % 18)];
+          if (eq == ke) { if (kind == 2) { r->info_flag_true++; gb_put(g, "\1", 1); } break; }
+          const uint8_t* v0 = eq + 1;
+          if (ke - v0 == 1 && v0[0] == '.') break;
+          if (kind == 0) { const long v = strtol((const char*)v0, NULL, 10); r->info_int_sum += (uint64_t)v; r->info_valid++; gb_u32(g, (uint32_t)v); }
+          else if (kind == 1) { char t[48]; size_t l = (size_t)(ke - v0); if (l > 47) l = 47; memcpy(t, v0, l); t[l] = 0;
+                                const float fv = strtof(t, NULL); r->info_float_sum += (double)fv; r->info_float_valid++; gb_put(g, &fv, 4); }
+          else if (kind == 3) { r->info_str_bytes += (uint64_t)(ke - v0); r->info_valid++; gb_put(g, v0, (size_t)(ke - v0)); }
+          else {
+            r->info_valid++;
+            for (const uint8_t* a0 = v0; a0 <= ke;) {
+              const uint8_t* ae = find_byte(a0, ke, ',');
+              r->info_list_elems++;
+              if (!(ae - a0 == 1 && a0[0] == '.')) {
+                if (kind == 4) { const long v = strtol((const char*)a0, NULL, 10); r->info_int_sum += (uint64_t)v; gb_u32(g, (uint32_t)v); }
+                else if (kind == 5) { char t[48]; size_t l = (size_t)(ae - a0); if (l > 47) l = 47; memcpy(t, a0, l); t[l] = 0;
+                                      const float fv = strtof(t, NULL); r->info_float_sum += (double)fv; r->info_float_valid++; gb_put(g, &fv, 4); }
+                else { r->info_str_bytes += (uint64_t)(ae - a0); gb_put(g, a0, (size_t)(ae - a0)); }
+              }
+              if (ae == ke) break;
+              a0 = ae + 1;
+            }
+          }
+          break;
+        }
+        k0 = ke + 1;
+      }
+    }
+    const uint64_t endcol = snv ? pos : vend;
+    gb_u32(&j->cols[1], (uint32_t)(j->zero_based ? pos - 1 : pos));
+    gb_u32(&j->cols[7], (uint32_t)endcol);
+    r->sum_start += j->zero_based ? pos - 1 : pos;
+    r->sum_end += endcol;
+    /* FORMAT GT:GQ:DP (positions taken from the FORMAT column) */
+    if (j->n_samples > 0 && nf == 9) {
+      int pgt = -1, pgq = -1, pdp = -1, kidx = 0;
+      for (const uint8_t* k0 = f[8]; k0 <= fe[8];) {
+        const uint8_t* ke = find_byte(k0, fe[8], ':');
+        if (ke - k0 == 2 && k0[0] == 'G' && k0[1] == 'T') pgt = kidx;
+        else if (ke - k0 == 2 && k0[0] == 'G' && k0[1] == 'Q') pgq = kidx;
+        else if (ke - k0 == 2 && k0[0] == 'D' && k0[1] == 'P') pdp = kidx;
+        kidx++;
+        if (ke == fe[8]) break;
+        k0 = ke + 1;
+      }
+      const uint8_t* s0 = samples;
+      int64_t sgq = 0, sdp = 0;
+      uint32_t ngq = 0, ndp = 0;
+      for (int s = 0; s < j->n_samples; s++) {
+        const uint8_t* se = s0 <= lend ? find_byte(s0, lend, '\t') : lend;
+        gq[s] = INT32_MIN; dp[s] = INT32_MIN;
+        r->cells++;
+        if (s0 < lend && !(se - s0 == 1 && s0[0] == '.')) {
+          int ki = 0;
+          for (const uint8_t* v0 = s0; v0 <= se;) {
+            const uint8_t* ve = find_byte(v0, se, ':');
+            const int missing = ve - v0 == 1 && v0[0] == '.';
+            if (!missing) {
+              if (ki == pgt) { gb_put(&j->cols[38], v0, (size_t)(ve - v0)); r->gt_bytes += (uint64_t)(ve - v0); r->gt_valid++; }
+              else if (ki == pgq) { gq[s] = (int32_t)strtol((const char*)v0, NULL, 10); r->gq_sum += (uint64_t)gq[s]; r->gq_valid++; }
+              else if (ki == pdp) { dp[s] = (int32_t)strtol((const char*)v0, NULL, 10); r->dp_sum += (uint64_t)dp[s]; r->dp_valid++; }
+            }
+            ki++;
+            if (ve == se) break;
+            v0 = ve + 1;
+          }
+        }
+        if (gq[s] != INT32_MIN) { sgq += gq[s]; ngq++; r->gq_gte_true += gq[s] >= 10; }
+        if (dp[s] != INT32_MIN) { sdp += dp[s]; ndp++; r->dp_gte_true += dp[s] >= 10; r->dp_lte_true += dp[s] <= 200; }
+        s0 = se + 1;
+      }
+      gb_put(&j->cols[36], gq, sizeof(int32_t) * (size_t)j->n_samples);
+      gb_put(&j->cols[37], dp, sizeof(int32_t) * (size_t)j->n_samples);
+      if (ngq) { r->avg_gq_sum += (double)sgq / (double)ngq; r->avg_gq_valid++; }
+      if (ndp) { r->avg_dp_sum += (double)sdp / (double)ndp; r->avg_dp_valid++; }
+    }
+    r->n_rows++;
+    p = le + 1;
+  }
+  free(gq);
+  for (int k = 0; k < 40; k++) { free(j->cols[k].p); j->cols[k].p = NULL; }
+  return NULL;
+}
+
+/* x0 / x1: text range relative to the first decoded byte of member b0 (x1 = 0: to the end); lines are
+ * assigned to threads by where they start. */
+int oracle_vcf_scan_mem(const uint8_t* file, uint64_t file_len, uint64_t b0, uint64_t b1, uint64_t x0, uint64_t x1, int zero_based,
+                        int threads, int n_info, const char* const* info_names, const int* info_kinds, int n_samples,
+                        oracle_vcf_result* out) {
+  memset(out, 0, sizeof(*out));
+  load_libdeflate();
+  const double t0 = now_s();
+  uint64_t nb = 0, cap = 1024;
+  uint64_t* coff = (uint64_t*)malloc(8 * (cap + 1));
+  uint64_t* uoff = (uint64_t*)malloc(8 * (cap + 1));
+  uint64_t o = 0, uo = 0;
+  while (o + 28 <= file_len) {
+    if (nb == cap) { cap *= 2; coff = (uint64_t*)realloc(coff, 8 * (cap + 1)); uoff = (uint64_t*)realloc(uoff, 8 * (cap + 1)); }
+    const uint32_t bsize = rd16(file + o + 16) + 1;
+    coff[nb] = o; uoff[nb] = uo;
+    uo += rd32(file + o + bsize - 4);
+    o += bsize;
+    nb++;
+  }
+  coff[nb] = o; uoff[nb] = uo;
+  if (b1 == 0 || b1 > nb) b1 = nb;
+  if (b0 > b1) b0 = b1;
+  const uint64_t base = uoff[b0], ulen = uoff[b1] - base;
+  uint8_t* u = (uint8_t*)malloc(ulen + 64);
+  for (uint64_t b = b0; b <= b1; b++) uoff[b] -= base;
+  if (threads < 1) threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  inflate_job* ij = (inflate_job*)calloc((size_t)threads, sizeof(inflate_job));
+  for (int t = 0; t < threads; t++) {
+    ij[t].file = file; ij[t].coff = coff; ij[t].uoff = uoff; ij[t].u = u;
+    ij[t].b0 = b0 + (b1 - b0) * (uint64_t)t / (uint64_t)threads;
+    ij[t].b1 = b0 + (b1 - b0) * (uint64_t)(t + 1) / (uint64_t)threads;
+    pthread_create(&th[t], NULL, inflate_worker, &ij[t]);
+  }
+  int bad = 0;
+  for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); bad |= ij[t].err; }
+  const double t1 = now_s();
+  if (bad) { snprintf(out->error, sizeof out->error, "BGZF inflate / CRC failure"); free(u); free(coff); free(uoff); free(th); free(ij); return 1; }
+  if (x1 == 0 || x1 > ulen) x1 = ulen;
+  vcf_job* vj = (vcf_job*)calloc((size_t)threads, sizeof(vcf_job));
+  uint64_t prev = x0;
+  for (int t = 0; t < threads; t++) {
+    uint64_t cut = t + 1 == threads ? x1 : x0 + (x1 - x0) * (uint64_t)(t + 1) / (uint64_t)threads;
+    if (t + 1 < threads) {  /* move the cut to the next line start */
+      const uint8_t* nlp = (const uint8_t*)memchr(u + cut, '\n', (size_t)(x1 - cut));
+      cut = nlp ? (uint64_t)(nlp - u) + 1 : x1;
+    }
+    if (cut < prev) cut = prev;
+    vj[t].u = u; vj[t].a = prev; vj[t].b = cut;
+    vj[t].zero_based = zero_based; vj[t].n_info = n_info; vj[t].info_names = info_names; vj[t].info_kinds = info_kinds;
+    vj[t].n_samples = n_samples;
+    prev = cut;
+    pthread_create(&th[t], NULL, vcf_worker, &vj[t]);
+  }
+  for (int t = 0; t < threads; t++) {
+    pthread_join(th[t], NULL);
+    bad |= vj[t].err;
+    const oracle_vcf_result* r = &vj[t].r;
+    out->n_rows += r->n_rows; out->sum_start += r->sum_start; out->sum_end += r->sum_end; out->core_str_bytes += r->core_str_bytes;
+    out->n_qual_valid += r->n_qual_valid; out->sum_qual += r->sum_qual;
+    out->info_int_sum += r->info_int_sum; out->info_valid += r->info_valid; out->info_float_valid += r->info_float_valid;
+    out->info_str_bytes += r->info_str_bytes; out->info_flag_true += r->info_flag_true; out->info_list_elems += r->info_list_elems;
+    out->info_float_sum += r->info_float_sum;
+    out->cells += r->cells; out->gt_bytes += r->gt_bytes; out->gt_valid += r->gt_valid; out->gq_sum += r->gq_sum; out->gq_valid += r->gq_valid;
+    out->dp_sum += r->dp_sum; out->dp_valid += r->dp_valid; out->avg_gq_sum += r->avg_gq_sum; out->avg_dp_sum += r->avg_dp_sum;
+    out->avg_gq_valid += r->avg_gq_valid; out->avg_dp_valid += r->avg_dp_valid; out->gq_gte_true += r->gq_gte_true;
+    out->dp_gte_true += r->dp_gte_true; out->dp_lte_true += r->dp_lte_true;
+  }
+  const double t2 = now_s();
+  out->n_blocks = b1 - b0;
+  out->compressed_bytes = coff[b1] - coff[b0];
+  out->inflated_bytes = ulen;
+  out->seconds_inflate = t1 - t0; out->seconds_parse = t2 - t1; out->seconds_total = t2 - t0;
+  out->threads = threads; out->used_libdeflate = ld_allocd != NULL;
+  free(u); free(coff); free(uoff); free(th); free(ij); free(vj);
+  if (bad) { snprintf(out->error, sizeof out->error, "VCF read error: invalid record"); return 1; }
+  return 0;
+}

@@ -67,3 +67,38 @@ def scan(data: bytes, zero_based=True, threads=1, max_blocks=0, tags=(), tag_kin
                 cols[name] = pa.Array.from_buffers(pa.uint32() if kind == "u" else pa.int32(), n, [vb, db])
     lib().oracle_free(C.byref(res))
     return stats, cols
+
+
+class _VcfResult(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64),
+                ("sum_start", C.c_uint64), ("sum_end", C.c_uint64), ("core_str_bytes", C.c_uint64), ("n_qual_valid", C.c_uint64),
+                ("sum_qual", C.c_double),
+                ("info_int_sum", C.c_uint64), ("info_valid", C.c_uint64), ("info_float_valid", C.c_uint64),
+                ("info_str_bytes", C.c_uint64), ("info_flag_true", C.c_uint64), ("info_list_elems", C.c_uint64),
+                ("info_float_sum", C.c_double),
+                ("cells", C.c_uint64), ("gt_bytes", C.c_uint64), ("gt_valid", C.c_uint64), ("gq_sum", C.c_uint64),
+                ("gq_valid", C.c_uint64), ("dp_sum", C.c_uint64), ("dp_valid", C.c_uint64),
+                ("avg_gq_sum", C.c_double), ("avg_dp_sum", C.c_double),
+                ("avg_gq_valid", C.c_uint64), ("avg_dp_valid", C.c_uint64), ("gq_gte_true", C.c_uint64),
+                ("dp_gte_true", C.c_uint64), ("dp_lte_true", C.c_uint64),
+                ("seconds_inflate", C.c_double), ("seconds_parse", C.c_double), ("seconds_total", C.c_double),
+                ("threads", C.c_int), ("used_libdeflate", C.c_int), ("error", C.c_char * 256)]
+
+
+VCF_KINDS = {"int": 0, "float": 1, "flag": 2, "string": 3, "list_int": 4, "list_float": 5, "list_string": 6}
+
+
+def vcf_scan(data: bytes, info=(), n_samples=0, zero_based=True, threads=1, b0=0, b1=0, x0=0, x1=0) -> dict:
+    """C restatement of the VCF scan over BGZF members [b0, b1) (b1 = 0: all), text range [x0, x1) relative to the
+    first decoded byte of member b0.  `info` = [(name, kind)] with kind in VCF_KINDS.  Returns counts + column checksums."""
+    L = lib()
+    L.oracle_vcf_scan_mem.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.POINTER(_VcfResult)]
+    names = (C.c_char_p * max(len(info), 1))(*[n.encode() for n, _ in info])
+    kinds = (C.c_int * max(len(info), 1))(*[VCF_KINDS[k] for _, k in info])
+    res = _VcfResult()
+    rc = L.oracle_vcf_scan_mem(data, len(data), b0, b1, x0, x1, 1 if zero_based else 0, threads, len(info), names, kinds,
+                               n_samples, C.byref(res))
+    if rc:
+        raise RuntimeError(res.error.decode())
+    return {k: getattr(res, k) for k, _ in _VcfResult._fields_ if k != "error"}

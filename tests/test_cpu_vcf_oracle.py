@@ -129,3 +129,88 @@ def test_choose_effective_batch_size():
     assert V.choose_effective_batch_size(8192, False, 3, 1000, 1000) == 8192
     assert V.choose_effective_batch_size(8192, True, 3, 1, 1) == 8192
     assert V.choose_effective_batch_size(8192, True, 2, 2, 2) == 8192
+
+
+def _synth(tmp_path, *args):
+    import json
+    import subprocess
+    root = os.path.join(HERE, "..")
+    exe = os.path.join(root, "tools", "_build", "synth_vcf")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(root, "tools")], stdout=subprocess.DEVNULL)
+    return json.loads(subprocess.check_output([exe] + [str(a) for a in args]))
+
+
+def _kinds(o):
+    out = []
+    for name in o.info_fields:
+        t = o.schema.field(name).type
+        if pa.types.is_list(t):
+            et = t.value_type
+            out.append((name, "list_int" if et == pa.int32() else "list_float" if et == pa.float32() else "list_string"))
+        else:
+            out.append((name, "int" if t == pa.int32() else "float" if t == pa.float32() else "flag" if t == pa.bool_() else "string"))
+    return out
+
+
+def test_c_vcf_oracle_matches_python_oracle(tmp_path):
+    """oracle/bioscan_oracle.c: oracle_vcf_scan_mem (the CPU baseline of the VCF bench lines) reproduces the column
+    checksums of the Python oracle on synthetic config-3 and config-4 style files."""
+    import c_oracle
+    import numpy as np
+    for mode, args, ns in (("sites", (3000, 3), 0), ("samples", (120, 40, 3), 40)):
+        path = str(tmp_path / f"{mode}.vcf.gz")
+        _synth(tmp_path, mode, path, *args)
+        o = V.VcfOracle(path, index_path=None)
+        _, bs = o.execute(o.scan(), 0)
+        t = pa.Table.from_batches(bs)
+        data = open(path, "rb").read()
+        for threads in (1, 3):
+            r = c_oracle.vcf_scan(data, _kinds(o), ns, True, threads, x0=o.data_start)
+            assert r["n_rows"] == t.num_rows
+            assert r["sum_start"] == sum(t.column("start").to_pylist()) and r["sum_end"] == sum(t.column("end").to_pylist())
+            assert r["core_str_bytes"] == sum(len(s) for c in ("chrom", "id", "ref", "alt", "filter") for s in t.column(c).to_pylist())
+            q = [x for x in t.column("qual").to_pylist() if x is not None]
+            assert r["n_qual_valid"] == len(q) and abs(r["sum_qual"] - sum(q)) < 1e-6 * max(1.0, sum(q))
+            ints = flt = strs = flags = elems = 0
+            for name, kind in _kinds(o):
+                for v in t.column(name).to_pylist():
+                    if v is None:
+                        continue
+                    if kind == "int":
+                        ints += v
+                    elif kind == "flag":
+                        flags += bool(v)
+                    elif kind == "string":
+                        strs += len(v)
+                    elif kind == "float":
+                        flt += 1
+                    else:
+                        elems += len(v)
+                        for x in v:
+                            if x is None:
+                                continue
+                            if kind == "list_int":
+                                ints += x
+                            elif kind == "list_float":
+                                flt += 1
+                            else:
+                                strs += len(x)
+            assert (r["info_int_sum"], r["info_float_valid"], r["info_str_bytes"], r["info_flag_true"], r["info_list_elems"]) == \
+                (ints, flt, strs, flags, elems)
+            if ns:
+                g = t.column("genotypes").combine_chunks()
+                gq, dp, gt = g.field("GQ"), g.field("DP"), g.field("GT")
+                fq = [x for row in gq.to_pylist() for x in row]
+                fd = [x for row in dp.to_pylist() for x in row]
+                fg = [x for row in gt.to_pylist() for x in row]
+                assert r["cells"] == len(fq)
+                assert (r["gq_sum"], r["gq_valid"]) == (sum(x for x in fq if x is not None), sum(x is not None for x in fq))
+                assert (r["dp_sum"], r["dp_valid"]) == (sum(x for x in fd if x is not None), sum(x is not None for x in fd))
+                assert (r["gt_bytes"], r["gt_valid"]) == (sum(len(x) for x in fg if x is not None), sum(x is not None for x in fg))
+                a = V.list_avg(gq).to_pylist()
+                assert r["avg_gq_valid"] == sum(x is not None for x in a)
+                assert abs(r["avg_gq_sum"] - sum(x for x in a if x is not None)) < 1e-9 * max(1.0, r["avg_gq_sum"])
+                assert r["gq_gte_true"] == sum(bool(x) for row in V.list_gte(gq, 10).to_pylist() for x in row)
+                assert r["dp_gte_true"] == sum(bool(x) for row in V.list_gte(dp, 10).to_pylist() for x in row)
+                assert r["dp_lte_true"] == sum(bool(x) for row in V.list_lte(dp, 200).to_pylist() for x in row)
