@@ -96,9 +96,10 @@ void BgzfSource::make_resident() {
     HIP_CHECK(hipGetDeviceProperties(&pr, device));
     const char* g = getenv("BIOSCAN_V2_WG_PER_CU");
     v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)(g ? atoi(g) : v2_resident_wg_per_cu());
+    if (getenv("BIOSCAN_DEBUG")) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", g ? atoi(g) : v2_resident_wg_per_cu(), pr.multiProcessorCount);
     v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
     d_v2_ctr.alloc(32);
-    d_v2_scratch.alloc((size_t)v2_grid * V2_SCRATCH_STRIDE);
+    d_v2_scratch.alloc(((size_t)v2_grid + 8) * V2_SCRATCH_STRIDE);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   resident = true;

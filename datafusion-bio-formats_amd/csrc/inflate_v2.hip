@@ -46,8 +46,19 @@ constexpr int V2_WIN = V2_WIN_BYTES;                    // LDS output window of 
 constexpr int V2_STAGE_DW = V2_GLOBAL_INPUT ? 4 : 64 * V2_MAX_SUB_DW + 8;
 constexpr int V2_LIT_SUB = 352;    // 852 - 512 = 340 sub-table entries at most
 constexpr int V2_DIST_SUB = 528;   // 592 - 64
-constexpr uint32_t E_LEN = 1u << 17, E_EOB = 1u << 18, E_SUB = 1u << 19;  // E_SUB: bits[4:7] = sub-table index bits, [8:18] = base
+// 16-bit table entries (half the LDS of u32 entries: K1 is latency-bound, its speed follows occupancy).
+// symbol entry: len[0:3] | symbol[4:12] (length / distance base and extra bits are recomputed from the symbol in
+// the decode loop); sub-table pointer: E_SUB | index bits[0:3] | absolute table index[4:14]; 0 = no code.
+constexpr uint32_t E_SUB = 0x8000u;
 constexpr uint32_t F_EOB = 1, F_BAD = 2;
+// Waves of one workgroup decode different members and never exchange data: a workgroup only exists to get past
+// the 16-workgroups-per-CU residency cap (K1 is latency-bound, its speed follows the number of resident waves).
+// Every synchronisation is therefore wave-local: LDS operations of one wave execute in order, so a compiler +
+// counter fence is all a "barrier" has to be.
+#ifndef V2_WAVES_PER_WG
+#define V2_WAVES_PER_WG 1
+#endif
+#define V2_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
 // Table-build scratch (code lengths, canonical order, precode table) is only live while a block header
 // is parsed, the output window only while a round is written and resolved: they share LDS.
@@ -62,9 +73,12 @@ struct V2Build {
   uint8_t pre_lens[20];
 };
 struct __attribute__((aligned(16))) V2Lds {
-  uint32_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];     // len[0:3] extra[4:7] base[8:16] E_LEN E_EOB | E_SUB pointer ; 0 = no code
-  uint32_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // len[0:3] extra[4:7] base[8:23] | E_SUB pointer
+  uint16_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];
+  uint16_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // must follow lit_fast: the decode loop indexes both as one array
   uint32_t stage[V2_STAGE_DW];
+#ifdef V2_PAD_LDS
+  uint32_t pad_lds[V2_PAD_LDS / 4];  // occupancy experiment only
+#endif
   union {
     uint8_t win[V2_WIN] __attribute__((aligned(16)));
     V2Build b;
@@ -121,35 +135,30 @@ __device__ __forceinline__ uint32_t ub_take(UBits& s, int n) {
 __device__ __forceinline__ uint64_t ub_bitpos(const UBits& s) { return (uint64_t)s.wpos * 32 - (uint64_t)s.bc; }
 
 // ---- table entries ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lit_entry(int sym, int len) {
-  if (sym < 256) return ((uint32_t)sym << 8) | (uint32_t)len;
-  if (sym == 256) return E_EOB | (uint32_t)len;
-  int s = sym - 257;
-  uint32_t base, eb;
-  if (s < 8) { base = 3 + s; eb = 0; }
-  else if (s == 28) { base = 258; eb = 0; }
-  else if (s < 28) { eb = (uint32_t)(s - 4) >> 2; base = 3 + ((4 + (s & 3)) << eb); }
-  else { base = 0; eb = 15; }  // invalid length symbol 286/287: flagged at decode time (eb == 15)
-  return E_LEN | (base << 8) | (eb << 4) | (uint32_t)len;
+__device__ __forceinline__ uint32_t sym_entry(int sym, int len) { return ((uint32_t)sym << 4) | (uint32_t)len; }
+// length symbol s = sym - 257 (0..28) / distance symbol (0..29): base value and extra-bit count (RFC 1951 3.2.5)
+__device__ __forceinline__ void len_base_extra(uint32_t s, uint32_t* base, uint32_t* eb) {
+  const uint32_t e = s < 8u ? 0u : (s - 4u) >> 2;
+  const uint32_t b = s < 8u ? 3u + s : 3u + ((4u + (s & 3u)) << e);
+  *eb = s == 28u ? 0u : e;
+  *base = s == 28u ? 258u : b;
 }
-__device__ __forceinline__ uint32_t dist_entry(int sym, int len) {
-  uint32_t base, eb;
-  if (sym < 4) { base = 1 + sym; eb = 0; }
-  else if (sym < 30) { eb = (uint32_t)(sym - 2) >> 1; base = 1 + ((2 + (sym & 1)) << eb); }
-  else { base = 0; eb = 15; }  // invalid distance symbol 30/31
-  return (base << 8) | (eb << 4) | (uint32_t)len;
+__device__ __forceinline__ void dist_base_extra(uint32_t s, uint32_t* base, uint32_t* eb) {
+  const uint32_t e = s < 4u ? 0u : (s - 2u) >> 1;
+  *eb = e;
+  *base = s < 4u ? 1u + s : 1u + ((2u + (s & 1u)) << e);
 }
 
 // Build the two-level decode table of one alphabet: root table of 2^root_bits entries followed by
 // sub-tables for codes longer than root_bits (canonical codes that share a root prefix are
 // contiguous in (len, sym) order, so each sub-table is sized by the last = longest code of its
 // group).  Returns 1 if the code is over-subscribed or the sub-table space is exhausted.
-__device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, int root_bits, int sub_cap, uint16_t* sorted,
-                        uint16_t* count, bool is_dist, int lane) {
-  __syncthreads();
+__device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, uint32_t abs_off, int root_bits, int sub_cap,
+                        uint16_t* sorted, uint16_t* count, bool is_dist, int lane) {
+  V2_SYNC();
   for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = 0;
   if (lane < 16) count[lane] = 0;
-  __syncthreads();
+  V2_SYNC();
   // 1. histogram of code lengths: 64 symbols per step, one ballot per length value; lane L keeps count[L]
   uint32_t my_cnt = 0;
   for (int c0 = 0; c0 < n; c0 += WAVE) {
@@ -162,7 +171,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
     }
   }
   if (lane >= 1 && lane <= 15) count[lane] = (uint16_t)my_cnt;
-  __syncthreads();
+  V2_SYNC();
   if (lane == 0) {
     uint32_t o = 0, code = 0;
     int left = 1, over = 0;
@@ -180,7 +189,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
     L.b.t_offs[0] = (uint16_t)o;
     L.b.t_first[0] = (uint16_t)over;
   }
-  __syncthreads();
+  V2_SYNC();
   // 2. canonical order (by length, then symbol): rank of a symbol inside its length class = symbols of
   //    the same length with a smaller index -> per-chunk ballots with a running base per length
   {
@@ -199,7 +208,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       if (l) sorted[slot] = (uint16_t)sidx;
     }
   }
-  __syncthreads();
+  V2_SYNC();
   if (lane == 0) {
     uint32_t o = L.b.t_offs[0];
     int over = L.b.t_first[0];
@@ -223,13 +232,13 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
       }
       const uint32_t sbits = (uint32_t)(max_len - root_bits);
       if (next_free + (1u << sbits) > (1u << root_bits) + (uint32_t)sub_cap) { over = 1; break; }
-      fast[bitrev2(prefix, root_bits)] = E_SUB | (next_free << 8) | (sbits << 4);
+      fast[bitrev2(prefix, root_bits)] = (uint16_t)(E_SUB | ((abs_off + next_free) << 4) | sbits);
       for (uint32_t m = k; m < j; m++) {
         const int sm = sorted[m];
         const int lm = lens[sm];
         const uint32_t cm = (uint32_t)L.b.t_first[lm] + (m - L.b.t_offs[lm]);
         const uint32_t r = bitrev2(cm, lm) >> root_bits;  // bits after the root, LSB-first
-        const uint32_t e = is_dist ? dist_entry(sm, lm) : lit_entry(sm, lm);
+        const uint16_t e = (uint16_t)sym_entry(sm, lm);
         for (uint32_t i = r; i < (1u << sbits); i += (1u << (lm - root_bits))) fast[next_free + i] = e;
       }
       next_free += 1u << sbits;
@@ -237,7 +246,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
     }
     L.b.t_first[0] = (uint16_t)over;
   }
-  __syncthreads();
+  V2_SYNC();
   if (uni2(L.b.t_first[0])) return 1;
   const uint32_t o = uni2(L.b.t_offs[0]);
   for (uint32_t k = lane; k < o; k += WAVE) {
@@ -246,11 +255,11 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint32_t* fast, in
     if (l <= root_bits) {
       uint32_t c = (uint32_t)L.b.t_first[l] + (k - L.b.t_offs[l]);
       uint32_t r = bitrev2(c, l);
-      uint32_t e = is_dist ? dist_entry(sym, l) : lit_entry(sym, l);
+      const uint16_t e = (uint16_t)sym_entry(sym, l);
       for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
     }
   }
-  __syncthreads();
+  V2_SYNC();
   return 0;
 }
 
@@ -293,7 +302,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
   // (0) or the distance of a pending match (1).  A sub-table pointer only re-targets the next lookup, a
   // length symbol switches the lane to the distance table: lanes in different states share the same
   // instructions, so a wave never pays for a path only one lane needs.
-  const uint32_t* __restrict__ T = L.lit_fast;  // dist_fast follows lit_fast in LDS
+  const uint16_t* __restrict__ T = L.lit_fast;  // dist_fast follows lit_fast in LDS
   constexpr uint32_t DIST_BASE = (1u << V2_LIT_BITS) + V2_LIT_SUB;
   uint32_t st = 0, tb = 0, sh = 0, mb = V2_LIT_BITS, mlen = 0;
   while (__ballot(run) != 0ull) {
@@ -309,25 +318,31 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
     }
     const uint32_t e = T[tb + ((uint32_t)(bb >> sh) & ((1u << mb) - 1u))];
-    const uint32_t l = e & 15u;
+    const bool is_ptr = (e & E_SUB) != 0;
+    const uint32_t l = is_ptr ? 0u : (e & 15u);
     const bool sym = run && l != 0;                       // a real table entry (code length l)
-    const bool sub = run && l == 0 && (e & E_SUB) != 0;   // pointer to a second-level table
-    uint32_t bad = (run && l == 0 && !(e & E_SUB)) ? F_BAD : 0u;
+    const bool sub = run && is_ptr;                        // pointer to a second-level table
+    uint32_t bad = (run && e == 0u) ? F_BAD : 0u;
     const bool in_lit = st == 0;
-    const bool is_len = sym && in_lit && (e & E_LEN) != 0;
-    const bool is_eob = sym && in_lit && (e & E_EOB) != 0;
-    const bool is_lit = sym && in_lit && !(e & (E_LEN | E_EOB));
+    const uint32_t sv = (e >> 4) & 0x1FFu;                // symbol value
+    const bool is_len = sym && in_lit && sv > 256u;
+    const bool is_eob = sym && in_lit && sv == 256u;
+    const bool is_lit = sym && in_lit && sv < 256u;
     const bool is_dist = sym && !in_lit;
-    const uint32_t eb = (e >> 4) & 15u;                   // extra bits (length or distance), 15 = invalid symbol
-    const uint32_t ebv = (is_len || is_dist) ? (eb == 15u ? 0u : eb) : 0u;
+    uint32_t lbase, leb, dbase, deb;
+    len_base_extra(sv - 257u, &lbase, &leb);
+    dist_base_extra(sv, &dbase, &deb);
+    const bool inval = in_lit ? (is_len && sv > 285u) : (is_dist && sv > 29u);  // symbols 286/287, 30/31 never occur in valid data
+    const uint32_t ebv = (is_len || is_dist) && !inval ? (in_lit ? leb : deb) : 0u;
+    const uint32_t base = in_lit ? lbase : dbase;
     const uint32_t extra = (uint32_t)(bb >> l) & ((1u << ebv) - 1u);
     const uint32_t adv = sym ? l + ebv : 0u;
     bb >>= adv; bc -= (int)adv; pos += adv;
-    if ((is_len || is_dist) && eb == 15u) bad = F_BAD;
-    if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)(e >> 8); }
-    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 8); }
-    if (is_len) mlen = ((e >> 8) & 511u) + extra;
-    const uint32_t dist = (e >> 8) + extra;
+    if (inval) bad = F_BAD;
+    if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)sv; }
+    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)sv; }
+    if (is_len) mlen = base + extra;
+    const uint32_t dist = base + extra;
     bool okm = is_dist && !bad;
     if (WRITE) {
       if (okm && dist > opos) { bad = F_BAD; okm = false; }
@@ -339,7 +354,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     no += produced;
     nm += okm ? 1u : 0u;
     // next lookup
-    if (sub) { tb = (in_lit ? 0u : DIST_BASE) + ((e >> 8) & 0x7FFu); sh = in_lit ? V2_LIT_BITS : V2_DIST_BITS; mb = (e >> 4) & 15u; }
+    if (sub) { tb = (e >> 4) & 0x7FFu; sh = in_lit ? V2_LIT_BITS : V2_DIST_BITS; mb = e & 15u; }
     if (sym) {
       st = is_len ? 1u : 0u;
       tb = is_len ? DIST_BASE : 0u;
@@ -523,15 +538,19 @@ __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t 
   }
 }
 
-__global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __restrict__ comp,
+#ifndef V2_WAVES_PER_EU
+#define V2_WAVES_PER_EU 5
+#endif
+__global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgzf_inflate_v2(const uint8_t* __restrict__ comp,
                                                            const uint64_t* __restrict__ blk_coff,
                                                            const uint64_t* __restrict__ blk_uoff, uint8_t* out_all,
                                                            uint32_t n_blocks, uint32_t* __restrict__ status,
                                                            uint32_t* counter, unsigned long long* scratch,
                                                            uint32_t scratch_stride, uint32_t* dbg, uint32_t ablate, uint32_t dbg_block) {
-  __shared__ V2Lds L;
-  const int lane = threadIdx.x;
-  unsigned long long* mlist = scratch + (size_t)blockIdx.x * scratch_stride;
+  __shared__ V2Lds L_all[V2_WAVES_PER_WG];
+  V2Lds& L = L_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  unsigned long long* mlist = scratch + ((size_t)blockIdx.x * V2_WAVES_PER_WG + (threadIdx.x >> 6)) * scratch_stride;
   uint32_t dbg_rounds = 0, dbg_passes = 0;
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = 0;
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
           if (i < 144) l = 8; else if (i < 256) l = 9; else if (i < 280) l = 7; else if (i < 288) l = 8; else l = 5;
           L.b.lens[i] = l;
         }
-        __syncthreads();
+        V2_SYNC();
       } else {
         ub_refill(in, lane);
         const uint32_t hlit = ub_take(in, 5) + 257;
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         const uint32_t hclen = ub_take(in, 4) + 4;
         if (hlit > 286 || hdist > 30) { st = INF_BAD_CODE | (1u << 8); break; }
         if (lane < 20) L.b.pre_lens[lane] = 0;
-        __syncthreads();
+        V2_SYNC();
         {
           const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
           for (uint32_t i = 0; i < hclen; i++) {
@@ -612,9 +631,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
             if (lane == 0) L.b.pre_lens[order[i]] = (uint8_t)v;
           }
         }
-        __syncthreads();
+        V2_SYNC();
         for (int i = lane; i < 128; i += WAVE) L.b.pre_fast[i] = 0;
-        __syncthreads();
+        V2_SYNC();
         if (lane == 0) {
           uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           for (int s = 0; s < 19; s++) cnt[L.b.pre_lens[s]]++;
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
             for (uint32_t i = r; i < 128; i += (1u << l)) L.b.pre_fast[i] = (uint8_t)((s << 3) | l);
           }
         }
-        __syncthreads();
+        V2_SYNC();
         {
           const uint32_t total = hlit + hdist;
           uint32_t i = 0, prev = 0;
@@ -662,11 +681,11 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
           if (bad) { st = INF_BAD_CODE | (2u << 8); break; }
           for (uint32_t k = hlit + lane; k < 288; k += WAVE) L.b.lens[k] = 0;
           for (uint32_t k = 288 + hdist + lane; k < 320; k += WAVE) L.b.lens[k] = 0;
-          __syncthreads();
+          V2_SYNC();
         }
       }
-      if (v2_build(L, L.b.lens, 288, L.lit_fast, V2_LIT_BITS, V2_LIT_SUB, L.b.lit_sorted, L.b.lit_count, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
-      if (v2_build(L, L.b.lens + 288, 32, L.dist_fast, V2_DIST_BITS, V2_DIST_SUB, L.b.dist_sorted, L.b.dist_count, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
+      if (v2_build(L, L.b.lens, 288, L.lit_fast, 0u, V2_LIT_BITS, V2_LIT_SUB, L.b.lit_sorted, L.b.lit_count, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
+      if (v2_build(L, L.b.lens + 288, 32, L.dist_fast, (1u << V2_LIT_BITS) + V2_LIT_SUB, V2_DIST_BITS, V2_DIST_SUB, L.b.dist_sorted, L.b.dist_count, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
       P = ub_bitpos(in);
       TOCK(0);
 
@@ -682,9 +701,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
         const uint32_t subb = sub_dw * 32;
         const uint64_t wb = P >> 5;
         const uint32_t nstage = 64 * sub_dw + 6;
-        __syncthreads();
+        V2_SYNC();
         if (!V2_GLOBAL_INPUT) for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
-        __syncthreads();
+        V2_SYNC();
         TOCK(1);
         const uint32_t rel0 = (uint32_t)(P & 31);
         const uint32_t bnd = rel0 + (uint32_t)lane * subb;
@@ -784,8 +803,9 @@ __global__ __launch_bounds__(WAVE, 4) void k_bgzf_inflate_v2(const uint8_t* __re
 
 int v2_resident_wg_per_cu() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v2, WAVE, 0) != hipSuccess || n < 1) n = 8;
-  return n;
+  // resident WAVES per CU (= members decoded concurrently per CU)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v2, WAVE * V2_WAVES_PER_WG, 0) != hipSuccess || n < 1) n = 8;
+  return n * V2_WAVES_PER_WG;
 }
 static uint32_t g_v2_grid = 0;
 void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
@@ -800,7 +820,8 @@ void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const
   (void)g_v2_grid;
   hipMemsetAsync(counter, 0, 4, st);
   uint32_t g = grid < n_blocks ? grid : n_blocks;
-  hipLaunchKernelGGL(k_bgzf_inflate_v2, dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status, counter,
+  g = (g + V2_WAVES_PER_WG - 1) / V2_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V2_WAVES_PER_WG match lists
+  hipLaunchKernelGGL(k_bgzf_inflate_v2, dim3(g), dim3(WAVE * V2_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status, counter,
                      scratch, scratch_stride, dbg, ablate, dbg_block);
 }
 
