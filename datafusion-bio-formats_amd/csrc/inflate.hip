@@ -461,14 +461,22 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
   // slice-by-16: one 16-byte load per step, 16 table lookups of which only 4 depend on the running CRC
   const uint4* w = (const uint4*)p;
   const uint32_t nq = n >> 4;
-  for (uint32_t k = 0; k < nq; k++) {
-    const uint4 v = w[k];
-    const uint32_t a0 = c ^ v.x, a1 = v.y, a2 = v.z, a3 = v.w;
-    c = T[15][a0 & 0xFF] ^ T[14][(a0 >> 8) & 0xFF] ^ T[13][(a0 >> 16) & 0xFF] ^ T[12][a0 >> 24] ^
-        T[11][a1 & 0xFF] ^ T[10][(a1 >> 8) & 0xFF] ^ T[9][(a1 >> 16) & 0xFF] ^ T[8][a1 >> 24] ^
-        T[7][a2 & 0xFF] ^ T[6][(a2 >> 8) & 0xFF] ^ T[5][(a2 >> 16) & 0xFF] ^ T[4][a2 >> 24] ^
-        T[3][a3 & 0xFF] ^ T[2][(a3 >> 8) & 0xFF] ^ T[1][(a3 >> 16) & 0xFF] ^ T[0][a3 >> 24];
+#define CRC_STEP16(v) do { \
+    const uint32_t a0 = c ^ (v).x, a1 = (v).y, a2 = (v).z, a3 = (v).w; \
+    c = T[15][a0 & 0xFF] ^ T[14][(a0 >> 8) & 0xFF] ^ T[13][(a0 >> 16) & 0xFF] ^ T[12][a0 >> 24] ^ \
+        T[11][a1 & 0xFF] ^ T[10][(a1 >> 8) & 0xFF] ^ T[9][(a1 >> 16) & 0xFF] ^ T[8][a1 >> 24] ^ \
+        T[7][a2 & 0xFF] ^ T[6][(a2 >> 8) & 0xFF] ^ T[5][(a2 >> 16) & 0xFF] ^ T[4][a2 >> 24] ^ \
+        T[3][a3 & 0xFF] ^ T[2][(a3 >> 8) & 0xFF] ^ T[1][(a3 >> 16) & 0xFF] ^ T[0][a3 >> 24]; } while (0)
+  uint32_t k = 0;
+  // 128 bytes (one cache line of this lane's member) per outer step: the eight loads are issued together so the
+  // line is consumed by one fill instead of being re-requested across iterations (the 655 k lanes in flight thrash L1)
+  for (; k + 8 <= nq; k += 8) {
+    const uint4 v0 = w[k], v1 = w[k + 1], v2 = w[k + 2], v3 = w[k + 3], v4 = w[k + 4], v5 = w[k + 5], v6 = w[k + 6], v7 = w[k + 7];
+    CRC_STEP16(v0); CRC_STEP16(v1); CRC_STEP16(v2); CRC_STEP16(v3);
+    CRC_STEP16(v4); CRC_STEP16(v5); CRC_STEP16(v6); CRC_STEP16(v7);
   }
+  for (; k < nq; k++) { const uint4 v = w[k]; CRC_STEP16(v); }
+#undef CRC_STEP16
   p += (size_t)nq * 16;
   n &= 15;
   while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
