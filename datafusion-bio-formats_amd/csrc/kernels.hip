@@ -759,60 +759,73 @@ __global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __r
     if (k >= nrow) continue;
     const uint8_t* sp = u + spo;
     const uint8_t* qp = sp + ((lseq + 1) >> 1);
-    if (d_name && lrn > 1) {
-      const uint8_t* np = sp - 4ull * ncig - lrn;  // read_name starts 36 bytes into the record
-      uint8_t* o = d_name + ono;
-      const uint32_t l = lrn - 1;
-      for (uint32_t c = (uint32_t)sl * 16; c < l; c += 256) {
-        const uint32_t rem = l - c;
-        if (rem >= 16) *(u32x4u*)(o + c) = *(const u32x4u*)(np + c);
-        else for (uint32_t j = 0; j < rem; j++) o[c + j] = np[c + j];
+    // First 256 bytes of each segment: one 16-byte chunk per lane, all three loads issued before any store.  A
+    // partial last chunk is served by the (overlapping) 16 bytes that END at the segment's end, so no lane runs a
+    // byte loop unless the whole segment is shorter than 16 bytes.
+    const uint32_t c0 = (uint32_t)sl * 16;
+    const uint32_t ln = lrn ? lrn - 1 : 0;
+    const uint8_t* np = sp - 4ull * ncig - lrn;  // read_name starts 36 bytes into the record
+    const bool n_on = d_name && c0 < ln, s_on = d_seq && c0 < lseq, q_on = d_qual && c0 < lseq;
+    const uint32_t cn = (c0 + 16 <= ln || ln < 16) ? c0 : ln - 16;
+    const uint32_t cq = (c0 + 16 <= lseq || lseq < 16) ? c0 : lseq - 16;
+    const uint32_t cs = (c0 + 16 <= lseq || lseq < 16) ? c0 : ((lseq - 16) & ~1u);  // packed bytes start on even bases
+    const bool n_vec = n_on && ln >= 16, s_vec = s_on && lseq >= 16, q_vec = q_on && lseq >= 16;
+    u32x4u vn = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
+    uint64_t pk = 0;
+    if (n_vec) vn = *(const u32x4u*)(np + cn);
+    if (s_vec) pk = ((const u64u*)(sp + (cs >> 1)))->v;
+    if (q_vec) vq = *(const u32x4u*)(qp + cq);
+    if (n_vec) *(u32x4u*)(d_name + ono + cn) = vn;
+    else if (n_on) for (uint32_t j = c0; j < ln; j++) d_name[ono + j] = np[j];
+    if (s_vec) {
+      u32x4u v;
+      v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
+      v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
+      v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
+      v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
+      *(u32x4u*)(d_seq + oso + cs) = v;
+      // odd-length tail: the vector ended one base early
+      if (cs != c0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
+    } else if (s_on) {
+      for (uint32_t j = c0; j < lseq; j += 2) {
+        const uint16_t pr = s_pair[sp[j >> 1]];
+        d_seq[oso + j] = (uint8_t)pr;
+        if (j + 1 < lseq) d_seq[oso + j + 1] = (uint8_t)(pr >> 8);
       }
     }
-    if (d_seq) {
-      uint8_t* o = d_seq + oso;
-      for (uint32_t c = (uint32_t)sl * 16; c < lseq; c += 256) {
-        const uint32_t rem = lseq - c;
-        if (rem >= 16) {
-          const uint64_t pk = ((const u64u*)(sp + (c >> 1)))->v;  // 8 packed bytes -> 16 bases
-          u32x4u v;
-          v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
-          v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
-          v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
-          v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
-          *(u32x4u*)(o + c) = v;
-        } else {
-          for (uint32_t j = 0; j < rem; j += 2) {
-            const uint16_t pr = s_pair[sp[(c + j) >> 1]];
-            o[c + j] = (uint8_t)pr;
-            if (j + 1 < rem) o[c + j + 1] = (uint8_t)(pr >> 8);
-          }
-        }
+    if (q_vec) {
+      vq.x = qual_swar(vq.x); vq.y = qual_swar(vq.y); vq.z = qual_swar(vq.z); vq.w = qual_swar(vq.w);
+      wide = wide || ((vq.x | vq.y | vq.z | vq.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
+      *(u32x4u*)(d_qual + oqo + cq) = vq;
+    } else if (q_on) {
+      for (uint32_t j = c0; j < lseq; j++) {
+        const uint32_t q = ((uint32_t)qp[j] + 33u) & 0xFFu;
+        wide = wide || q >= 128u;
+        d_qual[oqo + j] = (uint8_t)q;
       }
     }
-    if (d_qual) {
-      uint8_t* o = d_qual + oqo;
-      for (uint32_t c = (uint32_t)sl * 16; c < lseq; c += 256) {
-        const uint32_t rem = lseq - c;
-        if (rem >= 16) {
-          u32x4u v = *(const u32x4u*)(qp + c);
-          v.x = qual_swar(v.x); v.y = qual_swar(v.y); v.z = qual_swar(v.z); v.w = qual_swar(v.w);
-          wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
-          *(u32x4u*)(o + c) = v;
-        } else {
-          uint32_t j = 0;
-          for (; j + 4 <= rem; j += 4) {
-            const uint32_t res = qual_swar(((const u32u*)(qp + c + j))->v);
-            wide = wide || (res & 0x80808080u);
-            ((u32u*)(o + c + j))->v = res;
-          }
-          for (; j < rem; j++) {
-            const uint32_t q = ((uint32_t)qp[c + j] + 33u) & 0xFFu;
-            wide = wide || q >= 128u;
-            o[c + j] = (uint8_t)q;
-          }
-        }
-      }
+    // rows longer than 256 bytes per segment (long reads): remaining chunks, same scheme
+    if (d_name) for (uint32_t c = c0 + 256; c < ln; c += 256) {
+      const uint32_t cc = c + 16 <= ln ? c : ln - 16;
+      *(u32x4u*)(d_name + ono + cc) = *(const u32x4u*)(np + cc);
+    }
+    if (d_seq) for (uint32_t c = c0 + 256; c < lseq; c += 256) {
+      const uint32_t cc = c + 16 <= lseq ? c : ((lseq - 16) & ~1u);
+      const uint64_t p2 = ((const u64u*)(sp + (cc >> 1)))->v;
+      u32x4u v;
+      v.x = (uint32_t)s_pair[p2 & 0xFF] | ((uint32_t)s_pair[(p2 >> 8) & 0xFF] << 16);
+      v.y = (uint32_t)s_pair[(p2 >> 16) & 0xFF] | ((uint32_t)s_pair[(p2 >> 24) & 0xFF] << 16);
+      v.z = (uint32_t)s_pair[(p2 >> 32) & 0xFF] | ((uint32_t)s_pair[(p2 >> 40) & 0xFF] << 16);
+      v.w = (uint32_t)s_pair[(p2 >> 48) & 0xFF] | ((uint32_t)s_pair[(p2 >> 56) & 0xFF] << 16);
+      *(u32x4u*)(d_seq + oso + cc) = v;
+      if (cc != c && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
+    }
+    if (d_qual) for (uint32_t c = c0 + 256; c < lseq; c += 256) {
+      const uint32_t cc = c + 16 <= lseq ? c : lseq - 16;
+      u32x4u v = *(const u32x4u*)(qp + cc);
+      v.x = qual_swar(v.x); v.y = qual_swar(v.y); v.z = qual_swar(v.z); v.w = qual_swar(v.w);
+      wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);
+      *(u32x4u*)(d_qual + oqo + cc) = v;
     }
   }
   if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
