@@ -55,3 +55,46 @@ def test_two_rank_sharded_scan():
     assert m0 + m1 == list(range(len(m0) + len(m1))) and m0 and m1   # contiguous runs, rank order = partition order
     assert n0 + n1 == 4277 and c0 == c1 == 4277.0
     assert t0 == t1 == 2.0
+
+
+def _vcf_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from conftest import load_pkg
+    import vcf_oracle
+    pkg = load_pkg()
+    o = vcf_oracle.VcfOracle(os.path.join(ROOT, "tests", "golden", "multi_chrom_large.vcf.gz"))
+    plan = o.scan(target_partitions=5)                       # TBI chunk ranges -> 5 balanced partitions
+    mine = pkg.shard_partitions_in_order([a.total_estimated_bytes for a in plan["assignments"]], world)[rank]
+    starts = []
+    for p in mine:
+        _, bs = o.execute(plan, p, 8192)
+        for x in bs:
+            starts += list(zip(x.column("chrom").to_pylist(), x.column("start").to_pylist()))
+    c = torch.tensor([float(len(starts))], dtype=torch.float64)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    q.put((rank, mine, starts, float(c.item())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_vcf_scan():
+    """VCF: TBI partitions shard across ranks with no exchange; rank-order concatenation = single-rank row order."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_vcf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    (r0, m0, s0, c0), (r1, m1, s1, c1) = out
+    assert m0 + m1 == list(range(len(m0) + len(m1))) and m0 and m1
+    assert c0 == c1 == 10000.0
+    rows = s0 + s1
+    assert len(set(rows)) == 10000 and rows == sorted(rows, key=lambda t: (t[0], t[1]))
