@@ -955,7 +955,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       col.d_values.alloc(std::max<uint64_t>(tot, 1));
       col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
       launch_batch_offsets(col.d_off64.p, n, batch_size, col.d_off32.p, st);
-      launch_scatter_ranges(u, srcs[k].p, n, col.d_off64.p, col.d_values.p, st);
+      launch_scatter_ranges(u, srcs[k].p, n, col.d_off64.p, col.d_values.p, tot, st);
       arrow_bytes += tot + nb * ((uint64_t)batch_size + 1) * 4;
       col.d_len.reset();
     }

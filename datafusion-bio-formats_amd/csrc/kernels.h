@@ -159,6 +159,8 @@ void launch_fastq_fields(const uint8_t* u, uint64_t x0, uint64_t eof, const uint
                          FastqCols c, uint32_t* err, hipStream_t st);
 void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
                               unsigned long long* result, hipStream_t st);
-void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
+// total_bytes = off64[n] (the caller has just read it): the average row length picks the kernel shape
+void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
+                           hipStream_t st);
 
 }  // namespace bioscan

@@ -285,7 +285,7 @@ static void finish_utf8(Ctx& c, VNode& nd, const uint64_t* src, const uint32_t* 
   nd.d_off.alloc(N + 1);
   nd.total = c.scan(len, nd.d_off.p, N);
   nd.d_values.alloc(std::max<uint64_t>(nd.total, 1));
-  launch_scatter_ranges(c.u, src, N, nd.d_off.p, nd.d_values.p, c.st);
+  launch_scatter_ranges(c.u, src, N, nd.d_off.p, nd.d_values.p, nd.total, c.st);
   c.arrow_bytes += nd.total + (N + 1) * 4;
 }
 
