@@ -313,11 +313,28 @@ std::vector<std::pair<uint64_t, uint64_t>> bai_query_chunks(const Bai& bai, size
     auto it = ref.bins.find(b);
     if (it != ref.bins.end()) chunks.insert(chunks.end(), it->second.begin(), it->second.end());
   };
-  add(0);
   const int shifts[5] = {26, 23, 20, 17, 14};
   const uint32_t bases[5] = {1, 9, 73, 585, 4681};
-  for (int l = 0; l < 5; l++)
-    for (uint64_t b = bases[l] + (beg0 >> shifts[l]); b <= bases[l] + (end0 >> shifts[l]); b++) add((uint32_t)b);
+  uint64_t n_candidates = 1;
+  for (int l = 0; l < 5; l++) n_candidates += (end0 >> shifts[l]) - (beg0 >> shifts[l]) + 1;
+  if (n_candidates > 4 * ref.bins.size() + 16) {
+    // wide interval: walk the bins that exist (same set, same order: std::map iterates bin ids ascending,
+    // reg2bins enumerates level by level in ascending id) instead of probing tens of thousands of ids
+    for (auto& kv : ref.bins) {
+      const uint32_t b = kv.first;
+      bool hit = b == 0;
+      for (int l = 0; l < 5 && !hit; l++) {
+        const uint64_t lo = bases[l] + (beg0 >> shifts[l]), hi = bases[l] + (end0 >> shifts[l]);
+        const uint64_t next_base = l < 4 ? bases[l + 1] : 37449;
+        if (b >= bases[l] && b < next_base) { hit = b >= lo && b <= hi; break; }
+      }
+      if (hit) chunks.insert(chunks.end(), kv.second.begin(), kv.second.end());
+    }
+  } else {
+    add(0);
+    for (int l = 0; l < 5; l++)
+      for (uint64_t b = bases[l] + (beg0 >> shifts[l]); b <= bases[l] + (end0 >> shifts[l]); b++) add((uint32_t)b);
+  }
   size_t li = (size_t)(beg0 >> 14);
   uint64_t min_off = li < ref.intervals.size() ? ref.intervals[li] : 0;
   std::vector<std::pair<uint64_t, uint64_t>> f;

@@ -33,7 +33,7 @@ namespace bioscan {
 static std::mutex g_pool_mu;
 static std::multimap<size_t, void*> g_pool;
 static size_t g_pool_bytes = 0;
-constexpr size_t POOL_MIN = 1u << 20;
+constexpr size_t POOL_MIN = 1;  // every block is cached: hipFree of even a tiny block synchronises the device
 void* dev_pool_alloc(size_t bytes) {
   if (bytes >= POOL_MIN) {
     std::lock_guard<std::mutex> lk(g_pool_mu);

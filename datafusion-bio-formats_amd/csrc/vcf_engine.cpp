@@ -539,6 +539,10 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
   if (batch_size_in <= 0) throw Error("batch_size must be positive");
   std::lock_guard<std::mutex> lk(p.mu);
   const auto wall0 = std::chrono::steady_clock::now();
+  const bool dbg_wall = getenv("BIOSCAN_LAPS") != nullptr;
+  auto lap = [&](const char* what) {
+    if (dbg_wall) fprintf(stderr, "[bioscan] vcf execute: %-22s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+  };
   p.make_resident();
   p.set_device();
   hipStream_t st = p.stream;
@@ -587,9 +591,11 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
   }
   if (lo_abs >= p.text_len()) nothing = true;
 
+  lap("planning done");
   Timer t(st);
   DevBuf<uint32_t> err(1);
   HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
+  lap("timer+err ready");
   DevBuf<uint64_t> nl, nl_tabs, tab, base_nl, base_tab, scan_tmp;
   DevBuf<uint32_t> cnt_nl, cnt_tab;
   DevBuf<uint32_t> k_pos, k_vend;
@@ -613,11 +619,15 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
         if (p.d_u.n < bytes + 64) p.d_u.alloc(bytes + 64);
         t.start();
         p.launch_inflate(p.d_u.p, b_hi - b_lo, b_lo);
+        lap("inflate launched");
         res->stats.ms_inflate += t.stop();
+        lap("inflate done");
         t.start();
         p.launch_crc(p.d_u.p, b_hi - b_lo, b_lo);
         res->stats.ms_crc += t.stop();
+        lap("inflate+crc done");
         p.check_inflate_status(b_lo, b_hi - b_lo);
+        lap("status checked");
         u = p.d_u.p;
         res->stats.n_blocks = b_hi - b_lo;
         res->stats.compressed_bytes = p.blk_coff[b_hi] - p.blk_coff[b_lo];
@@ -670,6 +680,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       for (int s : col_src) if (s == 2) want_end = true;
       launch_vcf_keys(u, L, k_pos.p, k_vend.p, k_flags.p, want_end ? 1 : 0, err.p, st);
       res->stats.ms_chain += t.stop();
+      lap("index+keys done");
       break;
     }
     res->stats.n_records = L.n_lines;
@@ -812,6 +823,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       HIP_CHECK(hipStreamSynchronize(st));
     }
     res->stats.ms_select = t.stop();
+    lap("select done");
   }
   res->n_rows = n;
   res->stats.n_rows = n;
@@ -913,7 +925,9 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       DevBuf<uint64_t> sp_off((uint64_t)S * N);
       DevBuf<uint32_t> sp_len((uint64_t)S * N);
       DevBuf<uint8_t> sp_state((uint64_t)S * N);
-      launch_vcf_format_cells(u, L, rows.p, n, d_scol.p, (int)ns, fpos.p, S, gt_field, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+      // shape of the output nodes first: scalar Int32 / Float32 keys are parsed inside the cell kernel straight into
+      // their value buffers; strings and lists go through spans
+      std::vector<VNode*> leaf((size_t)S);
       if (geno_col >= 0) {
         VNode& g = res->cols[geno_col];
         g.kids.resize((size_t)S);
@@ -926,14 +940,46 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
           launch_stride_offsets(lst.d_off.p, n, ns, st);
           lst.kids.resize(1);
           lst.kids[0].fd = lst.fd.children.at(0);
-          build_from_spans(cx, lst.kids[0], sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
+          leaf[s] = &lst.kids[0];
           cx.arrow_bytes += (n + 1) * 4;
         }
       } else {
-        for (int s = 0; s < S; s++) {
-          VNode& nd = res->cols[fmt_cols[s].first];
-          build_from_spans(cx, nd, sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
+        for (int s = 0; s < S; s++) leaf[s] = &res->cols[fmt_cols[s].first];
+      }
+      VcfCellDirect D{};
+      const uint64_t nwN = (N + 63) / 64;
+      DevBuf<uint64_t> gt_src;
+      DevBuf<uint32_t> gt_len;
+      for (int s = 0; s < S && s < VCF_MAX_DIRECT; s++) {
+        VNode& nd = *leaf[s];
+        if (s == gt_field && nd.fd.kind == VK_UTF8) {   // GT: length + source + validity straight from the cell kernel
+          nd.n = N;
+          nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
+          nd.all_valid = false;
+          gt_src.alloc(std::max<uint64_t>(N, 1));
+          gt_len.alloc(std::max<uint64_t>(N, 1));
+          D.kind[s] = 3;
+          D.values[s] = gt_len.p;
+          D.src[s] = gt_src.p;
+          D.valid[s] = nd.d_valid.p;
+          cx.arrow_bytes += nwN * 8;
+          continue;
         }
+        if (nd.fd.kind != VK_INT32 && nd.fd.kind != VK_FLOAT32) continue;
+        nd.n = N;
+        nd.d_values.alloc(std::max<uint64_t>(N, 1) * 4);
+        nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
+        nd.all_valid = false;
+        D.kind[s] = nd.fd.kind == VK_INT32 ? 1 : 2;
+        D.values[s] = (uint32_t*)nd.d_values.p;
+        D.valid[s] = nd.d_valid.p;
+        cx.arrow_bytes += N * 4 + nwN * 8;
+      }
+      launch_vcf_format_cells(u, L, rows.p, n, d_scol.p, (int)ns, fpos.p, S, gt_field, D, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+      for (int s = 0; s < S; s++) {
+        if (s < VCF_MAX_DIRECT && D.kind[s] == 3) { finish_utf8(cx, *leaf[s], gt_src.p, gt_len.p, N); continue; }
+        if (s < VCF_MAX_DIRECT && D.kind[s] != 0) continue;
+        build_from_spans(cx, *leaf[s], sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
       }
       HIP_CHECK(hipStreamSynchronize(st));
     }
@@ -954,6 +1000,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
     for (auto& col : res->cols) shape(col);
   }
   res->stats.ms_extract = t.stop();
+  lap("extract done");
   res->stats.arrow_bytes = cx.arrow_bytes;
   res->stats.ms_total_gpu = res->stats.ms_inflate + res->stats.ms_crc + res->stats.ms_chain + res->stats.ms_select + res->stats.ms_extract;
   res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -963,6 +1010,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
     for (auto& col : res->cols) free_node_device(col);
     res->on_host = true;
   }
+  lap("end");
   if (stats_out) *stats_out = res->stats;
   auto* s = new VcfStream();
   s->res = res;

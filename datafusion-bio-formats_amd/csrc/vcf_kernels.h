@@ -89,9 +89,19 @@ void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream
 
 void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
                             int S, int16_t* fpos, hipStream_t st);
+// FORMAT keys parsed inside the cell kernel: kind 1 Int32 / 2 Float32 -> values[s][c] + validity words valid[s];
+// kind 3 GT -> values[s][c] = rendered length, src[s][c] = its first byte (offset into u) + validity; kind 0 = emit
+// a span for the typed span kernels (other strings, lists).  Only the first VCF_MAX_DIRECT selected keys can be direct.
+constexpr int VCF_MAX_DIRECT = 8;
+struct VcfCellDirect {
+  int32_t kind[VCF_MAX_DIRECT];
+  uint32_t* values[VCF_MAX_DIRECT];
+  uint64_t* valid[VCF_MAX_DIRECT];
+  uint64_t* src[VCF_MAX_DIRECT];
+};
 void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
-                             const int16_t* fpos, int S, int gt_field, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state,
-                             uint32_t* err, hipStream_t st);
+                             const int16_t* fpos, int S, int gt_field, VcfCellDirect D, uint64_t* sp_off, uint32_t* sp_len,
+                             uint8_t* sp_state, uint32_t* err, hipStream_t st);
 
 // list UDFs: off = u64 list offsets (n+1), values = 32-bit elements, evalid / lvalid = validity words or nullptr
 void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t* evalid, const uint64_t* lvalid, uint64_t n,

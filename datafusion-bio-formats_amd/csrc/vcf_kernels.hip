@@ -793,63 +793,133 @@ void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, 
 // a leading phasing character and is validated (alleles are digits or '.', separators '/' or '|').
 __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
                                                            uint64_t n, const int32_t* __restrict__ sample_col, int NS,
-                                                           const int16_t* __restrict__ fpos, int S, int gt_field,
+                                                           const int16_t* __restrict__ fpos, int S, int gt_field, VcfCellDirect D,
                                                            uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
                                                            uint8_t* __restrict__ sp_state, uint32_t* __restrict__ err) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t N = n * (uint64_t)NS;
-  if (c >= N) return;
-  const uint64_t r = c / NS;
+  const bool act = c < N;
+  // 32-bit division when the cell index fits (64-bit division is emulated with ~100 instructions)
+  const uint64_t r = !act ? 0 : (N <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)c / (uint32_t)NS) : c / NS);
   const int os = (int)(c - r * NS);
-  for (int s = 0; s < S; s++) sp_state[(uint64_t)s * N + c] = 0;
-  uint64_t a, b;
-  if (!field_span(L, u, rows[r], 9 + (uint32_t)sample_col[os], &a, &b)) return;
-  if (b == a || (b - a == 1 && u[a] == '.')) return;
-  int j = 0;
-  uint64_t q = a;
-  while (q <= b) {
-    uint64_t e = q;
-    while (e < b && u[e] != ':') e++;
-    for (int s = 0; s < S; s++) {
-      if (fpos[r * S + s] == j) {
-        const uint64_t o = (uint64_t)s * N + c;
-        uint64_t x = q;
-        if (s == gt_field && !(e - q == 1 && u[q] == '.')) {
-          if (x < e && (u[x] == '/' || u[x] == '|')) x++;
-          bool ok = x < e, isdot = false, lead0 = false;
-          uint32_t tl = 0;
-          for (uint64_t k = x; k <= e && ok; k++) {
-            const uint8_t ch = k < e ? u[k] : '/';
-            if (ch == '/' || ch == '|') {
-              if (tl == 0 || (!isdot && lead0 && tl > 1)) ok = false;
-              tl = 0; isdot = false; lead0 = false;
-            } else if (ch == '.') {
-              if (tl) ok = false;
-              isdot = true; tl = 1;
-            } else if (ch >= '0' && ch <= '9') {
-              if (isdot) ok = false;
-              if (tl == 0) lead0 = ch == '0';
-              tl++;
-            } else ok = false;
-          }
-          if (!ok) set_err(err, VERR_BAD_GT);
-        }
-        sp_state[o] = 1;
-        sp_off[o] = x;
-        sp_len[o] = (uint32_t)(e - x);
+  uint32_t dval[VCF_MAX_DIRECT];   // direct Int32 / Float32 value, or the length of a direct string
+  uint32_t dsrc[VCF_MAX_DIRECT];   // direct string: start relative to the cell
+  uint32_t dok = 0;                // bit s: direct field s has a value
+#pragma unroll
+  for (int s = 0; s < VCF_MAX_DIRECT; s++) { dval[s] = 0; dsrc[s] = 0; }
+  uint64_t a = 0, b = 0;
+  if (act) {
+    for (int s = 0; s < S; s++) if (s >= VCF_MAX_DIRECT || D.kind[s] == 0) sp_state[(uint64_t)s * N + c] = 0;
+    bool have = field_span(L, u, rows[r], 9 + (uint32_t)sample_col[os], &a, &b);
+    const uint32_t len = have ? (uint32_t)(b - a) : 0;
+    // the first 16 bytes of the cell travel in registers (one unaligned 16-byte load; the text buffer has slack)
+    uint64_t w_lo = 0, w_hi = 0;
+    if (len) { w_lo = ((const dl_u64*)(u + a))->v; w_hi = ((const dl_u64*)(u + a + 8))->v; }
+    auto byte_at = [&](uint32_t k) -> uint32_t {
+      if (k < 8) return (uint32_t)(w_lo >> (8 * k)) & 0xFFu;
+      if (k < 16) return (uint32_t)(w_hi >> (8 * (k - 8))) & 0xFFu;
+      return u[a + k];
+    };
+    if (len == 1 && byte_at(0) == '.') have = false;
+    // one forward pass: sub-field j belongs to selected key `cur` (-1: not selected).  The row's key positions are
+    // fetched once (independent loads) and packed into a nibble map, so the byte loop touches no memory.
+    uint64_t jmap = 0;   // nibble j = selected key index + 1
+    uint32_t kmap = 0;   // 2 bits per selected key: its direct kind
+#pragma unroll
+    for (int s = 0; s < VCF_MAX_DIRECT; s++) {
+      if (s < S) {
+        const int fp = fpos[r * S + s];
+        if (fp >= 0 && fp < 16 && ((jmap >> (4 * fp)) & 15ull) == 0) jmap |= (uint64_t)(s + 1) << (4 * fp);
+        kmap |= (uint32_t)D.kind[s] << (2 * s);
       }
     }
-    j++;
-    q = e + 1;
+    int j = 0, cur = -1, ckind = 0;
+    auto select = [&]() {
+      cur = -1; ckind = 0;
+      if (j < 16) cur = (int)((jmap >> (4 * j)) & 15ull) - 1;
+      if (S > VCF_MAX_DIRECT || j >= 16) {   // rare: more selected keys / sub-fields than the map holds
+        for (int s = 0; s < S; s++) if (fpos[r * S + s] == j) { cur = s; break; }
+      }
+      if (cur >= 0 && cur < VCF_MAX_DIRECT) ckind = (int)((kmap >> (2 * cur)) & 3u);
+    };
+    if (have && len) select();
+    uint32_t start = 0, ndig = 0, tl = 0;
+    int64_t acc = 0;
+    bool neg = false, bad = false, isdot = false, lead0 = false, gt_ok = true;
+    for (uint32_t k = 0; have && k <= len; k++) {
+      const uint32_t ch = k < len ? byte_at(k) : (uint32_t)':';
+      if (ch == ':') {
+        const uint32_t sl = k - start;
+        const bool missing = sl == 1 && byte_at(start) == '.';
+        if (cur >= 0 && !missing) {
+          if (ckind == 1) {           // Int32: [+-]?digits
+            if (bad || ndig == 0 || (neg ? acc > 2147483648ll : acc > 2147483647ll)) set_err(err, VERR_BAD_INT);
+            else {
+              const uint32_t v = (uint32_t)(int32_t)(neg ? -acc : acc);
+#pragma unroll
+              for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = v; dok |= 1u << s; }
+            }
+          } else if (ckind == 2) {    // Float32: correctly rounded parse of the span
+            float f;
+            const int rc = parse_f32_text(u + a + start, sl, &f);
+            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT);
+            else {
+#pragma unroll
+              for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = __float_as_uint(f); dok |= 1u << s; }
+            }
+          } else if (ckind == 3) {    // GT as a direct string: validated on the fly, leading phasing mark dropped
+            uint32_t x = start;
+            const uint32_t c0 = byte_at(start);
+            if (c0 == '/' || c0 == '|') x++;
+            if (!gt_ok || tl == 0 || (!isdot && lead0 && tl > 1) || x >= k) set_err(err, VERR_BAD_GT);
+#pragma unroll
+            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = k - x; dsrc[s] = x; dok |= 1u << s; }
+          } else {                    // span for the typed span kernels (strings, lists)
+            const uint64_t o = (uint64_t)cur * N + c;
+            sp_state[o] = 1;
+            sp_off[o] = a + start;
+            sp_len[o] = sl;
+          }
+        }
+        j++;
+        start = k + 1;
+        if (k < len) select();
+        acc = 0; ndig = 0; neg = false; bad = false; tl = 0; isdot = false; lead0 = false; gt_ok = true;
+      } else if (cur >= 0) {
+        if (ckind == 1) {
+          const uint32_t dgt = ch - '0';
+          if (dgt <= 9) { if (acc < 100000000000ll) acc = acc * 10 + dgt; ndig++; }
+          else if ((ch == '-' || ch == '+') && k == start) neg = ch == '-';
+          else bad = true;
+        } else if (ckind == 3) {
+          if (ch == '/' || ch == '|') {
+            if (k != start) { if (tl == 0 || (!isdot && lead0 && tl > 1)) gt_ok = false; tl = 0; isdot = false; lead0 = false; }
+          } else if (ch == '.') { if (tl) gt_ok = false; isdot = true; tl = 1; }
+          else if (ch >= '0' && ch <= '9') { if (isdot) gt_ok = false; if (tl == 0) lead0 = ch == '0'; tl++; }
+          else gt_ok = false;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < VCF_MAX_DIRECT; s++) {
+    if (s < S && D.kind[s] != 0) {   // wave-uniform
+      if (act) {
+        D.values[s][c] = dval[s];
+        if (D.kind[s] == 3) D.src[s][c] = a + dsrc[s];
+      }
+      const unsigned long long m = __ballot((dok >> s) & 1u);
+      if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) D.valid[s][c >> 6] = m;
+    }
   }
 }
 void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
-                             const int16_t* fpos, int S, int gt_field, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state,
-                             uint32_t* err, hipStream_t st) {
+                             const int16_t* fpos, int S, int gt_field, VcfCellDirect D, uint64_t* sp_off, uint32_t* sp_len,
+                             uint8_t* sp_state, uint32_t* err, hipStream_t st) {
   const uint64_t N = n * (uint64_t)NS;
   if (!N || !S) return;
   hipLaunchKernelGGL(k_vcf_format_cells, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, L, rows, n, sample_col, NS, fpos, S,
-                     gt_field, sp_off, sp_len, sp_state, err);
+                     gt_field, D, sp_off, sp_len, sp_state, err);
 }
 
 // ---- list UDFs (udfs.rs) ------------------------------------------------------------------------------------
