@@ -75,6 +75,7 @@ struct V2Build {
 struct __attribute__((aligned(16))) V2Lds {
   uint16_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];
   uint16_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // must follow lit_fast: the decode loop indexes both as one array
+  uint32_t be_lut[64];  // [0..31] length symbols 257.., [32..63] distance symbols: base | extra bits << 16 | invalid << 24
   uint32_t stage[V2_STAGE_DW];
 #ifdef V2_PAD_LDS
   uint32_t pad_lds[V2_PAD_LDS / 4];  // occupancy experiment only
@@ -329,12 +330,11 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     const bool is_eob = sym && in_lit && sv == 256u;
     const bool is_lit = sym && in_lit && sv < 256u;
     const bool is_dist = sym && !in_lit;
-    uint32_t lbase, leb, dbase, deb;
-    len_base_extra(sv - 257u, &lbase, &leb);
-    dist_base_extra(sv, &dbase, &deb);
-    const bool inval = in_lit ? (is_len && sv > 285u) : (is_dist && sv > 29u);  // symbols 286/287, 30/31 never occur in valid data
-    const uint32_t ebv = (is_len || is_dist) && !inval ? (in_lit ? leb : deb) : 0u;
-    const uint32_t base = in_lit ? lbase : dbase;
+    // base | extra bits << 16 | invalid << 24 of the length (sv - 257) or distance (sv) symbol: one LDS read
+    const uint32_t be = L.be_lut[in_lit ? ((sv - 257u) & 31u) : (32u + (sv & 31u))];
+    const bool inval = (is_len || is_dist) && (be >> 24) != 0;  // symbols 286/287, 30/31 never occur in valid data
+    const uint32_t ebv = (is_len || is_dist) && !inval ? ((be >> 16) & 15u) : 0u;
+    const uint32_t base = be & 0xFFFFu;
     const uint32_t extra = (uint32_t)(bb >> l) & ((1u << ebv) - 1u);
     const uint32_t adv = sym ? l + ebv : 0u;
     bb >>= adv; bc -= (int)adv; pos += adv;
@@ -556,6 +556,14 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
   unsigned long long t0 = 0;
 #define TICK() (t0 = dbg ? clock64() : 0)
 #define TOCK(i) do { if (dbg) { unsigned long long t1 = clock64(); tc[i] += t1 - t0; t0 = t1; } } while (0)
+
+  // base / extra-bit LUT of the length and distance symbols (RFC 1951 3.2.5), once per wave
+  {
+    uint32_t base, eb;
+    if (lane < 32) { len_base_extra((uint32_t)lane, &base, &eb); L.be_lut[lane] = lane > 28 ? (1u << 24) : (base | (eb << 16)); }
+    else { dist_base_extra((uint32_t)lane - 32u, &base, &eb); L.be_lut[lane] = lane - 32 > 29 ? (1u << 24) : (base | (eb << 16)); }
+  }
+  V2_SYNC();
 
   for (;;) {
     uint32_t b = 0;
