@@ -102,6 +102,7 @@ void BgzfSource::make_resident() {
     d_v2_scratch.alloc(((size_t)v2_grid + 8) * V2_SCRATCH_STRIDE);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
+  file.reset();  // the compressed bytes now live in HBM; the host image is not read again
   resident = true;
 }
 

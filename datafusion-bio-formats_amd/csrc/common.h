@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdexcept>
 #include <string>
 
@@ -86,26 +87,32 @@ struct DevBuf {
   size_t bytes() const { return n * sizeof(T); }
 };
 
-// pinned host buffer
+// host buffer: pinned when the driver grants it, pageable otherwise (8 ranks pinning 16 GB each can exceed the
+// node's locked-memory budget; a pageable source only makes the one-off upload slower)
 struct HostBuf {
   uint8_t* p = nullptr;
   size_t n = 0;
+  bool pinned = false;
   HostBuf() = default;
   HostBuf(const HostBuf&) = delete;
   HostBuf& operator=(const HostBuf&) = delete;
-  HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n), pinned(o.pinned) { o.p = nullptr; o.n = 0; }
   HostBuf& operator=(HostBuf&& o) noexcept {
-    if (this != &o) { reset(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { reset(); p = o.p; n = o.n; pinned = o.pinned; o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~HostBuf() { reset(); }
   void alloc(size_t bytes) {
     reset();
     n = bytes;
-    HIP_CHECK(hipHostMalloc((void**)&p, bytes ? bytes : 1, hipHostMallocDefault));
+    if (hipHostMalloc((void**)&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess) { pinned = true; return; }
+    (void)hipGetLastError();
+    p = (uint8_t*)malloc(bytes ? bytes : 1);
+    pinned = false;
+    if (!p) throw Error("out of host memory");
   }
   void reset() {
-    if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+    if (p) { if (pinned) (void)hipHostFree(p); else free(p); p = nullptr; n = 0; }
   }
 };
 
