@@ -13,11 +13,13 @@ namespace bioscan {
 
 #define WAVE 64
 
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) {
-  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
+// BAM fields sit at arbitrary byte alignment: one unaligned dword / word load each (gfx950 global loads need no
+// alignment) instead of four byte loads
+struct __attribute__((packed, aligned(1))) ld_u32_t { uint32_t v; };
+struct __attribute__((packed, aligned(1))) ld_u16_t { uint16_t v; };
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t* p) { return ((const ld_u32_t*)p)->v; }
 __device__ __forceinline__ int32_t ld_i32(const uint8_t* p) { return (int32_t)ld_u32(p); }
-__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)((const ld_u16_t*)p)->v; }
 
 // =================================================================================================
 // exclusive scan u32 -> u64 (three-kernel, 2048 elements per block)
