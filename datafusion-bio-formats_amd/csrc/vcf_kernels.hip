@@ -21,6 +21,7 @@ constexpr int WAVE = 64;
 constexpr int DL_CHUNK = 16384;
 constexpr int DL_PER_THREAD = 64;
 struct __attribute__((packed, aligned(1))) dl_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) dl_u32 { uint32_t v; };
 
 // bit 8k+7 of the result is set iff byte k of w equals c (c replicated in `pat`)
 __device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t pat) {
@@ -323,20 +324,28 @@ __global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u,
   if (need_end) {
     uint64_t ia, ib;
     field_span(L, u, i, 7, &ia, &ib);
-    uint64_t q = ia;
-    while (q + 4 <= ib) {
-      if (u[q] == 'E' && u[q + 1] == 'N' && u[q + 2] == 'D' && u[q + 3] == '=') {
-        uint64_t v0 = q + 4, v1 = v0;
-        while (v1 < ib && u[v1] != ';') v1++;
-        int32_t ev;
-        if (!(v1 - v0 == 1 && u[v0] == '.')) {
-          if (parse_i32_text(u + v0, (uint32_t)(v1 - v0), &ev) || ev <= 0) set_err(err, VERR_BAD_END);
-          else ve = (uint32_t)ev;
-        }
-        break;
+    // entry starts = the field start and every byte after a ';': the ';' are found eight bytes at a time, only the
+    // four bytes at an entry start are compared with "END="
+    const uint32_t END_EQ = 0x3D444E45u;  // "END=" little endian
+    uint64_t hit = ~0ull;
+    if (ia + 4 <= ib && ((const dl_u32*)(u + ia))->v == END_EQ) hit = ia;
+    for (uint64_t q = ia; hit == ~0ull && q < ib; q += 8) {
+      uint64_t m = eq_mask8(((const dl_u64*)(u + q))->v, 0x3B3B3B3B3B3B3B3Bull);  // ';' (reads past ib stay inside the buffer slack)
+      while (m) {
+        const uint64_t pq = q + (uint64_t)(__builtin_ctzll(m) >> 3) + 1;
+        m &= m - 1;
+        if (pq + 4 <= ib && ((const dl_u32*)(u + pq))->v == END_EQ) { hit = pq; break; }
       }
-      while (q < ib && u[q] != ';') q++;
-      q++;
+    }
+    if (hit != ~0ull) {
+      const uint64_t v0 = hit + 4;
+      uint64_t v1 = v0;
+      while (v1 < ib && u[v1] != ';') v1++;
+      int32_t ev;
+      if (!(v1 - v0 == 1 && u[v0] == '.')) {
+        if (parse_i32_text(u + v0, (uint32_t)(v1 - v0), &ev) || ev <= 0) set_err(err, VERR_BAD_END);
+        else ve = (uint32_t)ev;
+      }
     }
   }
   vend[i] = ve;
@@ -552,13 +561,13 @@ __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restri
   uint64_t a, b;
   field_span(L, u, i, 7, &a, &b);
   if (b - a == 1 && u[a] == '.') return;
-  uint64_t q = a;
-  while (q < b) {
-    uint64_t ke = q;
-    while (ke < b && u[ke] != '=' && u[ke] != ';') ke++;
-    uint64_t ve = ke;
-    const bool has_val = ke < b && u[ke] == '=';
-    if (has_val) { ve = ke + 1; while (ve < b && u[ve] != ';') ve++; }
+  // delimiter events (';' and '=') are taken eight bytes at a time; an entry is [q, next ';'), its key ends at the
+  // first '=' inside it
+  uint64_t q = a;        // current entry start
+  uint64_t eqp = ~0ull;  // first '=' of the current entry
+  auto finish = [&](uint64_t ve) {
+    const bool has_val = eqp != ~0ull;
+    const uint64_t ke = has_val ? eqp : ve;
     const uint32_t kl = (uint32_t)(ke - q);
     if (kl) {
       for (int k = 0; k < K; k++) {
@@ -573,8 +582,20 @@ __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restri
         }
       }
     }
-    q = ve + 1;
+  };
+  for (uint64_t w0 = a; w0 < b; w0 += 8) {
+    const uint64_t w = ((const dl_u64*)(u + w0))->v;  // reads past b stay inside the buffer slack
+    uint64_t m = eq_mask8(w, 0x3B3B3B3B3B3B3B3Bull) | eq_mask8(w, 0x3D3D3D3D3D3D3D3Dull);
+    while (m) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint64_t pq = w0 + (uint64_t)(bit >> 3);
+      if (pq >= b) break;
+      if (((w >> (bit - 7)) & 0xFF) == ';') { finish(pq); q = pq + 1; eqp = ~0ull; }
+      else if (eqp == ~0ull) eqp = pq;
+    }
   }
+  if (q < b) finish(b);
 }
 void launch_vcf_info_locate(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
                             int K, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state, uint32_t* err, hipStream_t st) {
