@@ -56,7 +56,7 @@ static void throw_vcf_err(uint32_t e) {
     case VERR_BAD_INT: throw Error("Error reading INFO / FORMAT field: invalid integer");
     case VERR_BAD_FLOAT: throw Error("Error reading INFO / FORMAT field: invalid float literal");
     case VERR_INVALID_FLAG: throw Error("Error reading INFO field: invalid flag");
-    case VERR_PERCENT: throw Error("VCF read error: percent-encoded string value (not supported on device)");
+    case VERR_PERCENT: throw Error("VCF read error: percent-encoded byte >= 0x80 in a string value (not supported on device)");
     case VERR_BAD_GT: throw Error("Error reading FORMAT field 'GT': invalid genotype");
     default: throw Error("VCF read error: device error " + std::to_string(e));
   }
@@ -266,6 +266,7 @@ struct Ctx {
   uint64_t tmp_n = 0;
   uint32_t* err;
   uint64_t arrow_bytes = 0;
+  DevBuf<uint32_t> pct;  // set by the string span kernels when a value holds a percent escape
   uint64_t* scratch(uint64_t n) {
     const uint64_t need = scan_tmp_elems(n);
     if (tmp.n < need) tmp.alloc(need);
@@ -280,12 +281,18 @@ struct Ctx {
   }
 };
 
-static void finish_utf8(Ctx& c, VNode& nd, const uint64_t* src, const uint32_t* len, uint64_t N) {
+static void finish_utf8(Ctx& c, VNode& nd, const uint64_t* src, const uint32_t* len, uint64_t N, bool may_have_pct = false) {
   nd.n = N;
   nd.d_off.alloc(N + 1);
   nd.total = c.scan(len, nd.d_off.p, N);
   nd.d_values.alloc(std::max<uint64_t>(nd.total, 1));
-  launch_scatter_ranges(c.u, src, N, nd.d_off.p, nd.d_values.p, nd.total, c.st);
+  uint32_t pct = 0;
+  if (may_have_pct) {
+    HIP_CHECK(hipMemcpyAsync(&pct, c.pct.p, 4, hipMemcpyDeviceToHost, c.st));
+    HIP_CHECK(hipStreamSynchronize(c.st));
+  }
+  if (pct) launch_scatter_pct(c.u, src, N, nd.d_off.p, nd.d_values.p, c.st);   // percent-decoding copy (noodles decodes INFO / FORMAT strings)
+  else launch_scatter_ranges(c.u, src, N, nd.d_off.p, nd.d_values.p, nd.total, c.st);
   c.arrow_bytes += nd.total + (N + 1) * 4;
 }
 
@@ -311,8 +318,10 @@ static void build_from_spans(Ctx& c, VNode& nd, const uint64_t* sp_off, const ui
       DevBuf<uint32_t> len(std::max<uint64_t>(N, 1));
       nd.d_valid.alloc(std::max<uint64_t>(nw, 1));
       nd.all_valid = false;
-      launch_span_str(c.u, sp_off, sp_len, sp_state, N, len.p, nd.d_valid.p, c.err, c.st);
-      finish_utf8(c, nd, sp_off, len.p, N);
+      if (!c.pct.p) c.pct.alloc(1);
+      HIP_CHECK(hipMemsetAsync(c.pct.p, 0, 4, c.st));
+      launch_span_str(c.u, sp_off, sp_len, sp_state, N, len.p, nd.d_valid.p, c.pct.p, c.err, c.st);
+      finish_utf8(c, nd, sp_off, len.p, N, true);
       c.arrow_bytes += nw * 8;
       break;
     }
@@ -334,13 +343,15 @@ static void build_from_spans(Ctx& c, VNode& nd, const uint64_t* sp_off, const ui
       if (ch.fd.kind == VK_INT32 || ch.fd.kind == VK_FLOAT32) {
         ch.d_values.alloc(std::max<uint64_t>(E, 1) * 4);
         launch_span_list_elems(c.u, sp_off, sp_len, sp_state, N, nd.d_off.p, ch.fd.kind == VK_INT32 ? 0 : 1, (uint32_t*)ch.d_values.p,
-                               nullptr, nullptr, evalid.p, c.err, c.st);
+                               nullptr, nullptr, evalid.p, nullptr, c.err, c.st);
         c.arrow_bytes += E * 4;
       } else if (ch.fd.kind == VK_UTF8) {
         DevBuf<uint64_t> esrc(std::max<uint64_t>(E, 1));
         DevBuf<uint32_t> elen(std::max<uint64_t>(E, 1));
-        launch_span_list_elems(c.u, sp_off, sp_len, sp_state, N, nd.d_off.p, 2, nullptr, esrc.p, elen.p, evalid.p, c.err, c.st);
-        finish_utf8(c, ch, esrc.p, elen.p, E);
+        if (!c.pct.p) c.pct.alloc(1);
+        HIP_CHECK(hipMemsetAsync(c.pct.p, 0, 4, c.st));
+        launch_span_list_elems(c.u, sp_off, sp_len, sp_state, N, nd.d_off.p, 2, nullptr, esrc.p, elen.p, evalid.p, c.pct.p, c.err, c.st);
+        finish_utf8(c, ch, esrc.p, elen.p, E, true);
       } else throw Error("Unsupported list element type in a VCF column");
       launch_pack_bits(evalid.p, E, ch.d_valid.p, c.st);
       HIP_CHECK(hipStreamSynchronize(c.st));  // evalid goes out of scope
@@ -832,7 +843,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
   t.start();
   res->cols.resize(out_fields.size());
   for (size_t c = 0; c < out_fields.size(); c++) { res->cols[c].fd = out_fields[c]; res->cols[c].n = n; }
-  Ctx cx{p, st, u, {}, 0, err.p, 0};
+  Ctx cx{p, st, u, {}, 0, err.p, 0, {}};
   if (n) {
     int core_col[8];
     for (int k = 0; k < 8; k++) core_col[k] = -1;

@@ -77,13 +77,15 @@ void launch_span_num(const uint8_t* u, const uint64_t* off, const uint32_t* len,
                      uint32_t* values, uint64_t* valid, uint32_t* err, hipStream_t st);
 void launch_span_flag(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint64_t* bits,
                       uint32_t* err, hipStream_t st);
+// out_len = length after percent-decoding; *pct_flag |= 1 when some value holds an escape (the scatter then decodes)
 void launch_span_str(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* out_len,
-                     uint64_t* valid, uint32_t* err, hipStream_t st);
+                     uint64_t* valid, uint32_t* pct_flag, uint32_t* err, hipStream_t st);
+void launch_scatter_pct(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
 void launch_span_list_count(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* cnt,
                             uint64_t* valid, hipStream_t st);
 void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N,
                             const uint64_t* eoff, int kind, uint32_t* values, uint64_t* esrc, uint32_t* elen, uint8_t* evalid,
-                            uint32_t* err, hipStream_t st);
+                            uint32_t* pct_flag, uint32_t* err, hipStream_t st);
 void launch_pack_bits(const uint8_t* bytes, uint64_t n, uint64_t* words, hipStream_t st);
 void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st);
 

@@ -288,6 +288,28 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
 }
 
 __device__ __forceinline__ void set_err(uint32_t* err, uint32_t code) { atomicCAS(err, 0u, code); }
+__device__ __forceinline__ int hexval(uint32_t c) {
+  if (c - '0' <= 9u) return (int)(c - '0');
+  c |= 0x20u;
+  if (c - 'a' <= 5u) return (int)(c - 'a') + 10;
+  return -1;
+}
+// length of [p, p+l) after percent-decoding (noodles decodes INFO / FORMAT strings; malformed escapes stay as they are).
+// Sets *pct when an escape was decoded; decoded bytes >= 0x80 would need UTF-8 validation and are refused.
+__device__ uint32_t pct_decoded_len(const uint8_t* p, uint32_t l, bool* pct, uint32_t* err) {
+  uint32_t out = 0;
+  for (uint32_t k = 0; k < l; k++, out++) {
+    if (p[k] == '%' && k + 2 < l) {
+      const int h = hexval(p[k + 1]), lo = hexval(p[k + 2]);
+      if (h >= 0 && lo >= 0) {
+        if (h >= 8) set_err(err, VERR_PERCENT);
+        *pct = true;
+        k += 2;
+      }
+    }
+  }
+  return out;
+}
 
 // ---- line keys ----------------------------------------------------------------------------------------------
 // pos = POS; vend = noodles variant_end (INFO END, else POS + len(REF) - 1); flags bit0 = single-base ACGT SNV
@@ -659,7 +681,8 @@ void launch_span_flag(const uint8_t* u, const uint64_t* off, const uint32_t* len
 // Utf8: out_len = span length (0 when NULL), validity; '%' (percent-encoding) is rejected, not decoded
 __global__ __launch_bounds__(256) void k_span_str(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
                                                    const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
-                                                   uint32_t* __restrict__ out_len, uint64_t* __restrict__ valid, uint32_t* __restrict__ err) {
+                                                   uint32_t* __restrict__ out_len, uint64_t* __restrict__ valid, uint32_t* __restrict__ pct_flag,
+                                                   uint32_t* __restrict__ err) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool v = false;
   if (c < N) {
@@ -670,7 +693,9 @@ __global__ __launch_bounds__(256) void k_span_str(const uint8_t* __restrict__ u,
       if (l == 1 && p[0] == '.') l = 0;
       else {
         v = true;
-        for (uint32_t k = 0; k < l; k++) if (p[k] == '%') { set_err(err, VERR_PERCENT); break; }
+        bool pct = false;
+        l = pct_decoded_len(p, l, &pct, err);
+        if (pct) atomicOr(pct_flag, 1u);
       }
     }
     out_len[c] = l;
@@ -679,9 +704,31 @@ __global__ __launch_bounds__(256) void k_span_str(const uint8_t* __restrict__ u,
   if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) valid[c >> 6] = m;
 }
 void launch_span_str(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, uint32_t* out_len,
-                     uint64_t* valid, uint32_t* err, hipStream_t st) {
+                     uint64_t* valid, uint32_t* pct_flag, uint32_t* err, hipStream_t st) {
   if (!N) return;
-  hipLaunchKernelGGL(k_span_str, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, out_len, valid, err);
+  hipLaunchKernelGGL(k_span_str, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, out_len, valid, pct_flag, err);
+}
+// copy with percent-decoding: row r produces off64[r+1] - off64[r] bytes from u[src[r] ..]
+__global__ __launch_bounds__(256) void k_scatter_pct(const uint8_t* __restrict__ u, const uint64_t* __restrict__ src, uint64_t n,
+                                                      const uint64_t* __restrict__ off64, uint8_t* __restrict__ dst) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t o = off64[r];
+  const uint32_t L = (uint32_t)(off64[r + 1] - o);
+  const uint8_t* p = u + src[r];
+  for (uint32_t k = 0; k < L; k++) {
+    uint32_t c = *p;
+    if (c == '%') {
+      const int h = hexval(p[1]), lo = h >= 0 ? hexval(p[2]) : -1;
+      if (lo >= 0) { c = (uint32_t)(h * 16 + lo); p += 2; }
+    }
+    dst[o + k] = (uint8_t)c;
+    p++;
+  }
+}
+void launch_scatter_pct(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scatter_pct, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
 }
 // list element count: "." / absent -> NULL list (0 elements); else commas + 1
 __global__ __launch_bounds__(256) void k_span_list_count(const uint8_t* __restrict__ u, const uint64_t* __restrict__ off,
@@ -716,7 +763,8 @@ __global__ __launch_bounds__(256) void k_span_list_elems(const uint8_t* __restri
                                                           const uint32_t* __restrict__ len, const uint8_t* __restrict__ state, uint64_t N,
                                                           const uint64_t* __restrict__ eoff, int kind, uint32_t* __restrict__ values,
                                                           uint64_t* __restrict__ esrc, uint32_t* __restrict__ elen,
-                                                          uint8_t* __restrict__ evalid, uint32_t* __restrict__ err) {
+                                                          uint8_t* __restrict__ evalid, uint32_t* __restrict__ pct_flag,
+                                                          uint32_t* __restrict__ err) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= N) return;
   uint64_t o = eoff[c];
@@ -732,8 +780,13 @@ __global__ __launch_bounds__(256) void k_span_list_elems(const uint8_t* __restri
       const bool miss = el == 1 && p[a] == '.';
       if (kind == 2) {
         esrc[o] = base + a;
-        elen[o] = miss ? 0 : el;
-        if (!miss) for (uint32_t k = a; k < j; k++) if (p[k] == '%') { set_err(err, VERR_PERCENT); break; }
+        uint32_t dl = 0;
+        if (!miss) {
+          bool pct = false;
+          dl = pct_decoded_len(p + a, el, &pct, err);
+          if (pct) atomicOr(pct_flag, 1u);
+        }
+        elen[o] = dl;
       } else {
         uint32_t out = 0;
         if (!miss) {
@@ -756,10 +809,10 @@ __global__ __launch_bounds__(256) void k_span_list_elems(const uint8_t* __restri
 }
 void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N,
                             const uint64_t* eoff, int kind, uint32_t* values, uint64_t* esrc, uint32_t* elen, uint8_t* evalid,
-                            uint32_t* err, hipStream_t st) {
+                            uint32_t* pct_flag, uint32_t* err, hipStream_t st) {
   if (!N) return;
   hipLaunchKernelGGL(k_span_list_elems, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, off, len, state, N, eoff, kind, values,
-                     esrc, elen, evalid, err);
+                     esrc, elen, evalid, pct_flag, err);
 }
 __global__ __launch_bounds__(256) void k_pack_bits(const uint8_t* __restrict__ bytes, uint64_t n, uint64_t* __restrict__ words) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;

@@ -311,7 +311,7 @@ def test_vcf_errors_are_loud(pkg, tmp_path):
     assert run("c\t5\t.\tA\tT\t.\t.\tDP=3\n")["DP"] == [3]
     for body, msg in (("c\t5\t.\tA\tT\t.\t.\tDP=x\n", "invalid integer"),
                       ("c\t5\t.\tA\tT\t.\t.\tDP=1;DP=2\n", "duplicate INFO key"),
-                      ("c\t5\t.\tA\tT\t.\t.\tS=a%3Bb\n", "percent-encoded"),
+                      ("c\t5\t.\tA\tT\t.\t.\tS=a%C3%A9\n", "percent-encoded byte"),
                       ("c\t5\t.\tA\tT\tbad\t.\tDP=1\n", "qual"),
                       ("c\t0\t.\tA\tT\t.\t.\tDP=1\n", "Missing variant start"),
                       ("c\tx\t.\tA\tT\t.\t.\tDP=1\n", "position"),
@@ -335,6 +335,23 @@ def test_vcf_errors_are_loud(pkg, tmp_path):
     # an INFO tag that the header does not define is refused (the reference unwraps the lookup and panics)
     with pytest.raises(pkg.BioscanError):
         pkg.VcfTableProvider(str(tmp_path / "x.vcf"), ["NOPE"])
+
+
+def test_percent_decoding(pkg, vo, tmp_path):
+    """noodles percent-decodes INFO / FORMAT string values (oracle header); the device copy does the same."""
+    text = ("##fileformat=VCFv4.3\n##INFO=<ID=S,Number=1,Type=String,Description=\"s\">\n"
+            "##INFO=<ID=L,Number=.,Type=String,Description=\"l\">\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"g\">\n"
+            "##FORMAT=<ID=FT,Number=1,Type=String,Description=\"f\">\n"
+            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n"
+            "c\t5\t.\tA\tT\t.\t.\tS=a%3Bb%3Dc;L=x%2Cy,.,%25z\tGT:FT\t0/1:p%3Aq\t1/1:.\n"
+            "c\t6\t.\tA\tT\t.\t.\tS=plain;L=%zz,100%\tGT:FT\t0/0:ok\t./.:%41\n")
+    p = tmp_path / "pct.vcf"
+    p.write_text(text)
+    assert _parity(pkg, vo, str(p), {}, exact_batches=False) == 2
+    t = GpuTable(pkg, str(p))
+    r = t.read(["S", "L", "genotypes"])
+    assert r["S"] == ["a;b=c", "plain"] and r["L"] == [["x,y", None, "%z"], ["%zz", "100%"]]
+    assert r["genotypes"][0]["FT"] == ["p:q", None] and r["genotypes"][1]["FT"] == ["ok", "A"]
 
 
 def test_vcf_multi_gpu_sharding_reproduces_single_gpu_order(pkg, vo, tmp_path):
