@@ -1465,6 +1465,27 @@ int bioscan_udf_list_cmp(const struct ArrowArray* in, const struct ArrowSchema* 
   udf_list_cmp_host(in, in_schema, op, threshold, device_id, out, out_schema);
   API_END
 }
+int bioscan_udf_list_and(const struct ArrowArray* a, const struct ArrowSchema* a_schema, const struct ArrowArray* b,
+                         const struct ArrowSchema* b_schema, int32_t device_id, struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  API_BEGIN
+  {
+    char nm[8];
+    if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(g_err);
+  }
+  udf_list_and_host(a, a_schema, b, b_schema, device_id, out, out_schema);
+  API_END
+}
+int bioscan_udf_vcf_set_gts(const struct ArrowArray* gt, const struct ArrowSchema* gt_schema, const struct ArrowArray* mask,
+                            const struct ArrowSchema* mask_schema, const char* replacement, int32_t device_id,
+                            struct ArrowArray* out, struct ArrowSchema* out_schema) {
+  API_BEGIN
+  {
+    char nm[8];
+    if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(g_err);
+  }
+  udf_set_gts_host(gt, gt_schema, mask, mask_schema, replacement, device_id, out, out_schema);
+  API_END
+}
 int bioscan_stream_list_udf(bioscan_stream* s, const char* field, int32_t udf, double threshold, bioscan_udf_stats* out) {
   API_BEGIN
   if (!s->vcf) throw Error("list UDFs apply to VCF streams");

@@ -34,4 +34,9 @@ void udf_list_avg_host(const ArrowArray* in, const ArrowSchema* in_schema, int32
 void udf_list_cmp_host(const ArrowArray* in, const ArrowSchema* in_schema, int32_t op, double threshold, int32_t device_id,
                        ArrowArray* out, ArrowSchema* out_schema);
 
+void udf_list_and_host(const ArrowArray* a, const ArrowSchema* as, const ArrowArray* b, const ArrowSchema* bs, int32_t device_id,
+                       ArrowArray* out, ArrowSchema* out_schema);
+void udf_set_gts_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowArray* mask, const ArrowSchema* ms, const char* replacement,
+                      int32_t device_id, ArrowArray* out, ArrowSchema* out_schema);
+
 }  // namespace bioscan

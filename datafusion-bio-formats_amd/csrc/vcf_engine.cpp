@@ -1093,8 +1093,8 @@ void VcfStream::list_udf(const char* field, int32_t udf, double threshold, biosc
 // Host Arrow in/out forms.
 struct UdfKeep {
   std::vector<double> f64;
-  std::vector<uint8_t> bits, bits2, lbits;
-  std::vector<int32_t> off;
+  std::vector<uint8_t> bits, bits2, lbits, data;
+  std::vector<int32_t> off, off2;
 };
 struct UdfPriv {
   std::shared_ptr<UdfKeep> keep;
@@ -1173,6 +1173,36 @@ static void upload_list(const ListIn& L, ListDev& D) {
   if (!L.evalid.empty()) { D.evalid.alloc(L.evalid.size()); HIP_CHECK(hipMemcpy(D.evalid.p, L.evalid.data(), L.evalid.size() * 8, hipMemcpyHostToDevice)); }
 }
 
+// List<Boolean> input window: bit-packed values / validity rebased to element 0
+struct BoolListIn {
+  uint64_t n = 0, E = 0;
+  std::vector<uint64_t> off, lvalid, val, evalid;
+};
+static BoolListIn read_bool_list(const ArrowArray* in, const ArrowSchema* sc) {
+  if (!in || !sc || !sc->format || strcmp(sc->format, "+l") != 0 || sc->n_children != 1 || in->n_children != 1 ||
+      strcmp(sc->children[0]->format, "b") != 0)
+    throw Error("expected a List<Boolean> array");
+  BoolListIn L;
+  L.n = (uint64_t)in->length;
+  const int32_t* off = (const int32_t*)in->buffers[1] + in->offset;
+  const ArrowArray* ch = in->children[0];
+  const uint64_t e0 = L.n ? (uint64_t)off[0] : 0, e1 = L.n ? (uint64_t)off[L.n] : 0;
+  L.E = e1 - e0;
+  L.off.resize(L.n + 1);
+  for (uint64_t i = 0; i <= L.n; i++) L.off[i] = L.n ? (uint64_t)off[i] - e0 : 0;
+  if (in->buffers[0] && in->null_count != 0) bits_to_words((const uint8_t*)in->buffers[0], (uint64_t)in->offset, L.n, L.lvalid);
+  if (ch->buffers[0] && ch->null_count != 0) bits_to_words((const uint8_t*)ch->buffers[0], (uint64_t)ch->offset + e0, L.E, L.evalid);
+  if (L.E) bits_to_words((const uint8_t*)ch->buffers[1], (uint64_t)ch->offset + e0, L.E, L.val);
+  else L.val.assign(1, 0);
+  return L;
+}
+template <typename T>
+static void up(DevBuf<T>& d, const std::vector<T>& h) {
+  d.alloc(std::max<size_t>(h.size(), 1));
+  if (!h.empty()) HIP_CHECK(hipMemcpy(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+static bool word_bit(const std::vector<uint64_t>& w, uint64_t i) { return w.empty() || ((w[i >> 6] >> (i & 63)) & 1ull); }
+
 }  // namespace
 
 void udf_list_avg_host(const ArrowArray* in, const ArrowSchema* in_schema, int32_t device_id, ArrowArray* out, ArrowSchema* out_schema) {
@@ -1250,6 +1280,138 @@ void udf_list_cmp_host(const ArrowArray* in, const ArrowSchema* in_schema, int32
   fill_schema(out_schema, op == 0 ? "list_gte" : "list_lte", "+l", true, {});
   std::unique_ptr<ArrowSchema> cs(new ArrowSchema);
   fill_schema(cs.get(), "item", "b", true, {});
+  add_child(out_schema, std::move(cs));
+}
+
+void udf_list_and_host(const ArrowArray* a, const ArrowSchema* as, const ArrowArray* b, const ArrowSchema* bs, int32_t device_id,
+                       ArrowArray* out, ArrowSchema* out_schema) {
+  BoolListIn L = read_bool_list(a, as), R = read_bool_list(b, bs);
+  if (L.n != R.n) throw Error("list_and: the two arguments have different lengths");
+  const uint64_t n = L.n;
+  std::vector<uint64_t> off_o(n + 1, 0);
+  auto keep = std::make_shared<UdfKeep>();
+  keep->lbits.assign((n + 7) / 8 + 8, 0);
+  int64_t lnulls = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    const bool ok = word_bit(L.lvalid, i) && word_bit(R.lvalid, i);   // NULL list on either side -> NULL list (udfs.rs:807-810)
+    const uint64_t ll = L.off[i + 1] - L.off[i], rl = R.off[i + 1] - R.off[i];
+    off_o[i + 1] = off_o[i] + (ok ? std::min(ll, rl) : 0);
+    if (ok) keep->lbits[i >> 3] |= (uint8_t)(1u << (i & 7)); else lnulls++;
+  }
+  const uint64_t E = off_o[n], ew = (E + 63) / 64 + 1;
+  HIP_CHECK(hipSetDevice(device_id));
+  DevBuf<uint64_t> d_ol, d_or, d_oo, d_lv, d_lva, d_rv, d_rva, d_val(ew), d_valid(ew);
+  up(d_ol, L.off); up(d_or, R.off); up(d_oo, off_o); up(d_lv, L.val); up(d_rv, R.val);
+  if (!L.evalid.empty()) up(d_lva, L.evalid);
+  if (!R.evalid.empty()) up(d_rva, R.evalid);
+  HIP_CHECK(hipMemset(d_val.p, 0, ew * 8));
+  HIP_CHECK(hipMemset(d_valid.p, 0, ew * 8));
+  launch_list_and(d_ol.p, d_or.p, d_oo.p, d_lv.p, L.evalid.empty() ? nullptr : d_lva.p, d_rv.p, R.evalid.empty() ? nullptr : d_rva.p, n,
+                  d_val.p, d_valid.p, nullptr);
+  HIP_CHECK(hipDeviceSynchronize());
+  keep->bits.assign(ew * 8 + 8, 0);
+  keep->bits2.assign(ew * 8 + 8, 0);
+  HIP_CHECK(hipMemcpy(keep->bits.data(), d_val.p, ew * 8, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(keep->bits2.data(), d_valid.p, ew * 8, hipMemcpyDeviceToHost));
+  int64_t enulls = 0;
+  for (uint64_t i = 0; i < E; i++) enulls += !((keep->bits2[i >> 3] >> (i & 7)) & 1);
+  keep->off.resize(n + 1);
+  for (uint64_t i = 0; i <= n; i++) keep->off[i] = (int32_t)off_o[i];
+  UdfPriv* pr = init_udf_array(out, keep, (int64_t)n);
+  out->null_count = lnulls;
+  pr->buffers.push_back(lnulls ? keep->lbits.data() : nullptr);
+  pr->buffers.push_back(keep->off.data());
+  std::unique_ptr<ArrowArray> item(new ArrowArray);
+  UdfPriv* ip = init_udf_array(item.get(), keep, (int64_t)E);
+  item->null_count = enulls;
+  ip->buffers.push_back(enulls ? keep->bits2.data() : nullptr);
+  ip->buffers.push_back(keep->bits.data());
+  finish_udf_array(item.get());
+  pr->children.push_back(item.get());
+  pr->owned.push_back(std::move(item));
+  finish_udf_array(out);
+  fill_schema(out_schema, "list_and", "+l", true, {});
+  std::unique_ptr<ArrowSchema> cs(new ArrowSchema);
+  fill_schema(cs.get(), "item", "b", true, {});
+  add_child(out_schema, std::move(cs));
+}
+
+void udf_set_gts_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowArray* mask, const ArrowSchema* ms, const char* replacement,
+                      int32_t device_id, ArrowArray* out, ArrowSchema* out_schema) {
+  if (!gt || !gs || strcmp(gs->format, "+l") != 0 || gs->n_children != 1 || strcmp(gs->children[0]->format, "u") != 0)
+    throw Error("vcf_set_gts expects List<Utf8> genotypes");
+  BoolListIn M = read_bool_list(mask, ms);
+  const uint64_t n = (uint64_t)gt->length;
+  if (M.n != n) throw Error("vcf_set_gts: the two list arguments have different lengths");
+  const std::string rep = replacement ? replacement : "./.";
+  const int32_t* off = (const int32_t*)gt->buffers[1] + gt->offset;
+  const ArrowArray* ch = gt->children[0];
+  const uint64_t e0 = n ? (uint64_t)off[0] : 0, e1 = n ? (uint64_t)off[n] : 0, E = e1 - e0;
+  std::vector<uint64_t> off_g(n + 1), goff(E + 1), gvalid, glvalid;
+  for (uint64_t i = 0; i <= n; i++) off_g[i] = n ? (uint64_t)off[i] - e0 : 0;
+  const int32_t* so = (const int32_t*)ch->buffers[1] + ch->offset + e0;
+  const uint64_t b0 = E ? (uint64_t)so[0] : 0, b1 = E ? (uint64_t)so[E] : 0;
+  for (uint64_t i = 0; i <= E; i++) goff[i] = E ? (uint64_t)so[i] - b0 : 0;
+  if (ch->buffers[0] && ch->null_count != 0) bits_to_words((const uint8_t*)ch->buffers[0], (uint64_t)ch->offset + e0, E, gvalid);
+  if (gt->buffers[0] && gt->null_count != 0) bits_to_words((const uint8_t*)gt->buffers[0], (uint64_t)gt->offset, n, glvalid);
+  const uint64_t data_len = b1 - b0;
+  HIP_CHECK(hipSetDevice(device_id));
+  DevBuf<uint8_t> d_u(data_len + rep.size() + 64);
+  if (data_len) HIP_CHECK(hipMemcpy(d_u.p, (const uint8_t*)ch->buffers[2] + b0, data_len, hipMemcpyHostToDevice));
+  if (!rep.empty()) HIP_CHECK(hipMemcpy(d_u.p + data_len, rep.data(), rep.size(), hipMemcpyHostToDevice));
+  DevBuf<uint64_t> d_og, d_goff, d_gv, d_om, d_mlv, d_mv, d_mva, d_src(std::max<uint64_t>(E, 1)), d_ooff(E + 2), d_tmp(scan_tmp_elems(E));
+  DevBuf<uint32_t> d_len(std::max<uint64_t>(E, 1));
+  DevBuf<uint8_t> d_ov(std::max<uint64_t>(E, 1));
+  up(d_og, off_g); up(d_goff, goff); up(d_om, M.off); up(d_mv, M.val);
+  if (!gvalid.empty()) up(d_gv, gvalid);
+  if (!M.lvalid.empty()) up(d_mlv, M.lvalid);
+  if (!M.evalid.empty()) up(d_mva, M.evalid);
+  launch_set_gts_plan(d_og.p, d_goff.p, gvalid.empty() ? nullptr : d_gv.p, d_om.p, M.lvalid.empty() ? nullptr : d_mlv.p, d_mv.p,
+                      M.evalid.empty() ? nullptr : d_mva.p, n, data_len, (uint32_t)rep.size(), d_src.p, d_len.p, d_ov.p, nullptr);
+  launch_exclusive_scan_u32_to_u64(d_len.p, d_ooff.p, E, d_tmp.p, nullptr);
+  std::vector<uint64_t> ooff(E + 1);
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpy(ooff.data(), d_ooff.p, (E + 1) * 8, hipMemcpyDeviceToHost));
+  const uint64_t tot = ooff[E];
+  if (tot > 0x7FFFFFFFull) throw Error("vcf_set_gts: result exceeds the int32 offsets of one Utf8 array");
+  DevBuf<uint8_t> d_out(std::max<uint64_t>(tot, 1));
+  launch_scatter_ranges(d_u.p, d_src.p, E, d_ooff.p, d_out.p, tot, nullptr);
+  HIP_CHECK(hipDeviceSynchronize());
+  auto keep = std::make_shared<UdfKeep>();
+  keep->data.resize(tot + 8);
+  if (tot) HIP_CHECK(hipMemcpy(keep->data.data(), d_out.p, tot, hipMemcpyDeviceToHost));
+  std::vector<uint8_t> ov(E + 1);
+  if (E) HIP_CHECK(hipMemcpy(ov.data(), d_ov.p, E, hipMemcpyDeviceToHost));
+  keep->bits2.assign((E + 7) / 8 + 8, 0);
+  int64_t enulls = 0;
+  for (uint64_t i = 0; i < E; i++) { if (ov[i]) keep->bits2[i >> 3] |= (uint8_t)(1u << (i & 7)); else enulls++; }
+  keep->off2.resize(E + 1);
+  for (uint64_t i = 0; i <= E; i++) keep->off2[i] = (int32_t)ooff[i];
+  keep->off.resize(n + 1);
+  for (uint64_t i = 0; i <= n; i++) keep->off[i] = (int32_t)off_g[i];
+  keep->lbits.assign((n + 7) / 8 + 8, 0xFF);
+  int64_t lnulls = 0;
+  if (!glvalid.empty()) {
+    memcpy(keep->lbits.data(), glvalid.data(), (n + 7) / 8);
+    for (uint64_t i = 0; i < n; i++) lnulls += !word_bit(glvalid, i);
+  }
+  UdfPriv* pr = init_udf_array(out, keep, (int64_t)n);
+  out->null_count = lnulls;
+  pr->buffers.push_back(lnulls ? keep->lbits.data() : nullptr);
+  pr->buffers.push_back(keep->off.data());
+  std::unique_ptr<ArrowArray> item(new ArrowArray);
+  UdfPriv* ip = init_udf_array(item.get(), keep, (int64_t)E);
+  item->null_count = enulls;
+  ip->buffers.push_back(enulls ? keep->bits2.data() : nullptr);
+  ip->buffers.push_back(keep->off2.data());
+  ip->buffers.push_back(keep->data.data());
+  finish_udf_array(item.get());
+  pr->children.push_back(item.get());
+  pr->owned.push_back(std::move(item));
+  finish_udf_array(out);
+  fill_schema(out_schema, "vcf_set_gts", "+l", true, {});
+  std::unique_ptr<ArrowSchema> cs(new ArrowSchema);
+  fill_schema(cs.get(), "item", "u", true, {});
   add_child(out_schema, std::move(cs));
 }
 

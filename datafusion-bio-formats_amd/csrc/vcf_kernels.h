@@ -108,6 +108,13 @@ void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows,
 // list UDFs: off = u64 list offsets (n+1), values = 32-bit elements, evalid / lvalid = validity words or nullptr
 void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t* evalid, const uint64_t* lvalid, uint64_t n,
                      int is_float, double* out, uint8_t* out_valid, hipStream_t st);
+// list_and: bit-packed Boolean values / validity of both lists, u64 offsets; out_val / out_valid zero-initialised
+void launch_list_and(const uint64_t* off_l, const uint64_t* off_r, const uint64_t* off_o, const uint64_t* lval, const uint64_t* lvalid,
+                     const uint64_t* rval, const uint64_t* rvalid, uint64_t n, uint64_t* out_val, uint64_t* out_valid, hipStream_t st);
+// vcf_set_gts: per GT element -> source offset (into [GT bytes | replacement]), length, validity byte
+void launch_set_gts_plan(const uint64_t* off_g, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_m,
+                         const uint64_t* mlvalid, const uint64_t* mval, const uint64_t* mvalid, uint64_t n, uint64_t rep_off,
+                         uint32_t rep_len, uint64_t* src, uint32_t* len, uint8_t* ovalid, hipStream_t st);
 void launch_count_bits(const uint64_t* bits, const uint64_t* valid, uint64_t n_elems, unsigned long long* counts, hipStream_t st);
 void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st);
 

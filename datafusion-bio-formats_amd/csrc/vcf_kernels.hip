@@ -1074,6 +1074,83 @@ void launch_count_bits(const uint64_t* bits, const uint64_t* valid, uint64_t n_e
   const uint32_t grid = (uint32_t)std::min<uint64_t>((nw + 255) / 256, 2048);
   hipLaunchKernelGGL(k_count_bits, dim3(grid), dim3(256), 0, st, bits, valid, n_elems, counts);
 }
+// list_and (udfs.rs:799-843): one wave per row, SQL three-valued AND over min(len_l, len_r) elements.  The output
+// bit range of a 64-element step is unaligned, so a wave ORs its ballot into the two words it straddles
+// (out_val / out_valid must be zeroed first).
+__device__ __forceinline__ void or_bits(uint64_t* words, uint64_t bit0, unsigned long long m, int lane) {
+  if (lane == 0 && m) {
+    const uint32_t sh = (uint32_t)(bit0 & 63);
+    atomicOr((unsigned long long*)&words[bit0 >> 6], m << sh);
+    if (sh && (m >> (64 - sh))) atomicOr((unsigned long long*)&words[(bit0 >> 6) + 1], m >> (64 - sh));
+  }
+}
+__global__ __launch_bounds__(256) void k_list_and(const uint64_t* __restrict__ off_l, const uint64_t* __restrict__ off_r,
+                                                   const uint64_t* __restrict__ off_o, const uint64_t* __restrict__ lval,
+                                                   const uint64_t* __restrict__ lvalid, const uint64_t* __restrict__ rval,
+                                                   const uint64_t* __restrict__ rvalid, uint64_t n, uint64_t* __restrict__ out_val,
+                                                   uint64_t* __restrict__ out_valid) {
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const uint64_t a = off_l[r], b = off_r[r], o = off_o[r];
+  const uint64_t len = off_o[r + 1] - o;
+  for (uint64_t j0 = 0; j0 < len; j0 += WAVE) {
+    const uint64_t j = j0 + lane;
+    bool v = false, ok = false;
+    if (j < len) {
+      const bool ln = !bit_at(lvalid, a + j), rn = !bit_at(rvalid, b + j);
+      const bool lv = ((lval[(a + j) >> 6] >> ((a + j) & 63)) & 1ull) != 0, rv = ((rval[(b + j) >> 6] >> ((b + j) & 63)) & 1ull) != 0;
+      if (ln && rn) ok = false;
+      else if (ln) ok = !rv;          // NULL AND false = false, NULL AND true = NULL
+      else if (rn) ok = !lv;
+      else { ok = true; v = lv && rv; }
+    }
+    or_bits(out_val, o + j0, __ballot(v), lane);
+    or_bits(out_valid, o + j0, __ballot(ok), lane);
+  }
+}
+void launch_list_and(const uint64_t* off_l, const uint64_t* off_r, const uint64_t* off_o, const uint64_t* lval, const uint64_t* lvalid,
+                     const uint64_t* rval, const uint64_t* rvalid, uint64_t n, uint64_t* out_val, uint64_t* out_valid, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_list_and, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, off_l, off_r, off_o, lval, lvalid, rval,
+                     rvalid, n, out_val, out_valid);
+}
+// vcf_set_gts (udfs.rs:896-949): per GT element the output length / source / validity.  src indexes the buffer
+// [GT value bytes | replacement]: a replaced element points at the replacement (rep_off).
+__global__ __launch_bounds__(256) void k_set_gts_plan(const uint64_t* __restrict__ off_g, const uint64_t* __restrict__ goff,
+                                                       const uint64_t* __restrict__ gvalid, const uint64_t* __restrict__ off_m,
+                                                       const uint64_t* __restrict__ mlvalid, const uint64_t* __restrict__ mval,
+                                                       const uint64_t* __restrict__ mvalid, uint64_t n, uint64_t rep_off, uint32_t rep_len,
+                                                       uint64_t* __restrict__ src, uint32_t* __restrict__ len, uint8_t* __restrict__ ovalid) {
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const uint64_t a = off_g[r], e = off_g[r + 1];
+  const bool mnull = !bit_at(mlvalid, r);
+  const uint64_t mb = off_m[r], mlen = off_m[r + 1] - mb;
+  for (uint64_t j = lane; a + j < e; j += WAVE) {
+    const uint64_t g = a + j;
+    bool keep = true;
+    if (!mnull && j < mlen && bit_at(mvalid, mb + j)) keep = ((mval[(mb + j) >> 6] >> ((mb + j) & 63)) & 1ull) != 0;
+    if (keep) {
+      const bool gv = bit_at(gvalid, g);
+      src[g] = goff[g];
+      len[g] = gv ? (uint32_t)(goff[g + 1] - goff[g]) : 0u;
+      ovalid[g] = gv ? 1 : 0;
+    } else {
+      src[g] = rep_off;
+      len[g] = rep_len;
+      ovalid[g] = 1;
+    }
+  }
+}
+void launch_set_gts_plan(const uint64_t* off_g, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_m,
+                         const uint64_t* mlvalid, const uint64_t* mval, const uint64_t* mvalid, uint64_t n, uint64_t rep_off,
+                         uint32_t rep_len, uint64_t* src, uint32_t* len, uint8_t* ovalid, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_set_gts_plan, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, off_g, goff, gvalid, off_m, mlvalid, mval,
+                     mvalid, n, rep_off, rep_len, src, len, ovalid);
+}
 void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st) {
   if (!n_elems) return;
   hipLaunchKernelGGL(k_list_cmp, dim3((uint32_t)((n_elems + 255) / 256)), dim3(256), 0, st, values, n_elems, is_float, op, thr_bits, out_bits);

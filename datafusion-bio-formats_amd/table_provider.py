@@ -78,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
-    "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf",
+    "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
 ]
 
 
@@ -115,6 +115,8 @@ def load_library():
     lib.bioscan_vcf_open.argtypes = [C.c_char_p, C.POINTER(_VcfOptions), C.POINTER(C.c_void_p)]
     lib.bioscan_udf_list_avg.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_udf_list_cmp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.bioscan_udf_list_and.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.bioscan_udf_vcf_set_gts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_stream_list_udf.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_double, C.POINTER(UdfStats)]
     _lib = lib
     return lib
@@ -523,7 +525,10 @@ def list_avg(arr: pa.Array, device_id: int = 0) -> pa.Array:
     lib = load_library()
     a, s = _export_array(arr)
     oa, os_ = _ArrowArray(), _ArrowSchema()
-    _check(lib.bioscan_udf_list_avg(C.addressof(a), C.addressof(s), device_id, C.addressof(oa), C.addressof(os_)))
+    try:
+        _check(lib.bioscan_udf_list_avg(C.addressof(a), C.addressof(s), device_id, C.addressof(oa), C.addressof(os_)))
+    finally:
+        pa.Array._import_from_c(C.addressof(a), C.addressof(s))  # releases the exported input
     return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
 
 
@@ -531,8 +536,11 @@ def _list_cmp(arr: pa.Array, threshold, op: int, device_id: int) -> pa.Array:
     lib = load_library()
     a, s = _export_array(arr)
     oa, os_ = _ArrowArray(), _ArrowSchema()
-    _check(lib.bioscan_udf_list_cmp(C.addressof(a), C.addressof(s), op, float(threshold), device_id, C.addressof(oa),
-                                    C.addressof(os_)))
+    try:
+        _check(lib.bioscan_udf_list_cmp(C.addressof(a), C.addressof(s), op, float(threshold), device_id, C.addressof(oa),
+                                        C.addressof(os_)))
+    finally:
+        pa.Array._import_from_c(C.addressof(a), C.addressof(s))
     return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
 
 
@@ -544,3 +552,33 @@ def list_gte(arr: pa.Array, threshold, device_id: int = 0) -> pa.Array:
 def list_lte(arr: pa.Array, threshold, device_id: int = 0) -> pa.Array:
     """`list_lte` UDF (udfs.rs:663-760)."""
     return _list_cmp(arr, threshold, 1, device_id)
+
+
+def list_and(a: pa.Array, b: pa.Array, device_id: int = 0) -> pa.Array:
+    """`list_and` UDF (udfs.rs:765-850): element-wise SQL AND of two List<Boolean> arrays."""
+    lib = load_library()
+    aa, asch = _export_array(a)
+    ba, bsch = _export_array(b)
+    oa, os_ = _ArrowArray(), _ArrowSchema()
+    try:
+        _check(lib.bioscan_udf_list_and(C.addressof(aa), C.addressof(asch), C.addressof(ba), C.addressof(bsch), device_id,
+                                        C.addressof(oa), C.addressof(os_)))
+    finally:
+        pa.Array._import_from_c(C.addressof(aa), C.addressof(asch))  # releases the exported inputs
+        pa.Array._import_from_c(C.addressof(ba), C.addressof(bsch))
+    return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
+
+
+def vcf_set_gts(gt: pa.Array, mask: pa.Array, replacement: str = "./.", device_id: int = 0) -> pa.Array:
+    """`vcf_set_gts` UDF (udfs.rs:857-953)."""
+    lib = load_library()
+    ga, gsch = _export_array(gt)
+    ma, msch = _export_array(mask)
+    oa, os_ = _ArrowArray(), _ArrowSchema()
+    try:
+        _check(lib.bioscan_udf_vcf_set_gts(C.addressof(ga), C.addressof(gsch), C.addressof(ma), C.addressof(msch), replacement.encode(),
+                                           device_id, C.addressof(oa), C.addressof(os_)))
+    finally:
+        pa.Array._import_from_c(C.addressof(ga), C.addressof(gsch))
+        pa.Array._import_from_c(C.addressof(ma), C.addressof(msch))
+    return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))

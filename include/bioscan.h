@@ -97,6 +97,14 @@ int bioscan_udf_list_avg(const struct ArrowArray* in, const struct ArrowSchema* 
                          struct ArrowArray* out, struct ArrowSchema* out_schema);
 int bioscan_udf_list_cmp(const struct ArrowArray* in, const struct ArrowSchema* in_schema, int32_t op, double threshold,
                          int32_t device_id, struct ArrowArray* out, struct ArrowSchema* out_schema);
+/* list_and :765-850 List<Boolean>, List<Boolean> -> List<Boolean> (SQL three-valued AND over min(len) elements; a NULL list
+ * on either side gives a NULL list).  vcf_set_gts :857-953 List<Utf8> genotypes, List<Boolean> mask, replacement ->
+ * List<Utf8>: a genotype is replaced where its mask element is false and kept where it is true, NULL or absent. */
+int bioscan_udf_list_and(const struct ArrowArray* a, const struct ArrowSchema* a_schema, const struct ArrowArray* b,
+                         const struct ArrowSchema* b_schema, int32_t device_id, struct ArrowArray* out, struct ArrowSchema* out_schema);
+int bioscan_udf_vcf_set_gts(const struct ArrowArray* gt, const struct ArrowSchema* gt_schema, const struct ArrowArray* mask,
+                            const struct ArrowSchema* mask_schema, const char* replacement, int32_t device_id,
+                            struct ArrowArray* out, struct ArrowSchema* out_schema);
 /* Device-resident form for a stream returned by bioscan_execute_device: applies the UDF to `genotypes.<field>` (or a
  * top-level List column named `field`) of the whole partition without leaving HBM.  udf: 0 list_avg, 1 list_gte,
  * 2 list_lte.  Reports the kernel time and two checksums the caller can compare with an oracle: for list_avg the

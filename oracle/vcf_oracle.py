@@ -1055,3 +1055,21 @@ def list_and(a: pa.ListArray, b: pa.ListArray) -> pa.Array:
                 row.append(l and r)
         out.append(row)
     return pa.array(out, type=pa.list_(pa.field("item", pa.bool_(), True)))
+
+
+def vcf_set_gts(gt: pa.ListArray, mask: pa.ListArray, replacement: str = "./.") -> pa.Array:
+    """udfs.rs:896-949: GT kept where the mask element is true, NULL or absent (and when the mask list is NULL);
+    replaced where it is false; NULL GT elements stay NULL when kept; NULL GT list -> NULL list."""
+    out = []
+    for i in range(len(gt)):
+        if not gt[i].is_valid:
+            out.append(None)
+            continue
+        g = gt[i].as_py()
+        m = mask[i].as_py() if mask[i].is_valid else None
+        row = []
+        for j, v in enumerate(g):
+            keep = True if m is None else (j >= len(m) or m[j] is None or m[j])
+            row.append(v if keep else replacement)
+        out.append(row)
+    return pa.array(out, type=pa.list_(pa.field("item", pa.utf8(), True)))

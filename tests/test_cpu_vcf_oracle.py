@@ -115,6 +115,10 @@ def test_udf_kats():
     assert V.list_avg(gq).to_pylist() == [20.0, 10.0]
     assert V.list_gte(gq, 15).to_pylist() == [[True, True, False], [False, None, True]]
     assert V.list_and(V.list_gte(gq, 10), V.list_lte(dp, 100)).to_pylist() == [[True, True, True], [False, False, True]]
+    # vcf_set_gts (udfs.rs:1112-1139): mask false -> "./.", NULL mask element keeps the GT
+    G = pa.list_(pa.field("item", pa.utf8(), True))
+    gt = pa.array([["0/1", "1/1", "0/0"], ["./.", "0/1", "1/1"]], type=G)
+    assert V.vcf_set_gts(gt, V.list_gte(gq, 15), "./.").to_pylist() == [["0/1", "1/1", "./."], ["./.", "0/1", "1/1"]]
     # NULL list -> NULL; empty / all-null list -> NULL average (udfs.rs:73-86)
     a = pa.array([None, [], [None]], type=L)
     assert V.list_avg(a).to_pylist() == [None, None, None]

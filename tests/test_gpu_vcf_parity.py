@@ -240,6 +240,31 @@ def test_list_udfs_host(pkg, vo):
     assert pkg.list_gte(gq, 15).to_pylist() == [[True, True, False], [False, None, True]]
 
 
+def test_list_and_and_set_gts(pkg, vo):
+    rnd = random.Random(8)
+    B = pa.list_(pa.field("item", pa.bool_(), True))
+    G = pa.list_(pa.field("item", pa.utf8(), True))
+
+    def blist(n, maxlen):
+        return pa.array([None if rnd.random() < 0.05 else [None if rnd.random() < 0.15 else rnd.random() < 0.5
+                                                          for _ in range(rnd.randint(0, maxlen))] for _ in range(n)], type=B)
+    a, b = blist(1500, 90), blist(1500, 90)
+    assert pkg.list_and(a, b).equals(vo.list_and(a, b))
+    assert pkg.list_and(a.slice(3, 700), b.slice(3, 700)).equals(vo.list_and(a.slice(3, 700), b.slice(3, 700)))
+    gts = ["0/0", "0/1", "1|1", "./.", ".", "10/11", ""]
+    gt = pa.array([None if rnd.random() < 0.05 else [None if rnd.random() < 0.1 else rnd.choice(gts) for _ in range(rnd.randint(0, 90))]
+                   for _ in range(1500)], type=G)
+    assert pkg.vcf_set_gts(gt, a, "./.").equals(vo.vcf_set_gts(gt, a, "./."))
+    assert pkg.vcf_set_gts(gt, b, ".").equals(vo.vcf_set_gts(gt, b, "."))
+    # udfs.rs:1112-1162 vectors
+    L = pa.list_(pa.field("item", pa.int32(), True))
+    gq = pa.array([[30, 20, 10], [5, None, 15]], type=L)
+    dp = pa.array([[50, 30, 20], [10, 200, 100]], type=L)
+    g2 = pa.array([["0/1", "1/1", "0/0"], ["./.", "0/1", "1/1"]], type=G)
+    assert pkg.vcf_set_gts(g2, pkg.list_gte(gq, 15), "./.").to_pylist() == [["0/1", "1/1", "./."], ["./.", "0/1", "1/1"]]
+    assert pkg.list_and(pkg.list_gte(gq, 10), pkg.list_lte(dp, 100)).to_pylist() == [[True, True, True], [False, False, True]]
+
+
 def test_list_udfs_device_resident(pkg, vo, tmp_path):
     path = str(tmp_path / "samples.vcf.gz")
     _synth(tmp_path, "samples", path, 300, 120, 9)
