@@ -296,7 +296,24 @@ def main():
     synth = os.path.join(ROOT, "tools", "_build", "synth_bam")
     if not os.path.exists(synth):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    # the synthetic file (~26 KB per member) goes to /dev/shm when every local rank's file fits there with room to
+    # spare, else to /tmp; if neither has the space the member count per rank is reduced and reported as such
+    need = int(args.blocks * 27000 * 1.15) * max(1, world)
+    shm = None
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK):
+                vfs = os.statvfs(cand)
+                if vfs.f_bavail * vfs.f_frsize > need:
+                    shm = cand
+                    break
+        except OSError:
+            pass
+    if shm is None:
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        vfs = os.statvfs(shm)
+        fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / max(1, world) / (27000 * 1.15))
+        args.blocks = max(4096, min(args.blocks, fit))
     path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.bam")
     ncpu = os.cpu_count() or 1
     gen_threads = max(1, min(16, ncpu // max(1, world if world > 1 else 1)))
