@@ -341,7 +341,6 @@ static void throw_extract_err(uint32_t e) {
     case 5: throw Error("BAM read error: duplicate optional field tag in one record");
     case 6: throw Error("Arrow error: tag value type mismatch");
     case 7: throw Error("Arrow error: tag value does not fit the column type");
-    case 8: throw Error("Arrow error: float tag in a Utf8 column is not supported on device yet");
     default: throw Error("BAM read error: device error " + std::to_string(e));
   }
 }

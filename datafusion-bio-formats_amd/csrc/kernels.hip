@@ -7,6 +7,7 @@
 // (i & 63) of wave (i >> 6), so fixed-width columns and validity words are written fully
 // coalesced and one wave owns exactly one 64-bit validity word per nullable column.
 #include "kernels.h"
+#include "f32_display.h"
 #include "../../include/bioscan.h"
 
 namespace bioscan {
@@ -1041,7 +1042,7 @@ __device__ __forceinline__ uint32_t dec_write_i64(uint8_t* d, int64_t x) {
 }
 
 // Utf8 tag builder (sam_tag_io.rs:658-732): Z/H -> string (invalid UTF-8 -> NULL), A -> 1 char,
-// ints -> the Unicode char of that code point if valid else decimal; f -> not supported on device yet.
+// ints -> the Unicode char of that code point if valid else decimal; f -> Rust's f32 Display (f32_display.h).
 __global__ void k_tag_utf8_len(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t row0, uint64_t n,
                                const uint32_t* __restrict__ loc, const uint8_t* __restrict__ typ, uint32_t* __restrict__ len,
                                uint64_t* __restrict__ valid, uint32_t* err) {
@@ -1061,7 +1062,8 @@ __global__ void k_tag_utf8_len(const uint8_t* __restrict__ u, const uint64_t* __
       } else if (ty == 'A') {
         v = true; l = utf8_len_cp(p[0]);
       } else if (ty == 'f') {
-        atomicExch(err, 8u);  // Rust f32::to_string on device: not implemented
+        uint8_t tmp[56];
+        v = true; l = f32disp::f32_display(ld_u32(p), tmp);  // Rust f32::to_string
       } else if (ty == 'B') {
         atomicExch(err, 6u);
       } else {
@@ -1095,6 +1097,10 @@ __global__ void k_tag_utf8_scatter(const uint8_t* __restrict__ u, const uint64_t
     for (uint32_t k = 0; p[k]; k++) d[k] = p[k];
   } else if (ty == 'A') {
     utf8_write_cp(d, p[0]);
+  } else if (ty == 'f') {
+    uint8_t tmp[56];
+    const uint32_t l = f32disp::f32_display(ld_u32(p), tmp);
+    for (uint32_t k = 0; k < l; k++) d[k] = tmp[k];
   } else {
     const int64_t x = aux_int(p, ty);
     if (valid_scalar_cp(x)) utf8_write_cp(d, (uint32_t)x); else dec_write_i64(d, x);

@@ -429,15 +429,57 @@ class TagError(Exception):
 
 
 def _f32_to_string(v: float) -> str:
-    """Rust `f32::to_string()` (shortest round-trip, no exponent for ordinary magnitudes)."""
-    import numpy as np
-    f = np.float32(v)
-    if np.isnan(f):
-        return "NaN"
-    if np.isinf(f):
-        return "inf" if f > 0 else "-inf"
-    s = np.format_float_positional(f, unique=True, trim="-")
-    return s
+    """Rust `f32::to_string()` (core::fmt Display for f32 -> flt2dec::to_shortest_str): the shortest digit string whose
+    value rounds back to the same f32 (interval ends included when the mantissa is even, as `decode` sets `inclusive`),
+    the candidate closest to the exact value, printed positionally with no exponent; "NaN", "inf", "-inf", "-0".
+    ASSUMPTION (core is not part of the reference tree): when the two shortest candidates are exactly equidistant
+    (e.g. 343126.125f32 -> 343126.12 / 343126.13) the upper one is taken, which is what flt2dec's Grisu-with-Dragon-
+    fallback does (`up && (!down || 2*mant >= scale)`); Ryu-style printers (numpy) round such ties to even instead.
+    Restated as a search over digit counts with exact rationals (not the digit-generation loop the device code uses)."""
+    import struct
+    from fractions import Fraction
+    bits = struct.unpack("<I", struct.pack("<f", v))[0]
+    neg, be, frac = bits >> 31, (bits >> 23) & 0xFF, bits & 0x7FFFFF
+    if be == 0xFF:
+        return "NaN" if frac else ("-inf" if neg else "inf")
+    sign = "-" if neg else ""
+    if be == 0 and frac == 0:
+        return sign + "0"
+    m, e = ((frac | 0x800000), be - 150) if be else (frac, -149)
+    two = Fraction(2) ** e
+    val = m * two
+    hi = val + two / 2
+    lo = val - (two / 4 if (frac == 0 and be > 1) else two / 2)
+    incl = (m & 1) == 0
+    inside = (lambda x: lo <= x <= hi) if incl else (lambda x: lo < x < hi)
+    k = 0  # 10^(k-1) <= val < 10^k
+    while Fraction(10) ** k <= val:
+        k += 1
+    while Fraction(10) ** (k - 1) > val:
+        k -= 1
+    for n in range(1, 12):
+        q = k - n
+        unit = Fraction(10) ** q
+        f = val / unit
+        c0 = f.numerator // f.denominator
+        c1 = c0 if f.denominator == 1 else c0 + 1
+        ok0, ok1 = c0 > 0 and inside(c0 * unit), inside(c1 * unit)
+        if not (ok0 or ok1):
+            continue
+        if ok0 and ok1:
+            c = c1 if (c1 * unit - val) <= (val - c0 * unit) else c0
+        else:
+            c = c0 if ok0 else c1
+        while c % 10 == 0:
+            c //= 10
+            q += 1
+        ds = str(c)
+        if q >= 0:
+            return sign + ds + "0" * q
+        if len(ds) <= -q:
+            return sign + "0." + "0" * (-q - len(ds)) + ds
+        return sign + ds[:q] + "." + ds[q:]
+    raise AssertionError("f32 display: no round-tripping digit string found")
 
 
 _LIST_RANGE = {"Int8": (-128, 127), "UInt8": (0, 255), "Int16": (-32768, 32767), "UInt16": (0, 65535),

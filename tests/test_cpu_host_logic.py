@@ -149,3 +149,48 @@ def test_shard_partitions_in_order(pkg):
         assert len(runs) == world
         assert [i for r in runs for i in r] == list(range(len(w)))   # contiguous, ordered, complete
         assert sum(1 for r in runs if r) == min(world, len(w))
+
+
+def test_f32_display_header_matches_oracle_and_numpy(oracle, tmp_path):
+    """csrc/f32_display.h (Rust f32::to_string on device) compiled for the host: known answers, the oracle's exact
+    rational search, and numpy's shortest printer (which differs only on exact ties, by one unit in the last place)."""
+    import ctypes
+    import subprocess
+    import numpy as np
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "f32_display.h"\n'
+                   'extern "C" void many(const uint32_t* b, uint64_t n, uint8_t* out, uint32_t* len) {\n'
+                   '  for (uint64_t i = 0; i < n; i++) len[i] = f32disp::f32_display(b[i], out + i * 56); }\n')
+    so = str(tmp_path / "t.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I", os.path.join(root, "datafusion-bio-formats_amd", "csrc"), str(src), "-o", so])
+    lib = ctypes.CDLL(so)
+
+    def disp(bits):
+        n = len(bits)
+        out = np.zeros(n * 56, np.uint8)
+        ln = np.zeros(n, np.uint32)
+        lib.many(bits.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(n), out.ctypes.data_as(ctypes.c_void_p), ln.ctypes.data_as(ctypes.c_void_p))
+        return [bytes(out[i * 56:i * 56 + ln[i]]).decode() for i in range(n)]
+
+    kats = [(1.0, "1"), (0.1, "0.1"), (1e-7, "0.0000001"), (3.4028235e38, "340282350000000000000000000000000000000"),
+            (1.1754944e-38, "0.000000000000000000000000000000000000011754944"), (1e-45, "0.000000000000000000000000000000000000000000001"),
+            (16777216.0, "16777216"), (0.3, "0.3"), (1.5, "1.5"), (-0.0, "-0"), (0.0, "0"), (8999999488.0, "9000000000"),
+            (9000000512.0, "9000001000"), (-2.5, "-2.5"), (1e20, "100000000000000000000"), (343126.125, "343126.13"),
+            (float("nan"), "NaN"), (float("inf"), "inf"), (float("-inf"), "-inf")]
+    got = disp(np.array([k for k, _ in kats], np.float32).view(np.uint32))
+    for (k, w), g in zip(kats, got):
+        assert g == w and oracle._f32_to_string(k) == w, (k, g, w)
+    rng = np.random.default_rng(5)
+    bits = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64).astype(np.uint32)
+    extra = [(e << 23) | f for e in range(255) for f in (0, 1, 0x7FFFFF, 0x400000)]
+    bits = np.concatenate([bits, np.array(extra, np.uint32)])
+    ties = 0
+    for g, f in zip(disp(bits), bits.view(np.float32)):
+        assert g == oracle._f32_to_string(float(f)), (float(f), g)
+        if np.isfinite(f):
+            w = np.format_float_positional(f, unique=True, trim="-")
+            if w != g:
+                ties += 1
+                assert len(w) == len(g) and int(g.replace(".", "").replace("-", "")) - int(w.replace(".", "").replace("-", "")) == 1, (g, w)
+    assert ties < 100
