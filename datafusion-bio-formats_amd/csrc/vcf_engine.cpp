@@ -99,6 +99,8 @@ struct VcfProvider : BgzfSource, VcfProviderI {
   bool has_index = false;
   std::string index_path;
   Tbi tbi;
+  bool index_readable = false;   // the tabix reader accepted the index (a CSI, or an unreadable file, only fails at execute)
+  std::string index_error;
   std::vector<std::string> contig_names;
   std::vector<uint64_t> contig_lengths;
 
@@ -248,7 +250,7 @@ VcfPlanI* VcfProvider::scan(const int32_t* projection, int32_t n_projection, con
     if (regions.empty())
       for (auto& n : contig_names) { GenomicRegion r; r.chrom = n; regions.push_back(r); }
     if (!regions.empty()) {
-      auto est = estimate_sizes_from_tbi(&tbi, regions, contig_names, contig_lengths);
+      auto est = estimate_sizes_from_tbi(index_readable ? &tbi : nullptr, regions, contig_names, contig_lengths);
       pl->assignments = balance_partitions(est, (size_t)std::max(target_partitions, 0));
       for (auto& f : fs) if (vcf_can_push_down(f, sch.fields)) pl->residual.push_back(f);
       pl->indexed = true;
@@ -578,6 +580,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
   std::vector<RegionQuery> queries;
   uint64_t lo_abs = p.hdr.header_bytes, E_abs = p.text_len();
   bool nothing = false;
+  if (indexed && !p.index_readable) throw Error("Failed to open indexed VCF: " + p.index_error);  // physical_exec.rs:2766-2768
   if (indexed) {
     uint64_t mn = ~0ull, mx = 0;
     for (auto& r : assignments[(size_t)partition].regions) {
@@ -1459,19 +1462,30 @@ VcfProviderI* vcf_open(const char* path, const bioscan_vcf_options* o) {
   if (p.has_index) {
     std::string lower = p.index_path;
     for (auto& ch : lower) ch = (char)tolower(ch);
-    if (lower.size() >= 4 && lower.compare(lower.size() - 4, 4, ".csi") == 0)
-      throw Error("Failed to open indexed VCF: CSI indexes are not supported for text VCF (the reference opens them with the tabix reader and fails too)");
-    // the index is BGZF itself: it is inflated by the same GPU kernel
-    BgzfSource ix;
-    ix.what = "tabix index";
-    ix.path = p.index_path;
-    ix.device = p.device;
-    ix.load_file();
-    ix.frame();
-    std::vector<uint8_t> raw = ix.inflate_prefix_to_host(ix.n_blocks());
-    std::string e;
-    if (!parse_tbi(raw, &p.tbi, &e)) throw Error("Failed to open indexed VCF: " + e);
-    index_names = p.tbi.names;
+    const bool csi = lower.size() >= 4 && lower.compare(lower.size() - 4, 4, ".csi") == 0;  // table_provider.rs:970-974
+    // An index that cannot be read is not an error here: the reference logs it and carries on with no index names
+    // (table_provider.rs:1012-1024); the scan then plans with unit estimates (storage.rs:826-840) and every partition
+    // fails when it opens the index (IndexedVcfReader::new, storage.rs:766).  A CSI only contributes its names.
+    try {
+      // the index is BGZF itself: it is inflated by the same GPU kernel
+      BgzfSource ix;
+      ix.what = csi ? "CSI index" : "tabix index";
+      ix.path = p.index_path;
+      ix.device = p.device;
+      ix.load_file();
+      ix.frame();
+      std::vector<uint8_t> raw = ix.inflate_prefix_to_host(ix.n_blocks());
+      std::string e;
+      if (csi) {
+        if (parse_csi_names(raw, &index_names, &e)) e = "invalid tabix header (the file is a CSI index; the VCF text reader only accepts tabix)";
+        p.index_error = e;
+      } else if (parse_tbi(raw, &p.tbi, &e)) {
+        p.index_readable = true;
+        index_names = p.tbi.names;
+      } else p.index_error = e;
+    } catch (const Error& ex) {
+      p.index_error = ex.what();
+    }
     if (!index_names.empty()) {  // table_provider.rs:1037-1075
       std::vector<uint64_t> lens;
       for (auto& n : index_names) {

@@ -349,6 +349,26 @@ std::string determine_vcf_schema(const VcfHeader& h, const std::vector<std::stri
 }
 
 // ---- tabix ---------------------------------------------------------------------------------------
+bool parse_csi_names(const std::vector<uint8_t>& d, std::vector<std::string>* names, std::string* err) {
+  names->clear();
+  if (d.size() < 16 || memcmp(d.data(), "CSI\1", 4) != 0) { *err = "invalid CSI header"; return false; }
+  int32_t l_aux;
+  memcpy(&l_aux, d.data() + 12, 4);
+  if (l_aux < 0 || 16 + (size_t)l_aux > d.size()) { *err = "truncated CSI index"; return false; }
+  if (l_aux < 28) return true;  // no tabix-style aux block: no names
+  int32_t l_nm;
+  memcpy(&l_nm, d.data() + 16 + 24, 4);
+  if (l_nm < 0 || 28 + (size_t)l_nm > (size_t)l_aux) { *err = "truncated CSI index"; return false; }
+  size_t p = 16 + 28, e = p + (size_t)l_nm;
+  while (p < e) {
+    const uint8_t* z = (const uint8_t*)memchr(d.data() + p, 0, e - p);
+    size_t q = z ? (size_t)(z - d.data()) : e;
+    names->emplace_back((const char*)d.data() + p, q - p);
+    p = q + 1;
+  }
+  return true;
+}
+
 bool parse_tbi(const std::vector<uint8_t>& d, Tbi* out, std::string* err) {
   *out = Tbi();
   if (d.size() < 36 || memcmp(d.data(), "TBI\1", 4) != 0) { *err = "invalid tabix header"; return false; }

@@ -69,6 +69,10 @@ struct Tbi {
   int32_t format = 0, col_seq = 0, col_beg = 0, col_end = 0, meta = 0, skip = 0;
 };
 bool parse_tbi(const std::vector<uint8_t>& inflated, Tbi* out, std::string* err);
+// CSI header (`CSI\1`, min_shift, depth, l_aux, aux = the tabix header with the reference names): only the names are
+// used — the reference reads them for `bio.vcf.contigs.indexed` (table_provider.rs:1019-1025) and then hands the file
+// to the tabix reader, which rejects it (storage.rs:766).
+bool parse_csi_names(const std::vector<uint8_t>& inflated, std::vector<std::string>* names, std::string* err);
 // bio-format-vcf/src/storage.rs:815-986
 std::vector<RegionSizeEstimate> estimate_sizes_from_tbi(const Tbi* tbi, const std::vector<GenomicRegion>& regions,
                                                         const std::vector<std::string>& contig_names,

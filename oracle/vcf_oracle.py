@@ -241,6 +241,18 @@ def parse_tbi(raw: bytes) -> Tbi:
     return Tbi(names, refs, n_no_coor, (fmt, col_seq, col_beg, col_end, meta, skip))
 
 
+def parse_csi_names(raw: bytes):
+    """Reference names from a CSI header's tabix-style aux block (CSI spec: magic, min_shift, depth, l_aux, aux)."""
+    d = bgzf_decompress(raw)
+    if d[:4] != b"CSI\x01":
+        raise ValueError("bad CSI magic")
+    l_aux = struct.unpack_from("<i", d, 12)[0]
+    if l_aux < 28:
+        return []
+    l_nm = struct.unpack_from("<i", d, 16 + 24)[0]
+    return [s.decode() for s in d[44:44 + l_nm].split(b"\x00")[:-1]] if l_nm else []
+
+
 def tbi_query_chunks(tbi: Tbi, ref_idx: int, start1: Optional[int], end1: Optional[int]):
     """noodles-csi BinningIndex::query for min_shift 14 / depth 5 (same scheme as BAI)."""
     s = start1 if start1 is not None else 1
@@ -569,18 +581,33 @@ class VcfOracle:
                         break
         elif index_path:
             self.index_path = index_path
+        # table_provider.rs:1011-1075: reference names from the TBI or CSI header; an index that cannot be read is only
+        # logged there.  The scan then plans with unit estimates (storage.rs:826-840) and each partition fails when
+        # IndexedVcfReader::new hands the file to the tabix reader (storage.rs:766; a CSI is rejected by it too).
         self.tbi = None
-        if self.index_path and not self.index_path.lower().endswith(".csi"):
-            with open(self.index_path, "rb") as f:
-                self.tbi = parse_tbi(f.read())
+        self.index_error = None
+        index_names = []
+        if self.index_path:
+            try:
+                with open(self.index_path, "rb") as f:
+                    raw = f.read()
+                if self.index_path.lower().endswith(".csi"):
+                    index_names = parse_csi_names(raw)
+                    self.index_error = "invalid tabix header (CSI index)"
+                else:
+                    self.tbi = parse_tbi(raw)
+                    index_names = list(self.tbi.names)
+            except Exception as e:  # noqa: BLE001 - any read/parse failure is soft at open
+                self.tbi = None
+                self.index_error = str(e)
         self.contig_names = [c[0] for c in h.contigs]
         self.contig_lengths = [c[1] or 0 for c in h.contigs]
         self._indexed_names = None
-        if self.tbi is not None and self.tbi.names:
+        if index_names:
             by_name = {c[0]: c[1] for c in h.contigs if c[1] is not None}
-            self.contig_lengths = [by_name.get(n, 0) for n in self.tbi.names]
-            self.contig_names = list(self.tbi.names)
-            self._indexed_names = list(self.tbi.names)
+            self.contig_lengths = [by_name.get(n, 0) for n in index_names]
+            self.contig_names = list(index_names)
+            self._indexed_names = list(index_names)
         self.schema = self._determine_schema()
 
     # ---- schema ------------------------------------------------------------------------------------
@@ -977,6 +1004,8 @@ class VcfOracle:
             recs = (Rec(t) for _, t in self._lines_from(self.data_start))
             return self._batches(recs, projection, batch_size, limit)
         residual = plan["residual"]
+        if self.tbi is None:  # physical_exec.rs:2766-2768
+            raise VcfError(f"Failed to open indexed VCF: {self.index_error}")
 
         def gen():
             for region in plan["assignments"][partition].regions:

@@ -218,3 +218,22 @@ def test_c_vcf_oracle_matches_python_oracle(tmp_path):
                 assert r["gq_gte_true"] == sum(bool(x) for row in V.list_gte(gq, 10).to_pylist() for x in row)
                 assert r["dp_gte_true"] == sum(bool(x) for row in V.list_gte(dp, 10).to_pylist() for x in row)
                 assert r["dp_lte_true"] == sum(bool(x) for row in V.list_lte(dp, 200).to_pylist() for x in row)
+
+
+def test_csi_index_contributes_names_only():
+    """indexed_read_test.rs:380-417: a `.csi` companion populates `bio.vcf.contigs.indexed`; the text-VCF reader then
+    hands it to the tabix reader (storage.rs:766), so an indexed partition fails when it is executed."""
+    import json
+    o = V.VcfOracle(os.path.join(GOLD, "multi_chrom_csi.vcf.gz"))
+    assert o.index_path.endswith(".csi")
+    assert sorted(json.loads(o.schema.metadata[b"bio.vcf.contigs.indexed"])) == ["21", "22"]
+    plan = o.scan(target_partitions=4)
+    assert plan["kind"] == "indexed" and o.num_partitions(plan) == 2
+    assert [a.total_estimated_bytes for a in plan["assignments"]] == [1, 1]
+    with pytest.raises(V.VcfError):
+        o.execute(plan, 0)
+    # without the index the same file scans sequentially: 1000 variants like multi_chrom.vcf.gz
+    o2 = V.VcfOracle(os.path.join(GOLD, "multi_chrom_csi.vcf.gz"), index_path=None)
+    assert b"bio.vcf.contigs.indexed" not in o2.schema.metadata
+    _, batches = o2.execute(o2.scan())
+    assert sum(b.num_rows for b in batches) == 1000

@@ -345,7 +345,7 @@ def test_vcf_errors_are_loud(pkg, tmp_path):
         with pytest.raises(pkg.BioscanError) as ei:
             run(body)
         assert msg.lower() in str(ei.value).lower(), (body, str(ei.value))
-    # plain gzip (no BGZF block structure) and CSI indexes are refused at open
+    # plain gzip (no BGZF block structure) is refused at open; a CSI index only at execute (as the reference's tabix reader does)
     gz = tmp_path / "plain.vcf.gz"
     gz.write_bytes(gzip.compress((hdr + "c\t5\t.\tA\tT\t.\t.\tDP=3\n").encode()))
     with pytest.raises(pkg.BioscanError) as ei:
@@ -354,9 +354,8 @@ def test_vcf_errors_are_loud(pkg, tmp_path):
     bg = tmp_path / "b.vcf.gz"
     bg.write_bytes(bgzf_compress((hdr + "c\t5\t.\tA\tT\t.\t.\tDP=3\n").encode()))
     (tmp_path / "b.vcf.gz.csi").write_bytes(b"CSI\x01")
-    with pytest.raises(pkg.BioscanError) as ei:
-        pkg.VcfTableProvider(str(bg))
-    assert "CSI" in str(ei.value)
+    prov = pkg.VcfTableProvider(str(bg))  # unreadable index + no ##contig lines: no regions, so the sequential fallback runs
+    assert sum(b.num_rows for b in prov.scan().execute(0, 8192)) == 1
     # an INFO tag that the header does not define is refused (the reference unwraps the lookup and panics)
     with pytest.raises(pkg.BioscanError):
         pkg.VcfTableProvider(str(tmp_path / "x.vcf"), ["NOPE"])
@@ -403,3 +402,49 @@ def test_vcf_multi_gpu_sharding_reproduces_single_gpu_order(pkg, vo, tmp_path):
         for rank in range(world):
             multi += rows_of(plan, shards[rank])
         assert multi == single and len(single) == 12000
+
+
+def test_csi_and_unreadable_indexes(pkg, vo, tmp_path):
+    """A CSI companion only contributes `bio.vcf.contigs.indexed` (indexed_read_test.rs:380-417); an index the tabix
+    reader rejects is soft at open and loud at execute (table_provider.rs:1012-1024, physical_exec.rs:2766-2768)."""
+    path = os.path.join(G, "multi_chrom_csi.vcf.gz")
+    o = vo.VcfOracle(path)
+    g = pkg.VcfTableProvider(path)
+    _schema_equal(g.schema(), o.schema)
+    assert sorted(json.loads(g.schema().metadata[b"bio.vcf.contigs.indexed"])) == ["21", "22"]
+    for target, filters in ((4, []), (1, [("chrom", "=", "21")])):
+        gp, op = g.scan(filters=filters, target_partitions=target), o.scan(filters=filters, target_partitions=target)
+        assert gp.num_partitions() == o.num_partitions(op)
+        with pytest.raises(vo.VcfError):
+            o.execute(op, 0)
+        with pytest.raises(RuntimeError, match="Failed to open indexed VCF"):
+            list(gp.execute(0, 8192))
+    # no index: the sequential scan of the same file
+    kw = dict(index_path=None)
+    o2 = vo.VcfOracle(path, **kw)
+    g2 = pkg.VcfTableProvider(path, None, None, None, True, None, "")
+    _schema_equal(g2.schema(), o2.schema)
+    got = list(g2.scan().execute(0, 8192))
+    _, want = o2.execute(o2.scan())
+    _cmp_partition(got, want, "csi-sequential")
+    assert sum(b.num_rows for b in got) == 1000
+    # garbage given as the index
+    bad = tmp_path / "bad.tbi"
+    bad.write_bytes(bgzf_compress(b"not an index at all"))
+    src = os.path.join(G, "multi_chrom.vcf.gz")
+    o3 = vo.VcfOracle(src, index_path=str(bad))
+    g3 = pkg.VcfTableProvider(src, None, None, None, True, None, str(bad))
+    _schema_equal(g3.schema(), o3.schema)
+    assert b"bio.vcf.contigs.indexed" not in (g3.schema().metadata or {})
+    gp, op = g3.scan(target_partitions=2), o3.scan(target_partitions=2)
+    assert gp.num_partitions() == o3.num_partitions(op)
+    with pytest.raises(vo.VcfError):
+        o3.execute(op, 0)
+    with pytest.raises(RuntimeError, match="Failed to open indexed VCF"):
+        list(gp.execute(0, 8192))
+    missing = str(tmp_path / "nope.tbi")
+    g4 = pkg.VcfTableProvider(src, None, None, None, True, None, missing)
+    o4 = vo.VcfOracle(src, index_path=missing)
+    _schema_equal(g4.schema(), o4.schema)
+    with pytest.raises(RuntimeError, match="Failed to open indexed VCF"):
+        list(g4.scan().execute(0, 8192))
