@@ -136,7 +136,16 @@ __device__ __forceinline__ uint32_t ub_take(UBits& s, int n) {
 __device__ __forceinline__ uint64_t ub_bitpos(const UBits& s) { return (uint64_t)s.wpos * 32 - (uint64_t)s.bc; }
 
 // ---- table entries ---------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sym_entry(int sym, int len) { return ((uint32_t)sym << 4) | (uint32_t)len; }
+// symbol entry: code length (minus the root bits for a sub-table entry) [0:3] | symbol code [4:12], where the code is
+// the literal byte, or 0x100 | index into be_lut (length symbol 257+c -> c, distance symbol d -> 32 + d), or
+// SV_EOB for end-of-block: the decode loop never has to subtract 257 or tell the alphabets apart to find base/extra.
+constexpr uint32_t SV_EOB = 0x11Fu;
+__device__ __forceinline__ uint32_t sym_code(int sym, bool is_dist) {
+  if (is_dist) return 0x100u | (32u + (uint32_t)sym);
+  if (sym < 256) return (uint32_t)sym;
+  return sym == 256 ? SV_EOB : (0x100u | (uint32_t)(sym - 257));
+}
+__device__ __forceinline__ uint32_t sym_entry(int sym, int len, bool is_dist) { return (sym_code(sym, is_dist) << 4) | (uint32_t)len; }
 // length symbol s = sym - 257 (0..28) / distance symbol (0..29): base value and extra-bit count (RFC 1951 3.2.5)
 __device__ __forceinline__ void len_base_extra(uint32_t s, uint32_t* base, uint32_t* eb) {
   const uint32_t e = s < 8u ? 0u : (s - 4u) >> 2;
@@ -239,7 +248,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
         const int lm = lens[sm];
         const uint32_t cm = (uint32_t)L.b.t_first[lm] + (m - L.b.t_offs[lm]);
         const uint32_t r = bitrev2(cm, lm) >> root_bits;  // bits after the root, LSB-first
-        const uint16_t e = (uint16_t)sym_entry(sm, lm);
+        const uint16_t e = (uint16_t)sym_entry(sm, lm - root_bits, is_dist);  // the root bits are consumed when the pointer is followed
         for (uint32_t i = r; i < (1u << sbits); i += (1u << (lm - root_bits))) fast[next_free + i] = e;
       }
       next_free += 1u << sbits;
@@ -256,7 +265,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
     if (l <= root_bits) {
       uint32_t c = (uint32_t)L.b.t_first[l] + (k - L.b.t_offs[l]);
       uint32_t r = bitrev2(c, l);
-      const uint16_t e = (uint16_t)sym_entry(sym, l);
+      const uint16_t e = (uint16_t)sym_entry(sym, l, is_dist);
       for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
     }
   }
@@ -282,62 +291,62 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
   // synchronise; the first symbol start at/after count_from is reported and counting restarts there.
   bool seen = pos >= count_from;
   uint32_t first = pos;
-  uint32_t wp = run ? (pos >> 5) : 0u;
-  uint64_t bb;
-  int bc;
 #if V2_GLOBAL_INPUT
 #define V2_SRC(i) gsrc[i]
 #else
 #define V2_SRC(i) L.stage[i]
 #endif
-  uint32_t nxt;  // prefetched dword wp
-  {
-    const uint64_t lo = V2_SRC(wp), hi = V2_SRC(wp + 1);
-    bb = ((hi << 32) | lo) >> (pos & 31);
-    bc = 64 - (int)(pos & 31);
-    wp += 2;
-    nxt = V2_SRC(wp);
-  }
-  // One table lookup per iteration.  A lane is a small state machine: `tb/sh/mb` describe its next lookup
-  // (table base, bits to skip, index width) and `st` says whether it is decoding a literal/length symbol
-  // (0) or the distance of a pending match (1).  A sub-table pointer only re-targets the next lookup, a
-  // length symbol switches the lane to the distance table: lanes in different states share the same
-  // instructions, so a wave never pays for a path only one lane needs.
+  // The lane's bit window is 32 bits starting at `pos`, funnel-shifted out of two input dwords d0 (dword wp) and d1;
+  // `nxt` is dword wp + 2, prefetched.  A symbol consumes <= 28 bits, so pos crosses at most one dword per step.
+  uint32_t wp = run ? (pos >> 5) : 0u;
+  uint32_t d0 = V2_SRC(wp), d1 = V2_SRC(wp + 1), nxt = V2_SRC(wp + 2);
+  // One table lookup per iteration.  A lane is a small state machine: `tb/mb` describe its next lookup (table base,
+  // index width).  tb == 0 is the literal/length root (a symbol boundary), tb == DIST_BASE the distance root of a
+  // pending match, anything else a sub-table (below DIST_BASE: literal/length).  A sub-table pointer consumes the
+  // root bits and re-targets the next lookup, a length symbol switches the lane to the distance table: lanes in
+  // different states share the same instructions, so a wave never pays for a path only one lane needs.
   const uint16_t* __restrict__ T = L.lit_fast;  // dist_fast follows lit_fast in LDS
   constexpr uint32_t DIST_BASE = (1u << V2_LIT_BITS) + V2_LIT_SUB;
-  uint32_t st = 0, tb = 0, sh = 0, mb = V2_LIT_BITS, mlen = 0;
+  uint32_t tb = 0, mb = V2_LIT_BITS, mlen = 0;
   while (__ballot(run) != 0ull) {
-    const bool at_start = st == 0 && sh == 0;
+#ifdef V2_ASM_MARKERS
+    asm volatile("; V2LOOP_BEGIN %0" ::"n"(MODE));
+#endif
+    const bool in_lit = tb < DIST_BASE;
     if (MODE == 0) {
-      const bool cross = run && at_start && !seen && pos >= count_from;
+      const bool cross = run && tb == 0u && !seen && pos >= count_from;
       if (cross) { first = pos; no = 0; nm = 0; }
       seen = seen || cross;
     }
-    // refill to >= 33 bits (reads of finished lanes stay inside the staged region: wp only moves while running)
-    {
-      const bool rf = run && bc <= 32;
-      if (rf) { bb |= (uint64_t)nxt << bc; bc += 32; wp++; nxt = V2_SRC(wp); }
-    }
-    const uint32_t e = T[tb + ((uint32_t)(bb >> sh) & ((1u << mb) - 1u))];
+    const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
+    const uint32_t e = T[tb + __builtin_amdgcn_ubfe(w, 0u, mb)];
     const bool is_ptr = (e & E_SUB) != 0;
-    const uint32_t l = is_ptr ? 0u : (e & 15u);
-    const bool sym = run && l != 0;                       // a real table entry (code length l)
+    const uint32_t l = e & 15u;                            // code length (pointer: index width of the sub-table)
+    const bool sym = run && !is_ptr && l != 0u;            // a real table entry
     const bool sub = run && is_ptr;                        // pointer to a second-level table
     uint32_t bad = (run && e == 0u) ? F_BAD : 0u;
-    const bool in_lit = st == 0;
-    const uint32_t sv = (e >> 4) & 0x1FFu;                // symbol value
-    const bool is_len = sym && in_lit && sv > 256u;
-    const bool is_eob = sym && in_lit && sv == 256u;
-    const bool is_lit = sym && in_lit && sv < 256u;
+    const uint32_t sv = (e >> 4) & 0x1FFu;                 // symbol code (sym_code)
+    const bool hi = sv > 255u;
+    const bool is_eob = sym && in_lit && sv == SV_EOB;
+    const bool is_lit = sym && in_lit && !hi;
+    const bool is_len = sym && in_lit && hi && sv != SV_EOB;
     const bool is_dist = sym && !in_lit;
-    // base | extra bits << 16 | invalid << 24 of the length (sv - 257) or distance (sv) symbol: one LDS read
-    const uint32_t be = L.be_lut[in_lit ? ((sv - 257u) & 31u) : (32u + (sv & 31u))];
+    // base | extra bits << 16 | invalid << 24 of the length or distance symbol: one LDS read
+    const uint32_t be = L.be_lut[sv & 63u];
     const bool inval = (is_len || is_dist) && (be >> 24) != 0;  // symbols 286/287, 30/31 never occur in valid data
     const uint32_t ebv = (is_len || is_dist) && !inval ? ((be >> 16) & 15u) : 0u;
     const uint32_t base = be & 0xFFFFu;
-    const uint32_t extra = (uint32_t)(bb >> l) & ((1u << ebv) - 1u);
-    const uint32_t adv = sym ? l + ebv : 0u;
-    bb >>= adv; bc -= (int)adv; pos += adv;
+    const uint32_t extra = __builtin_amdgcn_ubfe(w, l, ebv);
+    const uint32_t adv = sym ? l + ebv : (sub ? (in_lit ? (uint32_t)V2_LIT_BITS : (uint32_t)V2_DIST_BITS) : 0u);
+    pos += adv;
+    if ((pos >> 5) != wp) {
+      // explicit moves: left to the register allocator, the fresh load is copied into place right away and the
+      // wave waits for it here instead of one crossing later
+      asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));
+      wp++;
+      nxt = V2_SRC(wp + 2);
+    }
     if (inval) bad = F_BAD;
     if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)sv; }
     if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)sv; }
@@ -354,15 +363,16 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     no += produced;
     nm += okm ? 1u : 0u;
     // next lookup
-    if (sub) { tb = (e >> 4) & 0x7FFu; sh = in_lit ? V2_LIT_BITS : V2_DIST_BITS; mb = e & 15u; }
+    if (sub) { tb = (e >> 4) & 0x7FFu; mb = l; }
     if (sym) {
-      st = is_len ? 1u : 0u;
       tb = is_len ? DIST_BASE : 0u;
-      sh = 0;
       mb = is_len ? V2_DIST_BITS : V2_LIT_BITS;
     }
     fl |= bad | (is_eob ? F_EOB : 0u);
-    run = run && fl == 0 && (st != 0 || sh != 0 || pos < limit);
+    run = run && fl == 0 && (tb != 0u || pos < limit);
+#ifdef V2_ASM_MARKERS
+    asm volatile("; V2LOOP_END %0" ::"n"(MODE));
+#endif
   }
   if (active) {
     // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no
