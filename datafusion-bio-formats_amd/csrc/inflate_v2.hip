@@ -23,6 +23,7 @@
 // atomic counter so the per-workgroup match scratch is bounded by residency.
 #include "kernels.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace bioscan {
 
@@ -43,13 +44,24 @@ constexpr int V2_LIT_BITS = 9;                          // zlib's root sizes: EN
 constexpr int V2_DIST_BITS = 6;
 constexpr int V2_MAX_SUB_DW = V2_SUB_DW;                // odd => conflict-free initial LDS reads
 constexpr int V2_WIN = V2_WIN_BYTES;                    // LDS output window of one round (multiple of 16)
-constexpr int V2_STAGE_DW = V2_GLOBAL_INPUT ? 4 : 64 * V2_MAX_SUB_DW + 8;
+constexpr int V2_STAGE_DW = 64 * V2_MAX_SUB_DW + 8;  // only when the input is staged through LDS
 constexpr int V2_LIT_SUB = 352;    // 852 - 512 = 340 sub-table entries at most
 constexpr int V2_DIST_SUB = 528;   // 592 - 64
-// 16-bit table entries (half the LDS of u32 entries: K1 is latency-bound, its speed follows occupancy).
-// symbol entry: len[0:3] | symbol[4:12] (length / distance base and extra bits are recomputed from the symbol in
-// the decode loop); sub-table pointer: E_SUB | index bits[0:3] | absolute table index[4:14]; 0 = no code.
-constexpr uint32_t E_SUB = 0x8000u;
+// 16-bit table entries (half the LDS of u32 entries: more resident waves), laid out so that the decode loop (VALU-issue
+// bound: SQ_INSTS_VALU x 4 cycles = 96 % of K1's cycles) classifies an entry with the fewest instructions:
+//   literal        len[0:3] | byte[4:11]
+//   length / dist  len[0:3] | extra-bit count[4:7] | be_lut index[8:13] | E_HI   (length 257+c -> c, distance d -> 32+d)
+//   end of block   a length-like entry with index 31
+//   sub-table ptr  E_SUB | entry index of the sub-table from lit_fast [4:14] | index width[0:3] (up to 9 for distances)
+//   0 = no code.  `len` of a sub-table entry excludes the root bits (consumed when the pointer is followed).
+constexpr uint32_t E_SUB = 0x8000u, E_HI = 0x4000u, E_EOB_IDX = 31u;
+// Symbols that must not occur in valid data (literal/length 286, 287, distance 30, 31) may be given code lengths by a
+// header; their entries are 0, so using one is an invalid code.
+// A lane that has stopped parks on a null slot: an entry of zero index width that points to itself, so the lane keeps
+// executing the shared instructions without changing state and without a per-lane "running" predicate.  Which slot it
+// parks on says why it stopped.
+constexpr uint32_t V2_NULL_BASE = 2u * ((1u << V2_LIT_BITS) + V2_LIT_SUB + (1u << V2_DIST_BITS) + V2_DIST_SUB) + 64u * 4u;  // byte offset from lit_fast
+constexpr uint32_t STOP_END = V2_NULL_BASE, STOP_EOB = V2_NULL_BASE + 2u, STOP_BAD = V2_NULL_BASE + 4u;
 constexpr uint32_t F_EOB = 1, F_BAD = 2;
 // Waves of one workgroup decode different members and never exchange data: a workgroup only exists to get past
 // the 16-workgroups-per-CU residency cap (K1 is latency-bound, its speed follows the number of resident waves).
@@ -75,8 +87,11 @@ struct V2Build {
 struct __attribute__((aligned(16))) V2Lds {
   uint16_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];
   uint16_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // must follow lit_fast: the decode loop indexes both as one array
-  uint32_t be_lut[64];  // [0..31] length symbols 257.., [32..63] distance symbols: base | extra bits << 16 | invalid << 24
+  uint32_t be_lut[64];  // [0..31] length symbols 257.., [32..63] distance symbols: base value
+  uint16_t null_slot[8];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v2_pass)
+#if !V2_GLOBAL_INPUT
   uint32_t stage[V2_STAGE_DW];
+#endif
 #ifdef V2_PAD_LDS
   uint32_t pad_lds[V2_PAD_LDS / 4];  // occupancy experiment only
 #endif
@@ -135,17 +150,13 @@ __device__ __forceinline__ uint32_t ub_take(UBits& s, int n) {
 }
 __device__ __forceinline__ uint64_t ub_bitpos(const UBits& s) { return (uint64_t)s.wpos * 32 - (uint64_t)s.bc; }
 
+#ifdef V2_GUARD
+__device__ unsigned int v2_guard_word[8];
+#define V2_G(cond, code, val) ((cond) ? (atomicOr(&v2_guard_word[0], 1u << (code)), atomicMax(&v2_guard_word[code], (unsigned)(val)), true) : false)
+#else
+#define V2_G(cond, code, val) false
+#endif
 // ---- table entries ---------------------------------------------------------------------------------
-// symbol entry: code length (minus the root bits for a sub-table entry) [0:3] | symbol code [4:12], where the code is
-// the literal byte, or 0x100 | index into be_lut (length symbol 257+c -> c, distance symbol d -> 32 + d), or
-// SV_EOB for end-of-block: the decode loop never has to subtract 257 or tell the alphabets apart to find base/extra.
-constexpr uint32_t SV_EOB = 0x11Fu;
-__device__ __forceinline__ uint32_t sym_code(int sym, bool is_dist) {
-  if (is_dist) return 0x100u | (32u + (uint32_t)sym);
-  if (sym < 256) return (uint32_t)sym;
-  return sym == 256 ? SV_EOB : (0x100u | (uint32_t)(sym - 257));
-}
-__device__ __forceinline__ uint32_t sym_entry(int sym, int len, bool is_dist) { return (sym_code(sym, is_dist) << 4) | (uint32_t)len; }
 // length symbol s = sym - 257 (0..28) / distance symbol (0..29): base value and extra-bit count (RFC 1951 3.2.5)
 __device__ __forceinline__ void len_base_extra(uint32_t s, uint32_t* base, uint32_t* eb) {
   const uint32_t e = s < 8u ? 0u : (s - 4u) >> 2;
@@ -157,6 +168,19 @@ __device__ __forceinline__ void dist_base_extra(uint32_t s, uint32_t* base, uint
   const uint32_t e = s < 4u ? 0u : (s - 2u) >> 1;
   *eb = e;
   *base = s < 4u ? 1u + s : 1u + ((2u + (s & 1u)) << e);
+}
+__device__ __forceinline__ uint32_t sym_entry(int sym, int len, bool is_dist) {
+  uint32_t base, eb;
+  if (is_dist) {
+    dist_base_extra((uint32_t)sym, &base, &eb);
+    if (sym > 29) return 0u;
+    return E_HI | ((32u + (uint32_t)sym) << 8) | (eb << 4) | (uint32_t)len;
+  }
+  if (sym < 256) return ((uint32_t)sym << 4) | (uint32_t)len;
+  if (sym == 256) return E_HI | (E_EOB_IDX << 8) | (uint32_t)len;
+  len_base_extra((uint32_t)(sym - 257), &base, &eb);
+  if (sym > 285) return 0u;
+  return E_HI | ((uint32_t)(sym - 257) << 8) | (eb << 4) | (uint32_t)len;
 }
 
 // Build the two-level decode table of one alphabet: root table of 2^root_bits entries followed by
@@ -242,7 +266,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
       }
       const uint32_t sbits = (uint32_t)(max_len - root_bits);
       if (next_free + (1u << sbits) > (1u << root_bits) + (uint32_t)sub_cap) { over = 1; break; }
-      fast[bitrev2(prefix, root_bits)] = (uint16_t)(E_SUB | ((abs_off + next_free) << 4) | sbits);
+      fast[bitrev2(prefix, root_bits)] = (uint16_t)(E_SUB | ((abs_off + next_free) << 4) | sbits);  // sbits <= 9 (distance codes)
       for (uint32_t m = k; m < j; m++) {
         const int sm = sorted[m];
         const int lm = lens[sm];
@@ -284,61 +308,57 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
                                         unsigned long long* mlist, uint32_t mpos, uint32_t win_base,
                                         uint32_t count_from, uint32_t& first_out, const uint32_t* __restrict__ gsrc) {
   constexpr bool WRITE = MODE != 0;
+  static_assert(offsetof(V2Lds, null_slot) - offsetof(V2Lds, lit_fast) == V2_NULL_BASE, "null slots must sit at V2_NULL_BASE");
   uint32_t pos = start;
-  uint32_t fl = 0, no = 0, nm = 0;
-  bool run = active && pos < limit;
+  uint32_t no = 0, nm = 0;
+  const bool run0 = active && pos < limit;
   // speculative lanes start `overlap` bits early: symbols that begin before count_from only serve to
   // synchronise; the first symbol start at/after count_from is reported and counting restarts there.
-  bool seen = pos >= count_from;
-  uint32_t first = pos;
+  // first == ~0 means "not reached yet".
+  uint32_t first = pos >= count_from ? pos : 0xFFFFFFFFu;
 #if V2_GLOBAL_INPUT
+#ifdef V2_GUARD
+#define V2_SRC(i) (V2_G((i) > ((limit + 64u) >> 5) + 3u, 1, (i)) ? 0u : gsrc[i])
+#else
 #define V2_SRC(i) gsrc[i]
+#endif
 #else
 #define V2_SRC(i) L.stage[i]
 #endif
   // The lane's bit window is 32 bits starting at `pos`, funnel-shifted out of two input dwords d0 (dword wp) and d1;
   // `nxt` is dword wp + 2, prefetched.  A symbol consumes <= 28 bits, so pos crosses at most one dword per step.
-  uint32_t wp = run ? (pos >> 5) : 0u;
-  uint32_t d0 = V2_SRC(wp), d1 = V2_SRC(wp + 1), nxt = V2_SRC(wp + 2);
-  // One table lookup per iteration.  A lane is a small state machine: `tb/mb` describe its next lookup (table base,
-  // index width).  tb == 0 is the literal/length root (a symbol boundary), tb == DIST_BASE the distance root of a
-  // pending match, anything else a sub-table (below DIST_BASE: literal/length).  A sub-table pointer consumes the
-  // root bits and re-targets the next lookup, a length symbol switches the lane to the distance table: lanes in
-  // different states share the same instructions, so a wave never pays for a path only one lane needs.
-  const uint16_t* __restrict__ T = L.lit_fast;  // dist_fast follows lit_fast in LDS
-  constexpr uint32_t DIST_BASE = (1u << V2_LIT_BITS) + V2_LIT_SUB;
-  uint32_t tb = 0, mb = V2_LIT_BITS, mlen = 0;
-  while (__ballot(run) != 0ull) {
+  // (a lane that does not run keeps pos, so it never crosses and never loads again: its three reads are parked at 0)
+  uint32_t wp = pos >> 5;
+  const uint32_t wp0 = run0 ? wp : 0u;
+  uint32_t d0 = V2_SRC(wp0), d1 = V2_SRC(wp0 + 1), nxt = V2_SRC(wp0 + 2);
+  // One table lookup per iteration.  A lane is a small state machine: `tb/mb` describe its next lookup (byte offset
+  // of the table from lit_fast, index width).  tb == 0 is the literal/length root (a symbol boundary), tb == DIST_BASE
+  // the distance root of a pending match, a value below the null slots a sub-table (below DIST_BASE: literal/length),
+  // a null slot a stopped lane.  A sub-table pointer consumes the root bits and re-targets the next lookup, a length
+  // symbol switches the lane to the distance table, a stopped lane follows its self-pointer for ever: lanes in
+  // different states share the same instructions, so a wave never pays for a path only one lane needs, and there is
+  // no loop-carried predicate (each costs four scalar instructions per step to merge; K1 is bound by VALU + SALU issue).
+  const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;  // dist_fast follows lit_fast in LDS
+  constexpr uint32_t DIST_BASE = 2u * ((1u << V2_LIT_BITS) + V2_LIT_SUB);
+  uint32_t tb = run0 ? 0u : STOP_END, mb = run0 ? (uint32_t)V2_LIT_BITS : 0u, mlen = 0;
+  while (__ballot(tb < V2_NULL_BASE) != 0ull) {
 #ifdef V2_ASM_MARKERS
     asm volatile("; V2LOOP_BEGIN %0" ::"n"(MODE));
 #endif
     const bool in_lit = tb < DIST_BASE;
-    if (MODE == 0) {
-      const bool cross = run && tb == 0u && !seen && pos >= count_from;
-      if (cross) { first = pos; no = 0; nm = 0; }
-      seen = seen || cross;
-    }
     const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
-    const uint32_t e = T[tb + __builtin_amdgcn_ubfe(w, 0u, mb)];
-    const bool is_ptr = (e & E_SUB) != 0;
+    const uint32_t e = *(const uint16_t*)(T + tb + (__builtin_amdgcn_ubfe(w, 0u, mb) << 1));
     const uint32_t l = e & 15u;                            // code length (pointer: index width of the sub-table)
-    const bool sym = run && !is_ptr && l != 0u;            // a real table entry
-    const bool sub = run && is_ptr;                        // pointer to a second-level table
-    uint32_t bad = (run && e == 0u) ? F_BAD : 0u;
-    const uint32_t sv = (e >> 4) & 0x1FFu;                 // symbol code (sym_code)
-    const bool hi = sv > 255u;
-    const bool is_eob = sym && in_lit && sv == SV_EOB;
-    const bool is_lit = sym && in_lit && !hi;
-    const bool is_len = sym && in_lit && hi && sv != SV_EOB;
-    const bool is_dist = sym && !in_lit;
-    // base | extra bits << 16 | invalid << 24 of the length or distance symbol: one LDS read
-    const uint32_t be = L.be_lut[sv & 63u];
-    const bool inval = (is_len || is_dist) && (be >> 24) != 0;  // symbols 286/287, 30/31 never occur in valid data
-    const uint32_t ebv = (is_len || is_dist) && !inval ? ((be >> 16) & 15u) : 0u;
-    const uint32_t base = be & 0xFFFFu;
-    const uint32_t extra = __builtin_amdgcn_ubfe(w, l, ebv);
-    const uint32_t adv = sym ? l + ebv : (sub ? (in_lit ? (uint32_t)V2_LIT_BITS : (uint32_t)V2_DIST_BITS) : 0u);
-    pos += adv;
+    const bool ptr = e >= E_SUB;                           // pointer to a second-level table (or a null slot)
+    const bool lenlike = e - E_HI < E_HI;                  // length / distance / end-of-block entry
+    const bool is_eob = (e & 0xFFF0u) == (E_HI | (E_EOB_IDX << 8));
+    const bool is_lit = e - 1u < 0xFFFu;                   // literal entries are 0x001 .. 0xFFF
+    const bool is_len = lenlike && in_lit && !is_eob;
+    const bool is_dist = lenlike && !in_lit;
+    const uint32_t base = L.be_lut[(e >> 8) & 63u];
+    const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
+    const uint32_t val = base + __builtin_amdgcn_ubfe(w, l, ebv);
+    pos += ptr ? mb : l + ebv;
     if ((pos >> 5) != wp) {
       // explicit moves: left to the register allocator, the fresh load is copied into place right away and the
       // wave waits for it here instead of one crossing later
@@ -347,38 +367,44 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       wp++;
       nxt = V2_SRC(wp + 2);
     }
-    if (inval) bad = F_BAD;
-    if (MODE == 1) { if (is_lit) out[opos] = (uint8_t)sv; }
-    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)sv; }
-    if (is_len) mlen = base + extra;
-    const uint32_t dist = base + extra;
-    bool okm = is_dist && !bad;
+    bool bad = e == 0u;                                    // no such code (a stopped lane never reads a zero entry)
+    if (MODE == 1) { if (is_lit && !V2_G(opos >= win_base, 2, opos)) out[opos] = (uint8_t)(e >> 4); }
+    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 4); }
+    if (is_len) mlen = val;
+    bool okm = is_dist;
     if (WRITE) {
-      if (okm && dist > opos) { bad = F_BAD; okm = false; }
-      if (okm) mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)dist << 44);
+      if (okm && val > opos) { bad = true; okm = false; }
+      if (okm && !V2_G(mpos >= V2_SCRATCH_STRIDE, 3, mpos)) mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)val << 44);
       mpos += okm ? 1u : 0u;
     }
     const uint32_t produced = is_lit ? 1u : (okm ? mlen : 0u);
     opos += produced;
     no += produced;
     nm += okm ? 1u : 0u;
-    // next lookup
-    if (sub) { tb = (e >> 4) & 0x7FFu; mb = l; }
-    if (sym) {
-      tb = is_len ? DIST_BASE : 0u;
-      mb = is_len ? V2_DIST_BITS : V2_LIT_BITS;
+    // next lookup: a completed symbol returns to the literal/length root, or parks if the sub-stream is used up
+    const bool at_end = pos >= limit;
+    uint32_t ntb = is_len ? DIST_BASE : (at_end ? STOP_END : 0u);
+    uint32_t nmb = is_len ? (uint32_t)V2_DIST_BITS : (at_end ? 0u : (uint32_t)V2_LIT_BITS);
+    if (ptr) { ntb = (e >> 3) & 0xFFEu; nmb = l; }
+    if (is_eob) { ntb = STOP_EOB; nmb = 0u; }
+    if (bad) { ntb = STOP_BAD; nmb = 0u; }
+    tb = ntb; mb = nmb;
+    if (MODE == 0) {
+      // the next step starts a symbol at / after count_from: counting restarts there
+      const bool cross = tb == 0u && first == 0xFFFFFFFFu && pos >= count_from;
+      if (cross) { first = pos; no = 0; nm = 0; }
     }
-    fl |= bad | (is_eob ? F_EOB : 0u);
-    run = run && fl == 0 && (tb != 0u || pos < limit);
 #ifdef V2_ASM_MARKERS
     asm volatile("; V2LOOP_END %0" ::"n"(MODE));
 #endif
   }
   if (active) {
-    // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no
-    // valid result, even if it stopped exactly on a true symbol boundary
-    if (!seen) { first = 0xFFFFFFFFu; no = 0; nm = 0; }  // never equals a predecessor's end: forces a re-decode
-    end_out = pos; nout = no; nmatch = nm; flags = fl; first_out = first;
+    // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no valid result,
+    // even if it stopped exactly on a true symbol boundary: first stays ~0, which never equals a predecessor's end
+    // and so forces a re-decode
+    if (first == 0xFFFFFFFFu) { no = 0; nm = 0; }
+    end_out = pos; nout = no; nmatch = nm; first_out = first;
+    flags = tb == STOP_EOB ? F_EOB : (tb == STOP_BAD ? F_BAD : 0u);
   }
 }
 
@@ -407,7 +433,8 @@ __device__ __forceinline__ void st2(uint8_t* p, uint16_t v) { ((u16p*)p)->v = v;
 
 // dependency-ordered copy of <= 64 matches (one per lane)
 __device__ void v2_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
-  const bool valid = lane < nm;
+  bool valid = lane < nm;
+  if (valid && V2_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u, 4, m_dst + m_len)) valid = false;
   const uint32_t src_lo = m_dst - m_dist;
   const uint32_t src_end = src_lo + m_len;
   const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
@@ -481,7 +508,8 @@ __device__ void v2_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst,
 // after R are in the window, so dependency rounds cost LDS latency instead of HBM round trips.
 __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t R, int lane, int nm, uint32_t m_dst,
                                      uint32_t m_len, uint32_t m_dist) {
-  const bool valid = lane < nm;
+  bool valid = lane < nm;
+  if (valid && V2_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u || m_dst < R || m_dst + m_len - R > (uint32_t)V2_WIN, 5, m_dst + m_len)) valid = false;
   const uint32_t src_lo = m_dst - m_dist;
   const uint32_t src_end = src_lo + m_len;
   const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
@@ -570,8 +598,9 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
   // base / extra-bit LUT of the length and distance symbols (RFC 1951 3.2.5), once per wave
   {
     uint32_t base, eb;
-    if (lane < 32) { len_base_extra((uint32_t)lane, &base, &eb); L.be_lut[lane] = lane > 28 ? (1u << 24) : (base | (eb << 16)); }
-    else { dist_base_extra((uint32_t)lane - 32u, &base, &eb); L.be_lut[lane] = lane - 32 > 29 ? (1u << 24) : (base | (eb << 16)); }
+    if (lane < 32) { len_base_extra((uint32_t)lane, &base, &eb); L.be_lut[lane] = lane > 28 ? 0u : base; }
+    else { dist_base_extra((uint32_t)lane - 32u, &base, &eb); L.be_lut[lane] = lane - 32 > 29 ? 0u : base; }
+    if (lane < 8) L.null_slot[lane] = (uint16_t)(E_SUB | (((V2_NULL_BASE >> 1) + (uint32_t)lane) << 4));
   }
   V2_SYNC();
 
@@ -720,7 +749,11 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
         const uint64_t wb = P >> 5;
         const uint32_t nstage = 64 * sub_dw + 6;
         V2_SYNC();
-        if (!V2_GLOBAL_INPUT) for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
+#if !V2_GLOBAL_INPUT
+        for (uint32_t k = lane; k < nstage; k += WAVE) L.stage[k] = base32[wb + k];
+#else
+        (void)nstage;
+#endif
         V2_SYNC();
         TOCK(1);
         const uint32_t rel0 = (uint32_t)(P & 31);
@@ -765,7 +798,11 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
           if (!(ablate & 2u)) {
             uint32_t f_ = 0;
             if (use_win) v2_pass<2>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_, base32 + wb);
+#ifdef V2_GUARD
+            else v2_pass<1>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, isize, 0, f_, base32 + wb);
+#else
             else v2_pass<1>(L, valid && start < limit, start, limit, e2, o2, m2, f2, out, obase, mlist, mbase, opos, 0, f_, base32 + wb);
+#endif
           }
           dbg_passes++;
           if (__ballot(valid && (f2 & F_BAD)) != 0ull) { st = INF_BAD_DIST; break; }
@@ -819,6 +856,15 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
   }
 }
 
+void v2_guard_report() {
+#ifdef V2_GUARD
+  unsigned int w[8] = {0};
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(w, HIP_SYMBOL(v2_guard_word), sizeof w);
+  fprintf(stderr, "[v2 guard] mask=%#x src_idx=%u lit_opos=%u mpos=%u resolve=%u resolve_win=%u\n", w[0], w[1], w[2], w[3], w[4], w[5]);
+#endif
+}
+
 int v2_resident_wg_per_cu() {
   int n = 0;
   // resident WAVES per CU (= members decoded concurrently per CU)
@@ -841,6 +887,9 @@ void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const
   g = (g + V2_WAVES_PER_WG - 1) / V2_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V2_WAVES_PER_WG match lists
   hipLaunchKernelGGL(k_bgzf_inflate_v2, dim3(g), dim3(WAVE * V2_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status, counter,
                      scratch, scratch_stride, dbg, ablate, dbg_block);
+#ifdef V2_GUARD
+  v2_guard_report();
+#endif
 }
 
 }  // namespace bioscan

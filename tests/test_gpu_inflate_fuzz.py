@@ -87,3 +87,34 @@ def test_corrupt_members_are_rejected(pkg):
         pkg.bgzf_inflate(bytes(bad_body))
     with pytest.raises(pkg.BioscanError, match="BGZF"):
         pkg.bgzf_inflate(b"\x1f\x8b\x08\x00" + bytes(40))
+
+
+def test_inflate_handcrafted_huffman_codes(pkg, oracle):
+    """Dynamic blocks whose code lengths zlib's encoder never picks (tests/deflate_build.py): complete but wildly
+    skewed trees with 15-bit literal/length and distance codes (9-bit second-level distance tables), unused symbols
+    with codes, one-symbol distance alphabets, several such blocks per member; every stream is checked with zlib first."""
+    import deflate_build as db
+    rng = random.Random(2024)
+    members, max_code = [], 0
+    for it in range(500):
+        w, hist = db.BitWriter(), bytearray()
+        nblk = rng.randint(1, 3)
+        for b in range(nblk):
+            toks, made = db.random_tokens(rng, rng.choice([1, 50, 3000, 20000]), alphabet=rng.choice([2, 16, 64, 256]), have=len(hist),
+                                          match_prob=rng.choice([0.0, 0.2, 0.5, 0.9]))
+            if len(hist) + made > 65000:
+                toks = [('L', 1)]
+            db.dynamic_block(w, toks, rng, b == nblk - 1, skew=rng.choice([0.3, 0.7, 0.95, 1.0]), extra_symbols=rng.choice([0, 5, 29]))
+            db.apply_tokens(hist, toks)
+        body, payload = w.finish(), bytes(hist)
+        assert zlib.decompress(body, -15) == payload
+        total = 18 + len(body) + 8
+        if total > 65536:
+            continue
+        members.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + body +
+                       struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    assert len(members) > 400
+    data = b"".join(members) + bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    want, _ = oracle.bgzf_inflate_all(data)
+    got, _ = pkg.bgzf_inflate(data)
+    assert got == want
