@@ -51,17 +51,23 @@ constexpr int V2_DIST_SUB = 528;   // 592 - 64
 // bound: SQ_INSTS_VALU x 4 cycles = 96 % of K1's cycles) classifies an entry with the fewest instructions:
 //   literal        len[0:3] | byte[4:11]
 //   length / dist  len[0:3] | extra-bit count[4:7] | be_lut index[8:13] | E_HI   (length 257+c -> c, distance d -> 32+d)
-//   end of block   a length-like entry with index 31
+//   end of block   a pointer to the STOP_EOB null slot (E_EOB)
 //   sub-table ptr  E_SUB | entry index of the sub-table from lit_fast [4:14] | index width[0:3] (up to 9 for distances)
-//   0 = no code.  `len` of a sub-table entry excludes the root bits (consumed when the pointer is followed).
-constexpr uint32_t E_SUB = 0x8000u, E_HI = 0x4000u, E_EOB_IDX = 31u;
+//   `len` of a sub-table entry excludes the root bits (consumed when the pointer is followed).
+constexpr uint32_t E_SUB = 0x8000u, E_HI = 0x4000u;
 // Symbols that must not occur in valid data (literal/length 286, 287, distance 30, 31) may be given code lengths by a
-// header; their entries are 0, so using one is an invalid code.
+// header; their entries are E_BAD, so using one is an invalid code.
 // A lane that has stopped parks on a null slot: an entry of zero index width that points to itself, so the lane keeps
 // executing the shared instructions without changing state and without a per-lane "running" predicate.  Which slot it
 // parks on says why it stopped.
 constexpr uint32_t V2_NULL_BASE = 2u * ((1u << V2_LIT_BITS) + V2_LIT_SUB + (1u << V2_DIST_BITS) + V2_DIST_SUB) + 64u * 4u;  // byte offset from lit_fast
 constexpr uint32_t STOP_END = V2_NULL_BASE, STOP_EOB = V2_NULL_BASE + 2u, STOP_BAD = V2_NULL_BASE + 4u;
+// "no such code" is a pointer to the STOP_BAD slot: hitting it parks the lane there, the decode loop has no test for it
+constexpr uint32_t E_BAD = E_SUB | ((STOP_BAD >> 1) << 4);
+// End-of-block is a pointer to the STOP_EOB slot as well.  Following a pointer consumes the index width of the table
+// it sits in, not the code's length: the table build records the difference in V2Lds::eob_fix and the pass subtracts
+// it from the lane's end position.
+constexpr uint32_t E_EOB = E_SUB | ((STOP_EOB >> 1) << 4);
 constexpr uint32_t F_EOB = 1, F_BAD = 2;
 // Waves of one workgroup decode different members and never exchange data: a workgroup only exists to get past
 // the 16-workgroups-per-CU residency cap (K1 is latency-bound, its speed follows the number of resident waves).
@@ -88,7 +94,8 @@ struct __attribute__((aligned(16))) V2Lds {
   uint16_t lit_fast[(1 << V2_LIT_BITS) + V2_LIT_SUB];
   uint16_t dist_fast[(1 << V2_DIST_BITS) + V2_DIST_SUB];  // must follow lit_fast: the decode loop indexes both as one array
   uint32_t be_lut[64];  // [0..31] length symbols 257.., [32..63] distance symbols: base value
-  uint16_t null_slot[8];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v2_pass)
+  uint16_t null_slot[7];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v2_pass)
+  uint16_t eob_fix;       // bits a lane over-consumed when it followed the end-of-block pointer (see E_EOB)
 #if !V2_GLOBAL_INPUT
   uint32_t stage[V2_STAGE_DW];
 #endif
@@ -173,13 +180,13 @@ __device__ __forceinline__ uint32_t sym_entry(int sym, int len, bool is_dist) {
   uint32_t base, eb;
   if (is_dist) {
     dist_base_extra((uint32_t)sym, &base, &eb);
-    if (sym > 29) return 0u;
+    if (sym > 29) return E_BAD;
     return E_HI | ((32u + (uint32_t)sym) << 8) | (eb << 4) | (uint32_t)len;
   }
   if (sym < 256) return ((uint32_t)sym << 4) | (uint32_t)len;
-  if (sym == 256) return E_HI | (E_EOB_IDX << 8) | (uint32_t)len;
+  if (sym == 256) return E_EOB;
   len_base_extra((uint32_t)(sym - 257), &base, &eb);
-  if (sym > 285) return 0u;
+  if (sym > 285) return E_BAD;
   return E_HI | ((uint32_t)(sym - 257) << 8) | (eb << 4) | (uint32_t)len;
 }
 
@@ -190,7 +197,7 @@ __device__ __forceinline__ uint32_t sym_entry(int sym, int len, bool is_dist) {
 __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, uint32_t abs_off, int root_bits, int sub_cap,
                         uint16_t* sorted, uint16_t* count, bool is_dist, int lane) {
   V2_SYNC();
-  for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = 0;
+  for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = (uint16_t)E_BAD;  // bit patterns no code maps to
   if (lane < 16) count[lane] = 0;
   V2_SYNC();
   // 1. histogram of code lengths: 64 symbols per step, one ballot per length value; lane L keeps count[L]
@@ -273,6 +280,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
         const uint32_t cm = (uint32_t)L.b.t_first[lm] + (m - L.b.t_offs[lm]);
         const uint32_t r = bitrev2(cm, lm) >> root_bits;  // bits after the root, LSB-first
         const uint16_t e = (uint16_t)sym_entry(sm, lm - root_bits, is_dist);  // the root bits are consumed when the pointer is followed
+        if (!is_dist && sm == 256) L.eob_fix = (uint16_t)(sbits - (uint32_t)(lm - root_bits));
         for (uint32_t i = r; i < (1u << sbits); i += (1u << (lm - root_bits))) fast[next_free + i] = e;
       }
       next_free += 1u << sbits;
@@ -290,6 +298,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
       uint32_t c = (uint32_t)L.b.t_first[l] + (k - L.b.t_offs[l]);
       uint32_t r = bitrev2(c, l);
       const uint16_t e = (uint16_t)sym_entry(sym, l, is_dist);
+      if (!is_dist && sym == 256) L.eob_fix = (uint16_t)(root_bits - l);
       for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
     }
   }
@@ -351,10 +360,9 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     const uint32_t l = e & 15u;                            // code length (pointer: index width of the sub-table)
     const bool ptr = e >= E_SUB;                           // pointer to a second-level table (or a null slot)
     const bool lenlike = e - E_HI < E_HI;                  // length / distance / end-of-block entry
-    const bool is_eob = (e & 0xFFF0u) == (E_HI | (E_EOB_IDX << 8));
-    const bool is_lit = e - 1u < 0xFFFu;                   // literal entries are 0x001 .. 0xFFF
-    const bool is_len = lenlike && in_lit && !is_eob;
-    const bool is_dist = lenlike && !in_lit;
+    const bool is_lit = e < 0x1000u;                       // literal entries are 0x001 .. 0xFFF
+    const bool is_len = lenlike && in_lit;
+    const bool is_dist = lenlike && !is_len;
     const uint32_t base = L.be_lut[(e >> 8) & 63u];
     const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
     const uint32_t val = base + __builtin_amdgcn_ubfe(w, l, ebv);
@@ -367,7 +375,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       wp++;
       nxt = V2_SRC(wp + 2);
     }
-    bool bad = e == 0u;                                    // no such code (a stopped lane never reads a zero entry)
+    bool bad = false;                                      // (an unassigned code is a pointer to STOP_BAD)
     if (MODE == 1) { if (is_lit && !V2_G(opos >= win_base, 2, opos)) out[opos] = (uint8_t)(e >> 4); }
     if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 4); }
     if (is_len) mlen = val;
@@ -386,7 +394,6 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     uint32_t ntb = is_len ? DIST_BASE : (at_end ? STOP_END : 0u);
     uint32_t nmb = is_len ? (uint32_t)V2_DIST_BITS : (at_end ? 0u : (uint32_t)V2_LIT_BITS);
     if (ptr) { ntb = (e >> 3) & 0xFFEu; nmb = l; }
-    if (is_eob) { ntb = STOP_EOB; nmb = 0u; }
     if (bad) { ntb = STOP_BAD; nmb = 0u; }
     tb = ntb; mb = nmb;
     if (MODE == 0) {
@@ -403,7 +410,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     // even if it stopped exactly on a true symbol boundary: first stays ~0, which never equals a predecessor's end
     // and so forces a re-decode
     if (first == 0xFFFFFFFFu) { no = 0; nm = 0; }
-    end_out = pos; nout = no; nmatch = nm; first_out = first;
+    end_out = tb == STOP_EOB ? pos - (uint32_t)L.eob_fix : pos; nout = no; nmatch = nm; first_out = first;
     flags = tb == STOP_EOB ? F_EOB : (tb == STOP_BAD ? F_BAD : 0u);
   }
 }
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
     uint32_t base, eb;
     if (lane < 32) { len_base_extra((uint32_t)lane, &base, &eb); L.be_lut[lane] = lane > 28 ? 0u : base; }
     else { dist_base_extra((uint32_t)lane - 32u, &base, &eb); L.be_lut[lane] = lane - 32 > 29 ? 0u : base; }
-    if (lane < 8) L.null_slot[lane] = (uint16_t)(E_SUB | (((V2_NULL_BASE >> 1) + (uint32_t)lane) << 4));
+    if (lane < 7) L.null_slot[lane] = (uint16_t)(E_SUB | (((V2_NULL_BASE >> 1) + (uint32_t)lane) << 4));
   }
   V2_SYNC();
 
