@@ -311,7 +311,7 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
 // refills it one dword at a time from the staged input.  The body is written predicated (selects,
 // wave-uniform ballot branches, no break) so it compiles to straight-line code instead of nested
 // exec-mask regions.
-template <int MODE>
+template <int MODE, bool SPEC = false>
 __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, uint32_t limit, uint32_t& end_out,
                                         uint32_t& nout, uint32_t& nmatch, uint32_t& flags, uint8_t* out, uint32_t opos,
                                         unsigned long long* mlist, uint32_t mpos, uint32_t win_base,
@@ -319,12 +319,12 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
   constexpr bool WRITE = MODE != 0;
   static_assert(offsetof(V2Lds, null_slot) - offsetof(V2Lds, lit_fast) == V2_NULL_BASE, "null slots must sit at V2_NULL_BASE");
   uint32_t pos = start;
-  uint32_t no = 0, nm = 0;
+  uint32_t acc = 0;  // MODE 0: bytes produced [0:19] | matches [20:31] since `first`
   const bool run0 = active && pos < limit;
   // speculative lanes start `overlap` bits early: symbols that begin before count_from only serve to
   // synchronise; the first symbol start at/after count_from is reported and counting restarts there.
   // first == ~0 means "not reached yet".
-  uint32_t first = pos >= count_from ? pos : 0xFFFFFFFFu;
+  uint32_t first = (!SPEC || pos >= count_from) ? pos : 0xFFFFFFFFu;
 #if V2_GLOBAL_INPUT
 #ifdef V2_GUARD
 #define V2_SRC(i) (V2_G((i) > ((limit + 64u) >> 5) + 3u, 1, (i)) ? 0u : gsrc[i])
@@ -378,7 +378,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     bool bad = false;                                      // (an unassigned code is a pointer to STOP_BAD)
     if (MODE == 1) { if (is_lit && !V2_G(opos >= win_base, 2, opos)) out[opos] = (uint8_t)(e >> 4); }
     if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 4); }
-    if (is_len) mlen = val;
+    if (is_len) mlen = WRITE ? val : val + (1u << 20);   // count passes carry the match count in the same accumulator
     bool okm = is_dist;
     if (WRITE) {
       if (okm && val > opos) { bad = true; okm = false; }
@@ -386,9 +386,7 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
       mpos += okm ? 1u : 0u;
     }
     const uint32_t produced = is_lit ? 1u : (okm ? mlen : 0u);
-    opos += produced;
-    no += produced;
-    nm += okm ? 1u : 0u;
+    if (WRITE) opos += produced; else acc += produced;
     // next lookup: a completed symbol returns to the literal/length root, or parks if the sub-stream is used up
     const bool at_end = pos >= limit;
     uint32_t ntb = is_len ? DIST_BASE : (at_end ? STOP_END : 0u);
@@ -396,10 +394,10 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     if (ptr) { ntb = (e >> 3) & 0xFFEu; nmb = l; }
     if (bad) { ntb = STOP_BAD; nmb = 0u; }
     tb = ntb; mb = nmb;
-    if (MODE == 0) {
+    if (SPEC) {
       // the next step starts a symbol at / after count_from: counting restarts there
       const bool cross = tb == 0u && first == 0xFFFFFFFFu && pos >= count_from;
-      if (cross) { first = pos; no = 0; nm = 0; }
+      if (cross) { first = pos; acc = 0; }
     }
 #ifdef V2_ASM_MARKERS
     asm volatile("; V2LOOP_END %0" ::"n"(MODE));
@@ -409,8 +407,8 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no valid result,
     // even if it stopped exactly on a true symbol boundary: first stays ~0, which never equals a predecessor's end
     // and so forces a re-decode
-    if (first == 0xFFFFFFFFu) { no = 0; nm = 0; }
-    end_out = tb == STOP_EOB ? pos - (uint32_t)L.eob_fix : pos; nout = no; nmatch = nm; first_out = first;
+    if (first == 0xFFFFFFFFu) acc = 0;
+    end_out = tb == STOP_EOB ? pos - (uint32_t)L.eob_fix : pos; nout = acc & 0xFFFFFu; nmatch = acc >> 20; first_out = first;
     flags = tb == STOP_EOB ? F_EOB : (tb == STOP_BAD ? F_BAD : 0u);
   }
 }
@@ -770,7 +768,7 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
         {
           const uint32_t ov = lane == 0 ? 0u : (uint32_t)V2_OV_BITS;
           uint32_t first = bnd;
-          v2_pass<0>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first, base32 + wb);
+          v2_pass<0, true>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first, base32 + wb);
           start = first;  // counts are valid from here
         }
         dbg_passes++;
