@@ -512,7 +512,7 @@ __device__ void v2_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst,
 // (absolute output position R maps to win[0]).  Sources before R are final bytes in HBM; sources at or
 // after R are in the window, so dependency rounds cost LDS latency instead of HBM round trips.
 __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t R, int lane, int nm, uint32_t m_dst,
-                                     uint32_t m_len, uint32_t m_dist) {
+                                     uint32_t m_len, uint32_t m_dist, uint32_t ablate = 0) {
   bool valid = lane < nm;
   if (valid && V2_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u || m_dst < R || m_dst + m_len - R > (uint32_t)V2_WIN, 5, m_dst + m_len)) valid = false;
   const uint32_t src_lo = m_dst - m_dist;
@@ -521,7 +521,7 @@ __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t 
   const uint32_t first_dst = __builtin_amdgcn_readlane(m_dst, 0);
   uint64_t dep = 0;
   const bool maybe = valid && src_hi > first_dst;
-  if (__ballot(maybe) != 0ull) {
+  if (!(ablate & 4u) && __ballot(maybe) != 0ull) {
     const uint32_t dend = valid ? m_dst + m_len : 0xFFFFFFFFu;
     const uint32_t dbeg = valid ? m_dst : 0xFFFFFFFFu;
     int lo1 = 0, hi1 = nm, lo2 = 0, hi2 = nm;
@@ -543,36 +543,41 @@ __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t 
   // far part: the first n_far source bytes precede the window (final bytes in HBM) -- no dependency
   uint32_t n_far = 0;
   if (valid && src_lo < R) { n_far = R - src_lo; if (n_far > m_len) n_far = m_len; }
-  if (n_far) {
+  if (n_far && !(ablate & 8u)) {
+    // LDS takes unaligned 4 / 8-byte stores on gfx950: the bytes go out in the widest pieces that fit
     uint8_t* d = win + (m_dst - R);
     const uint8_t* s = out + src_lo;
     uint32_t k = 0;
     for (; k + 16 <= n_far; k += 16) {
       const u32x4 v = ld16(s + k);
-      uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 16; q++) d[k + q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+      st8(d + k, (uint64_t)v.x | ((uint64_t)v.y << 32));
+      st8(d + k + 8, (uint64_t)v.z | ((uint64_t)v.w << 32));
     }
-    if (k < n_far) {
-      const u32x4 v = ld16(s + k);
-      uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int q = 0; q < 16; q++) if (k + q < n_far) d[k + q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    const uint32_t rem = n_far - k;
+    if (rem) {
+      const u32x4 v = ld16(s + k);  // over-read is inside the (padded) buffer
+      uint8_t* t = d + k;
+      uint32_t o = 0;
+      if (rem & 8) { st8(t, (uint64_t)v.x | ((uint64_t)v.y << 32)); o = 8; }
+      if (rem & 4) { st4(t + o, o ? v.z : v.x); o += 4; }
+      const uint32_t w = o == 0 ? v.x : o == 4 ? v.y : o == 8 ? v.z : v.w;
+      if (rem & 2) { st2(t + o, (uint16_t)w); if (rem & 1) t[o + 2] = (uint8_t)(w >> 16); }
+      else if (rem & 1) t[o] = (uint8_t)w;
     }
   }
   const uint64_t all = nm >= 64 ? ~0ull : ((1ull << nm) - 1ull);
   uint64_t done = 0;
   while (done != all) {
     const bool ready = valid && !((done >> lane) & 1ull) && ((dep & ~done) == 0ull);
-    if (ready && n_far < m_len) {
+    if (ready && n_far < m_len && !(ablate & 16u)) {
       uint8_t* d = win + (m_dst - R);
       const uint8_t* s = win + (src_lo - R);  // only indexed at k >= n_far, where src_lo + k >= R
       uint32_t k = n_far;
+      if (m_dist >= 8) {
+        for (; k + 8 <= m_len; k += 8) st8(d + k, ((const u64p*)(s + k))->v);
+      }
       if (m_dist >= 4) {
-        for (; k + 4 <= m_len; k += 4) {
-          uint8_t b0 = s[k], b1 = s[k + 1], b2 = s[k + 2], b3 = s[k + 3];
-          d[k] = b0; d[k + 1] = b1; d[k + 2] = b2; d[k + 3] = b3;
-        }
+        for (; k + 4 <= m_len; k += 4) st4(d + k, ((const u32p*)(s + k))->v);
       }
       for (; k < m_len; k++) d[k] = s[k];
     }
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
             const unsigned long long m = m_next;
             if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
             const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
-            if (use_win) v2_resolve_batch_win(L.win, out, opos, lane, (int)nmb, md, ml, mdist);
+            if (use_win) v2_resolve_batch_win(L.win, out, opos, lane, (int)nmb, md, ml, mdist, ablate);
             else v2_resolve_batch(out, lane, (int)nmb, md, ml, mdist);
           }
           if (use_win) {
