@@ -133,6 +133,8 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
   for (int i = 0; i < 5; i++) tot += (double)tc[i];
   const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
   for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+  fprintf(stderr, "[bioscan]   LZ77 matches %u (%.1f per round), %.1f %% with a source inside the round's window\n", h[14], h[2] ? (double)h[14] / h[2] : 0.0,
+          h[14] ? 100.0 * h[15] / h[14] : 0.0);
 }
 
 void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {

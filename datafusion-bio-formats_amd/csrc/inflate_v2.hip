@@ -508,42 +508,17 @@ __device__ void v2_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst,
   }
 }
 
-// Same dependency-ordered batch copy, but the round's output lives in the LDS window `win`
-// (absolute output position R maps to win[0]).  Sources before R are final bytes in HBM; sources at or
-// after R are in the window, so dependency rounds cost LDS latency instead of HBM round trips.
-__device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t R, int lane, int nm, uint32_t m_dst,
-                                     uint32_t m_len, uint32_t m_dist, uint32_t ablate = 0) {
-  bool valid = lane < nm;
-  if (valid && V2_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u || m_dst < R || m_dst + m_len - R > (uint32_t)V2_WIN, 5, m_dst + m_len)) valid = false;
+// Resolve of a round whose output lives in the LDS window `win` (absolute output position R maps to win[0]).  Sources
+// before R are final bytes in HBM, sources at or after R are in the window.  58 % of the matches of a BAM member read
+// only bytes before R: they need no ordering at all, so the list is walked twice -- first every match copies the part
+// of its source that precedes R (v2_far_copy) and the matches that also read the window are compacted to the front
+// of the list, then only those go through the dependency-ordered copy (v2_near_batch), in dense batches of 64.
+__device__ __forceinline__ void v2_far_copy(uint8_t* win, const uint8_t* out, uint32_t R, bool valid, uint32_t m_dst, uint32_t m_len,
+                                            uint32_t m_dist) {
   const uint32_t src_lo = m_dst - m_dist;
-  const uint32_t src_end = src_lo + m_len;
-  const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
-  const uint32_t first_dst = __builtin_amdgcn_readlane(m_dst, 0);
-  uint64_t dep = 0;
-  const bool maybe = valid && src_hi > first_dst;
-  if (!(ablate & 4u) && __ballot(maybe) != 0ull) {
-    const uint32_t dend = valid ? m_dst + m_len : 0xFFFFFFFFu;
-    const uint32_t dbeg = valid ? m_dst : 0xFFFFFFFFu;
-    int lo1 = 0, hi1 = nm, lo2 = 0, hi2 = nm;
-#pragma unroll
-    for (int step = 0; step < 7; step++) {
-      const int mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
-      const uint32_t v1 = (uint32_t)__shfl((int)dend, mid1 & 63, WAVE);
-      const uint32_t v2 = (uint32_t)__shfl((int)dbeg, mid2 & 63, WAVE);
-      if (lo1 < hi1) { if (v1 > src_lo) hi1 = mid1; else lo1 = mid1 + 1; }
-      if (lo2 < hi2) { if (v2 >= src_hi) hi2 = mid2; else lo2 = mid2 + 1; }
-    }
-    int a = lo1, b = lo2 - 1;
-    if (b > lane - 1) b = lane - 1;
-    if (maybe && a <= b) {
-      const uint64_t hi_mask = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
-      dep = hi_mask & ~((1ull << a) - 1ull);
-    }
-  }
-  // far part: the first n_far source bytes precede the window (final bytes in HBM) -- no dependency
   uint32_t n_far = 0;
   if (valid && src_lo < R) { n_far = R - src_lo; if (n_far > m_len) n_far = m_len; }
-  if (n_far && !(ablate & 8u)) {
+  if (n_far) {
     // LDS takes unaligned 4 / 8-byte stores on gfx950: the bytes go out in the widest pieces that fit
     uint8_t* d = win + (m_dst - R);
     const uint8_t* s = out + src_lo;
@@ -565,11 +540,47 @@ __device__ void v2_resolve_batch_win(uint8_t* win, const uint8_t* out, uint32_t 
       else if (rem & 1) t[o] = (uint8_t)w;
     }
   }
+}
+
+// dependency-ordered copy of the in-window part of <= 64 matches (one per lane, sorted by destination)
+__device__ void v2_near_batch(uint8_t* win, uint32_t R, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
+  bool valid = lane < nm;
+  if (valid && V2_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u || m_dst < R || m_dst + m_len - R > (uint32_t)V2_WIN, 5, m_dst + m_len)) valid = false;
+  const uint32_t src_lo = m_dst - m_dist;
+  const uint32_t src_end = src_lo + m_len;
+  const uint32_t src_hi = src_end < m_dst ? src_end : m_dst;
+  const uint32_t first_dst = __builtin_amdgcn_readlane(m_dst, 0);
+  uint64_t dep = 0;
+  const bool maybe = valid && src_hi > first_dst;
+  if (__ballot(maybe) != 0ull) {
+    // destinations are sorted and disjoint: the earlier matches overlapping [src_lo, src_hi) are the
+    // index range [first i with dst_end_i > src_lo, last i with dst_i < src_hi]; two binary searches
+    // over the lanes (ds_bpermute) instead of a 63-step sweep.
+    const uint32_t dend = valid ? m_dst + m_len : 0xFFFFFFFFu;
+    const uint32_t dbeg = valid ? m_dst : 0xFFFFFFFFu;
+    int lo1 = 0, hi1 = nm, lo2 = 0, hi2 = nm;
+#pragma unroll
+    for (int step = 0; step < 7; step++) {
+      const int mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
+      const uint32_t v1 = (uint32_t)__shfl((int)dend, mid1 & 63, WAVE);
+      const uint32_t v2 = (uint32_t)__shfl((int)dbeg, mid2 & 63, WAVE);
+      if (lo1 < hi1) { if (v1 > src_lo) hi1 = mid1; else lo1 = mid1 + 1; }
+      if (lo2 < hi2) { if (v2 >= src_hi) hi2 = mid2; else lo2 = mid2 + 1; }
+    }
+    int a = lo1, b = lo2 - 1;
+    if (b > lane - 1) b = lane - 1;
+    if (maybe && a <= b) {
+      const uint64_t hi_mask = b >= 63 ? ~0ull : ((1ull << (b + 1)) - 1ull);
+      dep = hi_mask & ~((1ull << a) - 1ull);
+    }
+  }
+  uint32_t n_far = 0;  // already copied by v2_far_copy
+  if (valid && src_lo < R) { n_far = R - src_lo; if (n_far > m_len) n_far = m_len; }
   const uint64_t all = nm >= 64 ? ~0ull : ((1ull << nm) - 1ull);
   uint64_t done = 0;
   while (done != all) {
     const bool ready = valid && !((done >> lane) & 1ull) && ((dep & ~done) == 0ull);
-    if (ready && n_far < m_len && !(ablate & 16u)) {
+    if (ready && n_far < m_len) {
       uint8_t* d = win + (m_dst - R);
       const uint8_t* s = win + (src_lo - R);  // only indexed at k >= n_far, where src_lo + k >= R
       uint32_t k = n_far;
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
   V2Lds& L = L_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
   unsigned long long* mlist = scratch + ((size_t)blockIdx.x * V2_WAVES_PER_WG + (threadIdx.x >> 6)) * scratch_stride;
-  uint32_t dbg_rounds = 0, dbg_passes = 0;
+  uint32_t dbg_rounds = 0, dbg_passes = 0, dbg_matches = 0, dbg_near = 0;
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = 0;
 #define TICK() (t0 = dbg ? clock64() : 0)
@@ -822,13 +833,39 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
         if (!(ablate & 1u)) {
           unsigned long long m_next = 0;
           if ((uint32_t)lane < tot_m) m_next = mlist[lane];
-          for (uint32_t k = 0; k < tot_m; k += WAVE) {
-            const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
-            const unsigned long long m = m_next;
-            if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
-            const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
-            if (use_win) v2_resolve_batch_win(L.win, out, opos, lane, (int)nmb, md, ml, mdist, ablate);
-            else v2_resolve_batch(out, lane, (int)nmb, md, ml, mdist);
+          if (use_win) {
+            uint32_t n_near = 0;  // matches that also read this round's window, compacted to the front of the list
+            for (uint32_t k = 0; k < tot_m; k += WAVE) {
+              const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
+              const unsigned long long m = m_next;
+              if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
+              const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
+              const bool valid_m = (uint32_t)lane < nmb;
+              v2_far_copy(L.win, out, opos, valid_m, md, ml, mdist);
+              const bool near = valid_m && md - mdist + ml > opos;
+              const unsigned long long nmask = __ballot(near);
+              if (near) mlist[n_near + __builtin_amdgcn_mbcnt_hi((uint32_t)(nmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nmask, 0u))] = m;  // < k + 64: never a slot still to be read
+              n_near += (uint32_t)__popcll(nmask);
+              if (dbg) { dbg_matches += nmb; dbg_near += (uint32_t)__popcll(nmask); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if ((uint32_t)lane < n_near) m_next = mlist[lane];
+            for (uint32_t k = 0; k < n_near; k += WAVE) {
+              const uint32_t nmb = n_near - k < WAVE ? n_near - k : WAVE;
+              const unsigned long long m = m_next;
+              if (k + WAVE + (uint32_t)lane < n_near) m_next = mlist[k + WAVE + lane];
+              const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
+              v2_near_batch(L.win, opos, lane, (int)nmb, md, ml, mdist);
+            }
+          } else {
+            for (uint32_t k = 0; k < tot_m; k += WAVE) {
+              const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
+              const unsigned long long m = m_next;
+              if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
+              const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
+              v2_resolve_batch(out, lane, (int)nmb, md, ml, mdist);
+            }
           }
           if (use_win) {
             // coalesced flush of the window (16 B per lane; the destination may be unaligned)
@@ -863,6 +900,8 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
     atomicAdd(&dbg[0], dbg_rounds);
     atomicAdd(&dbg[1], dbg_passes);
     for (int i = 0; i < 5; i++) atomicAdd((unsigned long long*)(dbg + 2) + i, tc[i]);
+    atomicAdd(&dbg[12], dbg_matches);
+    atomicAdd(&dbg[13], dbg_near);
   }
 }
 
