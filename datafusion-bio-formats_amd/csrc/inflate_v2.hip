@@ -357,9 +357,10 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     const bool in_lit = tb < DIST_BASE;
     const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
     const uint32_t e = *(const uint16_t*)(T + tb + (__builtin_amdgcn_ubfe(w, 0u, mb) << 1));
+    __builtin_assume(e < 65536u);
     const uint32_t l = e & 15u;                            // code length (pointer: index width of the sub-table)
     const bool ptr = e >= E_SUB;                           // pointer to a second-level table (or a null slot)
-    const bool lenlike = e - E_HI < E_HI;                  // length / distance / end-of-block entry
+    const bool lenlike = e >= E_HI && !ptr;                // length / distance entry (the `and` is a scalar op)
     const bool is_lit = e < 0x1000u;                       // literal entries are 0x001 .. 0xFFF
     const bool is_len = lenlike && in_lit;
     const bool is_dist = lenlike && !is_len;
