@@ -1,0 +1,78 @@
+"""GPU parity on hand-built BAM records (tests/bam_build.py) for the corners of the per-record decode (SURVEY §8 a8,
+bam/src/physical_exec.rs:412-540): empty sequence, odd / long sequences, no CIGAR, every CIGAR op, unmapped reads,
+missing mates, read names of length 1 and 254, quality bytes >= 95 (two UTF-8 bytes each), records that span BGZF
+members, negative template lengths, records with many aux fields, tiny and single-record files."""
+import random
+
+import pytest
+
+import bam_build as bb
+from test_gpu_bam_parity import _cmp_batches
+
+pytestmark = pytest.mark.gpu
+
+REFS = [("chr1", 248956422), ("chrUn_KI270742v1", 186739), ("2", 1000)]
+
+
+def _records(rng, n):
+    recs = []
+    for k in range(n):
+        kind = k % 12
+        seq_len = [0, 1, 2, 3, 7, 150, 151, 1000, 31, 32, 33, 5000][kind]
+        seq = "".join(rng.choice("=ACMGRSVTWYHKDBN") for _ in range(seq_len))
+        if kind in (5, 6):
+            seq = "".join(rng.choice("ACGT") for _ in range(seq_len))
+        qual = [rng.choice([0, 1, 40, 41, 93, 94, 95, 96, 127, 200, 222]) for _ in range(seq_len)]
+        if kind == 4:
+            qual = [rng.randrange(0, 94) for _ in range(seq_len)]
+        ops = "MIDNSHP=X"
+        ncig = [0, 1, 2, 9, 1, 3, 1, 40, 2, 0, 5, 1][kind]
+        cigar = tuple((rng.choice([1, 2, 15, 100, 268435455 if kind == 3 else 77]), ops[(k + j) % 9]) for j in range(ncig))
+        name = ["r", "x" * 254, "read/1", "a b", f"q{k}", "SRR1.1", "n" * 100, "é".encode().decode("latin-1")[:1] + "z", "*", "0", "READ", "r_r"][kind]
+        refid = [0, 1, 2, -1, 0, 0, 1, 0, -1, 2, 0, 1][kind]
+        pos = [-1 if refid < 0 else rng.randrange(0, 900), 0, 999, -1, 5, 100000, 186000, 7, 12, 0, 2 ** 29 - 1, 1][kind]
+        nref = [-1, 0, 1, 2, -1, 0, 0, -1, 1, 2, 0, 1][(kind + 3) % 12]
+        npos = -1 if nref < 0 else rng.randrange(0, 1000)
+        aux = b""
+        if kind in (5, 7, 10):
+            aux = bb.aux("NM", "C", k % 250) + bb.aux("MD", "Z", "10A5^AC6") + bb.aux("XA", "A", b"Q") + bb.aux("XB", "BS", [1, 2, 65535])
+        recs.append(bb.record(name=name, refid=refid, pos=pos, mapq=rng.choice([0, 1, 60, 254, 255]), flag=rng.choice([0, 4, 77, 141, 2048, 65535]),
+                              cigar=cigar, seq=seq, qual=qual, next_refid=nref, next_pos=npos,
+                              tlen=rng.choice([0, 1, -1, 2 ** 31 - 1, -2 ** 31, 350, -350]), aux_bytes=aux))
+    return recs
+
+
+@pytest.mark.parametrize("member", [60000, 4096, 97])
+@pytest.mark.parametrize("zero_based", [True, False])
+def test_record_corners(pkg, oracle, tmp_path, member, zero_based):
+    rng = random.Random(member)
+    recs = _records(rng, 240 if member > 100 else 48)
+    path = str(tmp_path / "edge.bam")
+    open(path, "wb").write(bb.bam(REFS, recs, member=member))   # small members: headers and records span BGZF blocks
+    tags = ["NM", "MD", "XA", "XB"]
+    prov = pkg.BamTableProvider(path, None, zero_based, tags, index_path="")
+    orc = oracle.BamOracle(path, zero_based=zero_based, tag_fields=tags, index_path=None)
+    assert prov.schema().equals(orc.schema, check_metadata=False)
+    for bs in (8192, 7):
+        got = list(prov.scan().execute(0, bs))
+        _, want = orc.execute_sequential(None, bs)
+        _cmp_batches(got, want, ("edge", member, zero_based, bs))
+    # projections of single columns and COUNT(*)
+    names = orc.schema.names
+    for cols in ([names.index("quality_scores")], [names.index("cigar"), names.index("end")], []):
+        got = list(prov.scan(projection=cols).execute(0, 8192))
+        _, want = orc.execute_sequential(cols, 8192)
+        _cmp_batches(got, want, ("edge-proj", cols))
+
+
+def test_tiny_files(pkg, oracle, tmp_path):
+    for n in (0, 1, 2):
+        rng = random.Random(n)
+        path = str(tmp_path / f"tiny{n}.bam")
+        open(path, "wb").write(bb.bam(REFS, _records(rng, 12)[5:5 + n]))
+        prov = pkg.BamTableProvider(path, None, True, None, index_path="")
+        orc = oracle.BamOracle(path, zero_based=True, tag_fields=None, index_path=None)
+        got = list(prov.scan().execute(0, 8192))
+        _, want = orc.execute_sequential(None, 8192)
+        _cmp_batches(got, want, ("tiny", n))
+        assert sum(b.num_rows for b in got) == n
