@@ -40,6 +40,23 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
     prov = pkg.FastqTableProvider(path, None, device_id=local_rank)
     plan = prov.scan(target_partitions=1)
     assert plan.num_partitions() == 1
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the C restatement (oracle/bioscan_oracle.c::oracle_fastq_scan_mem) on a bounded sample of the same file
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+        nb_s = min(int(meta["n_blocks"]), 65536)
+        need = int(meta["compressed_bytes"] * 1.1 * (nb_s + 1) / max(1, int(meta["n_blocks"]))) + (1 << 20)
+        with open(path, "rb") as f:
+            head = f.read(need)
+        thr = max(1, min(16, ncpu))
+        r = c_oracle.fastq_scan(head, threads=thr, max_blocks=nb_s)
+        cpu = {"value": round(r["n_rows"] / r["seconds_total"] / 1e6, 3), "unit": "Mrec/s", "cores": thr, "kind": "port",
+               "sample": f"first {r['n_blocks']} BGZF members of the same file ({r['inflated_bytes'] / 1e9:.2f} GB text, {r['n_rows']} reads), "
+                         f"all four columns, {'libdeflate' if r['used_libdeflate'] else 'zlib'} inflate, {thr} threads (oracle/bioscan_oracle.c)",
+               "decoded_GB_s": round(r["inflated_bytes"] / r["seconds_total"] / 1e9, 3), "seconds": round(r["seconds_total"], 3),
+               "seconds_inflate": round(r["seconds_inflate"], 3)}
+        del head
     for p in (path, path + ".gzi"):
         if not args.keep_file:
             try:
@@ -84,7 +101,7 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
                          "newline_index": round(st["ms_chain"], 3), "extract": round(st["ms_extract"], 3)},
             "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate_v2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
-            "cpu_baseline": None,
+            "cpu_baseline": cpu,
             "reference_published": {"source": "openspec/changes/refactor-single-thread-partition-reads/design.md:29-36",
                                     "Mrec_s": {"1 thread": 1.49, "8 threads": 11.2, "8 partitions reader+consumer threads": 17.4},
                                     "note": "different file (523 MB, 26.5 M reads) and unstated developer machine"},

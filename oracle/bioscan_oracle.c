@@ -677,3 +677,146 @@ int oracle_vcf_scan_mem(const uint8_t* file, uint64_t file_len, uint64_t b0, uin
   if (bad) { snprintf(out->error, sizeof out->error, "VCF read error: invalid record"); return 1; }
   return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * FASTQ: BGZF -> four Utf8 columns (bio-format-fastq/src/physical_exec.rs:393-465 batch_producer, :554-589
+ * build_batch_from_builders): name = first line after '@' up to the first space, description = the rest (NULL when
+ * empty, :430-434), sequence, quality as raw text.  Threads take text ranges cut at record starts found with the
+ * reference's resync rule (:184-248: a line starting with '@' whose line + 2 starts with '+').  Used as the
+ * cpu_baseline of bench.py --format fastq and checked against oracle/fastq_oracle.py in tests/test_cpu_fastq_oracle.py.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  uint64_t n_rows, n_blocks, compressed_bytes, inflated_bytes;
+  uint64_t name_bytes, desc_bytes, seq_bytes, qual_bytes, desc_null;
+  uint64_t byte_sum;  /* sum over rows of (sum of name bytes + 3 * desc + 5 * seq + 7 * qual bytes) */
+  double seconds_inflate, seconds_parse, seconds_total;
+  int threads, used_libdeflate;
+  char error[256];
+} oracle_fastq_result;
+
+typedef struct {
+  const uint8_t* u;
+  uint64_t a, b, end;      /* records starting in [a, b); text ends at `end` */
+  oracle_fastq_result r;
+  gbuf cols[4], offs[4], valid;
+  int err;
+} fastq_job;
+
+/* NULL when there is no such byte (find_byte above returns the end instead) */
+static inline const uint8_t* find_or_null(const uint8_t* p, const uint8_t* e, int c) {
+  return p < e ? (const uint8_t*)memchr(p, c, (size_t)(e - p)) : NULL;
+}
+static inline uint64_t bsum(const uint8_t* p, size_t n) { uint64_t s = 0; for (size_t i = 0; i < n; i++) s += p[i]; return s; }
+
+static void* fastq_worker(void* arg) {
+  fastq_job* j = (fastq_job*)arg;
+  const uint8_t* u = j->u;
+  uint64_t x = j->a;
+  while (x < j->b) {
+    const uint8_t* e = u + j->end;
+    const uint8_t* l1 = find_or_null(u + x, e, '\n');
+    if (!l1) break;
+    const uint8_t* l2 = find_or_null(l1 + 1, e, '\n');
+    if (!l2) break;
+    const uint8_t* l3 = find_or_null(l2 + 1, e, '\n');
+    if (!l3) break;
+    const uint8_t* l4 = find_or_null(l3 + 1, e, '\n');
+    const uint8_t* q_end = l4 ? l4 : e;                 /* the last record may lack the final newline */
+    if (u[x] != '@' || l2[1] != '+') { j->err = 1; break; }
+    const uint8_t* h = u + x + 1;
+    const uint8_t* sp = (const uint8_t*)memchr(h, ' ', (size_t)(l1 - h));
+    const uint8_t* name_e = sp ? sp : l1;
+    const size_t n_name = (size_t)(name_e - h), n_desc = sp ? (size_t)(l1 - sp - 1) : 0;
+    const size_t n_seq = (size_t)(l2 - l1 - 1), n_qual = (size_t)(q_end - l3 - 1);
+    gb_put(&j->cols[0], h, n_name);
+    if (n_desc) gb_put(&j->cols[1], sp + 1, n_desc); else j->r.desc_null++;
+    gb_put(&j->cols[2], l1 + 1, n_seq);
+    gb_put(&j->cols[3], l3 + 1, n_qual);
+    for (int c = 0; c < 4; c++) gb_u32(&j->offs[c], (uint32_t)j->cols[c].n);
+    { uint8_t v = n_desc ? 1 : 0; gb_put(&j->valid, &v, 1); }
+    j->r.name_bytes += n_name; j->r.desc_bytes += n_desc; j->r.seq_bytes += n_seq; j->r.qual_bytes += n_qual;
+    j->r.byte_sum += bsum(h, n_name) + 3 * (n_desc ? bsum(sp + 1, n_desc) : 0) + 5 * bsum(l1 + 1, n_seq) + 7 * bsum(l3 + 1, n_qual);
+    j->r.n_rows++;
+    if (!l4) break;
+    x = (uint64_t)(l4 - u) + 1;
+  }
+  for (int c = 0; c < 4; c++) { free(j->cols[c].p); free(j->offs[c].p); }
+  free(j->valid.p);
+  return NULL;
+}
+
+/* first record start at or after x (reference resync rule); `end` when there is none */
+static uint64_t fastq_sync(const uint8_t* u, uint64_t x, uint64_t end) {
+  if (x == 0) return 0;
+  const uint8_t* e = u + end;
+  const uint8_t* p = find_or_null(u + x - 1, e, '\n');
+  while (p) {
+    const uint8_t* s = p + 1;
+    if (s >= e) break;
+    if (*s == '@') {
+      const uint8_t* l1 = find_or_null(s, e, '\n');
+      const uint8_t* l2 = l1 ? find_or_null(l1 + 1, e, '\n') : NULL;
+      if (l2 && l2 + 1 < e && l2[1] == '+') return (uint64_t)(s - u);
+    }
+    p = find_or_null(s, e, '\n');
+  }
+  return end;
+}
+
+int oracle_fastq_scan_mem(const uint8_t* file, uint64_t file_len, uint64_t max_blocks, int threads, oracle_fastq_result* out) {
+  memset(out, 0, sizeof(*out));
+  load_libdeflate();
+  const double t0 = now_s();
+  uint64_t nb = 0, cap = 1024;
+  uint64_t* coff = (uint64_t*)malloc(8 * (cap + 1));
+  uint64_t* uoff = (uint64_t*)malloc(8 * (cap + 1));
+  uint64_t o = 0, uo = 0;
+  while (o + 28 <= file_len && (max_blocks == 0 || nb < max_blocks)) {
+    if (nb == cap) { cap *= 2; coff = (uint64_t*)realloc(coff, 8 * (cap + 1)); uoff = (uint64_t*)realloc(uoff, 8 * (cap + 1)); }
+    const uint32_t bsize = rd16(file + o + 16) + 1;
+    if (o + bsize > file_len) break;  /* a member cut off by the caller's prefix read */
+    coff[nb] = o; uoff[nb] = uo;
+    uo += rd32(file + o + bsize - 4);
+    o += bsize;
+    nb++;
+  }
+  coff[nb] = o; uoff[nb] = uo;
+  const uint64_t ulen = uo;
+  uint8_t* u = (uint8_t*)malloc(ulen + 64);
+  if (threads < 1) threads = 1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  inflate_job* ij = (inflate_job*)calloc((size_t)threads, sizeof(inflate_job));
+  for (int t = 0; t < threads; t++) {
+    ij[t].file = file; ij[t].coff = coff; ij[t].uoff = uoff; ij[t].u = u;
+    ij[t].b0 = nb * (uint64_t)t / (uint64_t)threads;
+    ij[t].b1 = nb * (uint64_t)(t + 1) / (uint64_t)threads;
+    pthread_create(&th[t], NULL, inflate_worker, &ij[t]);
+  }
+  int bad = 0;
+  for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); bad |= ij[t].err; }
+  const double t1 = now_s();
+  if (bad) { snprintf(out->error, sizeof out->error, "BGZF inflate / CRC failure"); free(u); free(coff); free(uoff); free(th); free(ij); return 1; }
+  fastq_job* fj = (fastq_job*)calloc((size_t)threads, sizeof(fastq_job));
+  uint64_t prev = 0;
+  for (int t = 0; t < threads; t++) {
+    uint64_t cut = t + 1 == threads ? ulen : fastq_sync(u, ulen * (uint64_t)(t + 1) / (uint64_t)threads, ulen);
+    if (cut < prev) cut = prev;
+    fj[t].u = u; fj[t].a = prev; fj[t].b = cut; fj[t].end = ulen;
+    prev = cut;
+    pthread_create(&th[t], NULL, fastq_worker, &fj[t]);
+  }
+  for (int t = 0; t < threads; t++) {
+    pthread_join(th[t], NULL);
+    bad |= fj[t].err;
+    const oracle_fastq_result* r = &fj[t].r;
+    out->n_rows += r->n_rows; out->name_bytes += r->name_bytes; out->desc_bytes += r->desc_bytes; out->seq_bytes += r->seq_bytes;
+    out->qual_bytes += r->qual_bytes; out->desc_null += r->desc_null; out->byte_sum += r->byte_sum;
+  }
+  const double t2 = now_s();
+  out->n_blocks = nb; out->compressed_bytes = coff[nb]; out->inflated_bytes = ulen;
+  out->seconds_inflate = t1 - t0; out->seconds_parse = t2 - t1; out->seconds_total = t2 - t0;
+  out->threads = threads; out->used_libdeflate = ld_allocd != NULL;
+  free(u); free(coff); free(uoff); free(th); free(ij); free(fj);
+  if (bad) { snprintf(out->error, sizeof out->error, "FASTQ read error: invalid record"); return 1; }
+  return 0;
+}

@@ -28,9 +28,8 @@ CORE = [("name", "s", False), ("chrom", "s", True), ("start", "u", True), ("end"
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
-            import subprocess
-            subprocess.check_call(["make", "-C", _HERE])
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", _HERE])  # no-op when _build/liboracle.so is newer than the source
         _lib = C.CDLL(_LIB)
         _lib.oracle_bam_scan_mem.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_char_p,
                                              C.POINTER(C.c_int), C.c_int, C.POINTER(_Result)]
@@ -102,3 +101,23 @@ def vcf_scan(data: bytes, info=(), n_samples=0, zero_based=True, threads=1, b0=0
     if rc:
         raise RuntimeError(res.error.decode())
     return {k: getattr(res, k) for k, _ in _VcfResult._fields_ if k != "error"}
+
+
+class _FastqResult(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64), ("inflated_bytes", C.c_uint64),
+                ("name_bytes", C.c_uint64), ("desc_bytes", C.c_uint64), ("seq_bytes", C.c_uint64), ("qual_bytes", C.c_uint64),
+                ("desc_null", C.c_uint64), ("byte_sum", C.c_uint64),
+                ("seconds_inflate", C.c_double), ("seconds_parse", C.c_double), ("seconds_total", C.c_double),
+                ("threads", C.c_int), ("used_libdeflate", C.c_int), ("error", C.c_char * 256)]
+
+
+def fastq_scan(data: bytes, threads=1, max_blocks=0) -> dict:
+    """C restatement of the BGZF-FASTQ scan over the first max_blocks members (0 = all): four Utf8 columns are built
+    per thread; returns row count, per-column byte totals, NULL descriptions and a weighted byte checksum."""
+    L = lib()
+    L.oracle_fastq_scan_mem.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(_FastqResult)]
+    res = _FastqResult()
+    rc = L.oracle_fastq_scan_mem(data, len(data), max_blocks, threads, C.byref(res))
+    if rc:
+        raise RuntimeError(res.error.decode())
+    return {k: getattr(res, k) for k, _ in _FastqResult._fields_ if k != "error"}

@@ -71,3 +71,23 @@ def test_gzi_bounds_kat(fo):
     assert fo.bgzf_partition_bounds(gzi, 3) == [(0, 400), (4000, 700), (7000, None)]
     assert len(fo.bgzf_partition_bounds(gzi, 64)) == 10
     assert fo.bgzf_partition_bounds([], 4) == [(0, None)]
+
+
+def test_c_fastq_oracle_matches_python_oracle(fo):
+    """oracle/bioscan_oracle.c::oracle_fastq_scan_mem (bench.py's cpu_baseline for --format fastq) against the Python
+    oracle on the reference's sample.fastq.bgz, for 1..5 threads (thread cuts use the reference's resync rule)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "oracle"))
+    import c_oracle
+    path = os.path.join(G, "sample.fastq.bgz")
+    o = fo.FastqOracle(path)
+    _, _, rows = _rows(o, 1)
+    want = dict(n_rows=len(rows), name_bytes=sum(len(r[0].encode()) for r in rows),
+                desc_bytes=sum(len(r[1].encode()) for r in rows if r[1] is not None), desc_null=sum(r[1] is None for r in rows),
+                seq_bytes=sum(len(r[2]) for r in rows), qual_bytes=sum(len(r[3]) for r in rows),
+                byte_sum=sum(sum(r[0].encode()) + 3 * (sum(r[1].encode()) if r[1] is not None else 0) + 5 * sum(r[2].encode()) + 7 * sum(r[3].encode()) for r in rows))
+    data = open(path, "rb").read()
+    for threads in (1, 2, 3, 5):
+        got = c_oracle.fastq_scan(data, threads=threads)
+        assert {k: got[k] for k in want} == want, (threads, got, want)
+    assert got["n_rows"] == 2000
