@@ -68,6 +68,9 @@ void launch_fastq_sync(const uint8_t* u, uint64_t start, uint64_t ulen, const ui
 // Tile = 16 KiB per 256-thread workgroup, 64 contiguous bytes per thread (adjacent lanes read adjacent
 // 64-byte lines).  '\n' bytes are found 8 at a time with an exact SWAR zero-byte test; pass 1 counts
 // per tile, a scan gives tile bases, pass 2 recounts and writes the positions in order.
+// newline index entry: position [0:47] | first byte of the next line [48:55] | bit 63: the byte before is '\r'
+constexpr uint64_t NL_POS = (1ull << 48) - 1, NL_CR = 1ull << 63;
+constexpr int NL_NEXT_SHIFT = 48;
 constexpr int NL_CHUNK = 16384;
 constexpr int NL_PER_THREAD = 64;
 struct __attribute__((packed, aligned(1))) nl_u64 { uint64_t v; };
@@ -79,7 +82,8 @@ __device__ __forceinline__ uint64_t nl_mask8(uint64_t w) {
   return ~(t | x | 0x7F7F7F7F7F7F7F7Full);
 }
 // masks of the 8 words of this thread's 64 bytes [a, a+64) clipped to hi (bytes past hi never match)
-__device__ __forceinline__ uint32_t nl_thread_masks(const uint8_t* __restrict__ u, uint64_t a, uint64_t hi, uint64_t m[8]) {
+__device__ __forceinline__ uint32_t nl_thread_masks(const uint8_t* __restrict__ u, uint64_t a, uint64_t hi, uint64_t m[8],
+                                                     uint64_t* words = nullptr) {
   uint32_t n = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -88,6 +92,7 @@ __device__ __forceinline__ uint32_t nl_thread_masks(const uint8_t* __restrict__ 
     if (p + 8 <= hi) w = ((const nl_u64*)(u + p))->v;
     else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
     m[k] = p < hi ? nl_mask8(w) : 0ull;
+    if (words) words[k] = w;
     n += (uint32_t)__popcll(m[k]);
   }
   return n;
@@ -108,8 +113,8 @@ __global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ u,
   __shared__ uint32_t s_w[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint64_t a = lo + (uint64_t)blockIdx.x * NL_CHUNK + (uint64_t)threadIdx.x * NL_PER_THREAD;
-  uint64_t m[8];
-  const uint32_t n = a < hi ? nl_thread_masks(u, a, hi, m) : 0u;
+  uint64_t m[8], w[8];
+  const uint32_t n = a < hi ? nl_thread_masks(u, a, hi, m, w) : 0u;
   uint32_t inc = n;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -127,7 +132,19 @@ __global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ u,
       uint64_t mk = m[k];
       while (mk) {
         const int bit = __builtin_ctzll(mk);
-        nl[o++] = a + 8 * k + (uint64_t)(bit >> 3);
+        const int b = bit >> 3;
+        const uint64_t p = a + 8 * k + (uint64_t)b;
+        // the bytes around the newline ride along, so that the field kernel does not have to touch the text again for
+        // CRLF and '@' / '+' checks: they come from this thread's own words except at the ends of its 64 bytes
+        uint32_t pb, nb;
+        if (b > 0) pb = (uint32_t)(w[k] >> (8 * (b - 1))) & 0xFFu;
+        else if (k > 0) pb = (uint32_t)(w[k - 1] >> 56);
+        else pb = p > lo ? u[p - 1] : 0u;
+        if (b < 7) nb = (uint32_t)(w[k] >> (8 * (b + 1))) & 0xFFu;
+        else if (k < 7) nb = (uint32_t)w[k + 1] & 0xFFu;
+        else nb = p + 1 < hi ? u[p + 1] : 0u;
+        if (p + 1 >= hi) nb = 0u;
+        nl[o++] = p | (pb == '\r' ? NL_CR : 0ull) | ((uint64_t)nb << NL_NEXT_SHIFT);
         mk &= mk - 1;
       }
     }
@@ -150,6 +167,12 @@ void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t*
 // positions >= x0 in order; a last line without '\n' ends at `eof` (only legal at the end of the data).
 // Outputs per record: source offset + length of name, description, sequence, quality; description
 // validity (NULL when empty, physical_exec.rs:430-434); err: 1 = missing '@', 2 = missing '+'.
+// bit 8k+7 set iff byte k of w equals c (exact SWAR zero-byte test)
+__device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t c8) {
+  const uint64_t x = w ^ c8;
+  const uint64_t t = (x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full;
+  return ~(t | x | 0x7F7F7F7F7F7F7F7Full);
+}
 __global__ __launch_bounds__(256) void k_fastq_fields(const uint8_t* __restrict__ u, uint64_t x0, uint64_t eof,
                                                        const uint64_t* __restrict__ nl, uint64_t n_nl, uint64_t n_rec,
                                                        FastqCols c, uint32_t* err) {
@@ -157,19 +180,45 @@ __global__ __launch_bounds__(256) void k_fastq_fields(const uint8_t* __restrict_
   const bool act = r < n_rec;
   bool dvalid = false;
   if (act) {
+    // the five index entries around the record: nl[4r-1] .. nl[4r+3]
+    uint64_t q[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint64_t li = 4 * r + k;  // entry li - 1
+      q[k] = (li >= 1 && li - 1 < n_nl) ? nl[li - 1] : ~0ull;
+    }
     uint64_t s[4], e[4];
+    uint32_t first[4];
+#pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint64_t li = 4 * r + k;
-      s[k] = li == 0 ? x0 : (li - 1 < n_nl ? nl[li - 1] + 1 : eof);
-      uint64_t en = li < n_nl ? nl[li] : eof;
-      if (en > s[k] && u[en - 1] == '\r') en--;  // CRLF
+      const bool have_prev = li >= 1 && li - 1 < n_nl;
+      s[k] = li == 0 ? x0 : (have_prev ? (q[k] & NL_POS) + 1 : eof);
+      first[k] = li == 0 ? (x0 < eof ? u[x0] : 0u) : (have_prev ? (uint32_t)(q[k] >> NL_NEXT_SHIFT) & 0xFFu : 0u);
+      uint64_t en;
+      if (li < n_nl) {
+        en = q[k + 1] & NL_POS;
+        if (en > s[k] && (q[k + 1] & NL_CR)) en--;  // CRLF
+      } else {
+        en = eof;                                  // a last line without '\n'
+        if (en > s[k] && u[en - 1] == '\r') en--;
+      }
       e[k] = en < s[k] ? s[k] : en;
     }
-    if (u[s[0]] != '@') atomicExch(err, 1u);
-    if (s[2] < eof && u[s[2]] != '+') atomicExch(err, 2u);
-    const uint64_t d0 = s[0] + 1;
-    uint64_t sp = d0;
-    while (sp < e[0] && u[sp] != ' ' && u[sp] != '\t') sp++;
+    if (first[0] != '@') atomicExch(err, 1u);
+    if (s[2] < eof && first[2] != '+') atomicExch(err, 2u);
+    // name = header up to the first space or tab, found eight bytes at a time
+    const uint64_t d0 = s[0] + 1 < e[0] ? s[0] + 1 : e[0];
+    uint64_t sp = e[0];
+    for (uint64_t p = d0; p < e[0]; p += 8) {
+      uint64_t w;
+      if (p + 8 <= eof) w = ((const nl_u64*)(u + p))->v;
+      else { w = 0; for (uint64_t t = p; t < eof; t++) w |= (uint64_t)u[t] << (8 * (t - p)); }
+      uint64_t m = eq_mask8(w, 0x2020202020202020ull) | eq_mask8(w, 0x0909090909090909ull);
+      const uint64_t left = e[0] - p;
+      if (left < 8) m &= (1ull << (8 * left)) - 1ull;
+      if (m) { sp = p + (uint64_t)(__builtin_ctzll(m) >> 3); break; }
+    }
     const uint64_t name_len = sp - d0;
     const uint64_t desc_off = sp < e[0] ? sp + 1 : e[0];
     const uint64_t desc_len = e[0] - desc_off;
@@ -201,7 +250,7 @@ __global__ void k_fastq_count_owned(const uint64_t* __restrict__ nl, uint64_t n_
     uint64_t st;
     bool exists = true;
     if (mid == 0) st = x0;
-    else if (4 * mid - 1 < n_nl) st = nl[4 * mid - 1] + 1;
+    else if (4 * mid - 1 < n_nl) st = (nl[4 * mid - 1] & NL_POS) + 1;
     else { st = eof; exists = false; }
     if (exists && st < eof && st < limit_off) lo = mid + 1; else hi = mid;
   }
