@@ -139,12 +139,18 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
 
 void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {
   if (getenv("BIOSCAN_V2_ABLATE")) return;  // timing-only ablation builds produce wrong bytes on purpose
-  std::vector<uint32_t> st(nb);
-  HIP_CHECK(hipMemcpy(st.data(), d_status.p + b0, nb * 4, hipMemcpyDeviceToHost));
-  for (uint32_t i = 0; i < nb; i++)
-    if (st[i] != INF_OK)
-      throw Error(std::string(what) + " read error: BGZF block " + std::to_string(b0 + i) + " at offset " +
-                  std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st[i] & 0xFF) + " (code " + std::to_string(st[i]) + ")");
+  // the first failing member is found on the device: 8 bytes come back instead of the whole status array
+  DevBuf<uint32_t> res(1);
+  launch_first_bad_status(d_status.p + b0, nb, res.p, stream);
+  uint32_t i = 0xFFFFFFFFu;
+  HIP_CHECK(hipMemcpyAsync(&i, res.p, 4, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  if (i != 0xFFFFFFFFu) {
+    uint32_t st = 0;
+    HIP_CHECK(hipMemcpy(&st, d_status.p + b0 + i, 4, hipMemcpyDeviceToHost));
+    throw Error(std::string(what) + " read error: BGZF block " + std::to_string(b0 + i) + " at offset " +
+                std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st & 0xFF) + " (code " + std::to_string(st) + ")");
+  }
 }
 
 std::vector<uint8_t> BgzfSource::inflate_prefix_to_host(uint32_t b1) {

@@ -227,15 +227,15 @@ struct Provider : BgzfSource {
     launch_seg_emit(d_u.p, stop, nseg, cb, base.p, d_rec_off.p, stream);
     // last exit must be exactly the end of the stream
     {
-      std::vector<uint64_t> ex(nseg), en(nseg);
+      DevBuf<unsigned long long> lastx(2);
+      launch_last_exit(exit_.p, nseg, lastx.p, stream);
+      unsigned long long lx[2] = {0, 0};
       uint32_t errf = 0;
       HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipMemcpyAsync(ex.data(), exit_.p, nseg * 8, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(lx, lastx.p, 16, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
       if (errf) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
-      uint64_t last = SEG_NONE;
-      for (uint64_t k = nseg; k-- > 0;)
-        if (ex[k] != SEG_NONE) { last = ex[k]; break; }
+      const uint64_t last = lx[1];
       if (last == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
       if (first_rec < stop && last != stop) throw Error("BAM read error: unexpected end of record stream");
     }

@@ -51,6 +51,8 @@ void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint6
                       ChainBuffers cb, hipStream_t st);
 void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, hipStream_t st);
 void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st);
+void launch_last_exit(const uint64_t* exit_, uint64_t nseg, unsigned long long* res, hipStream_t st);
+void launch_first_bad_status(const uint32_t* status, uint32_t n, uint32_t* res, hipStream_t st);
 void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, const uint64_t* base,
                      uint64_t* rec_off, hipStream_t st);
 

@@ -270,6 +270,30 @@ void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffer
   hipLaunchKernelGGL(k_seg_emit, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, base, rec_off);
 }
 
+// exit of the last segment that holds a record start: res[0] = index + 1 of that segment (0: none), res[1] = its exit.
+// (The host used to copy the whole exit array back for this: 5 MB of pageable D2H per scan of config 2.)
+__global__ void k_last_exit_idx(const uint64_t* __restrict__ exit_, uint64_t nseg, unsigned long long* res) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool hit = k < nseg && exit_[k] != SEG_NONE;
+  const unsigned long long m = __ballot(hit);
+  if (m && (threadIdx.x & 63) == 0) atomicMax(res, (unsigned long long)(k + 64 - __builtin_clzll(m)));
+}
+__global__ void k_last_exit_val(const uint64_t* __restrict__ exit_, unsigned long long* res) { res[1] = res[0] ? exit_[res[0] - 1] : SEG_NONE; }
+void launch_last_exit(const uint64_t* exit_, uint64_t nseg, unsigned long long* res, hipStream_t st) {
+  hipMemsetAsync(res, 0, 16, st);
+  hipLaunchKernelGGL(k_last_exit_idx, dim3((uint32_t)((nseg + 255) / 256)), dim3(256), 0, st, exit_, nseg, res);
+  hipLaunchKernelGGL(k_last_exit_val, dim3(1), dim3(1), 0, st, exit_, res);
+}
+// first BGZF member whose inflate status is not INF_OK: res[0] = index + 1 (0: all fine)
+__global__ void k_first_bad_status(const uint32_t* __restrict__ status, uint32_t n, uint32_t* res) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n && status[k] != 0u) atomicMin(res, k);
+}
+void launch_first_bad_status(const uint32_t* status, uint32_t n, uint32_t* res, hipStream_t st) {
+  hipMemsetAsync(res, 0xFF, 4, st);
+  if (n) hipLaunchKernelGGL(k_first_bad_status, dim3((n + 255) / 256), dim3(256), 0, st, status, n, res);
+}
+
 // =================================================================================================
 // record key table + row selection
 // =================================================================================================
