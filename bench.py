@@ -25,6 +25,9 @@ DEFAULT_BLOCKS = 655360  # config 2: ~10 GiB compressed BGZF-BAM
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
+COLL_DEVICE = "cuda"  # where the bench's own collectives (barrier, MAX of times, SUM of counts) live
+
+
 def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
     """BGZF-FASTQ + GZI full scan (4 Utf8 columns), one partition per rank over its own file."""
     synth = os.path.join(ROOT, "tools", "_build", "synth_fastq")
@@ -79,10 +82,10 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
     elapsed = time.perf_counter() - t0
     rows, ubytes = float(st["n_rows"]), float(st["inflated_bytes"])
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([rows, ubytes], dtype=torch.float64, device="cuda")
+        c = torch.tensor([rows, ubytes], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rows, ubytes = [float(x) for x in c.tolist()]
     if rank == 0:
@@ -206,10 +209,10 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
     elapsed = time.perf_counter() - t0
     rows, ubytes = float(st["n_rows"]), float(st["inflated_bytes"])
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([rows, ubytes], dtype=torch.float64, device="cuda")
+        c = torch.tensor([rows, ubytes], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rows, ubytes = [float(x) for x in c.tolist()]
     cpu = None
@@ -297,9 +300,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+    global COLL_DEVICE
+    # BIOSCAN_BENCH_REHEARSE=1: walk the N > 1 control flow on a box with fewer GPUs than ranks (every rank on cuda:0,
+    # gloo instead of RCCL for the bench's own barrier / MAX / SUM).  Not a measurement mode.
+    rehearse = os.environ.get("BIOSCAN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+        COLL_DEVICE = "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     pkg = ge._load_pkg()
@@ -408,11 +421,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         cnt = torch.tensor([float(stats["n_rows"]), float(stats["inflated_bytes"]), float(stats["compressed_bytes"]),
-                            float(stats["arrow_bytes"])], dtype=torch.float64, device="cuda")
+                            float(stats["arrow_bytes"])], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_rows, tot_u, tot_c, tot_a = [float(x) for x in cnt.tolist()]
     else:
