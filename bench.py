@@ -455,6 +455,14 @@ def main():
         data, sample_blocks = cpu_sample
         cores = min(16, ncpu)
         st, _ = c_oracle.scan(data, True, cores, sample_blocks, (), (), build_columns=True, to_arrow=False)
+        # the same restatement at 1 and 8 threads (one thread per partition, like the reference's
+        # sync_batch_stream), on smaller samples so that the whole baseline stays within ~20 s
+        sweep = {}
+        for thr, blocks in ((1, min(sample_blocks, 8192)), (8, min(sample_blocks, 32768))):
+            if thr < cores:
+                s2, _ = c_oracle.scan(data, True, thr, blocks, (), (), build_columns=True, to_arrow=False)
+                sweep[str(thr)] = {"Mrec_s": round(s2["n_rows"] / s2["seconds_total"] / 1e6, 3), "blocks": int(s2["n_blocks"]),
+                                   "seconds": round(s2["seconds_total"], 3)}
         del data, cpu_sample
         cpu = {
             "value": round(st["n_rows"] / st["seconds_total"] / 1e6, 3), "unit": "Mrec/s", "cores": cores, "kind": "port",
@@ -463,6 +471,7 @@ def main():
                       f"{'libdeflate' if st['used_libdeflate'] else 'zlib'} inflate, {cores} threads",
             "decoded_GB_s": round(st["inflated_bytes"] / st["seconds_total"] / 1e9, 3),
             "seconds": round(st["seconds_total"], 3),
+            "threads_sweep": sweep,
         }
 
     if rank == 0:
