@@ -499,7 +499,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": (int(pmc_traffic_per_member() * stats["n_blocks"]) if pmc_traffic_per_member() else None),
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01/v2_pmc_*), "
-                                           "per-member average x members of this launch; FETCH_SIZE as reported (uncorrected)",
+                                           "per-member average x members of this launch; FETCH_SIZE as reported (K1 issues dword / 8-byte / unaligned 16-byte loads, "
+                                           "widths the guide calls uncalibrated; K2 in the same profile confirms the x2 rule for 16 B/lane reads)",
                          "algorithmic_bytes_per_launch": int(c + u), "avg_launch_ms": round(avg_infl, 3)},
             "cpu_baseline": cpu,
             "setup_s": {"generate": round(t_gen, 1), "load_and_h2d": round(t_load, 1)},
