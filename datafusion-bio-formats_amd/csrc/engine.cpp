@@ -542,27 +542,45 @@ static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_
     sels.push_back(s);
   }
   if (!satisfiable) sels.clear();
-  // pass 1: totals
-  std::vector<uint64_t> totals;
+  // One pass per selection: flags, scan, compaction straight behind the rows of the previous selections.  A record
+  // belongs to one region unless the caller's regions overlap, so n rows of capacity are enough; if they are not,
+  // the totals are taken first and the selections are run again into an exact allocation.
   uint64_t total = 0;
+  bool overflow = false;
+  rows_owned->alloc(std::max<uint64_t>(n, 1));
   for (auto& s : sels) {
     launch_row_flags(rk, n, s, d_terms.p, keep.p, st);
     launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
     uint64_t t = 0;
     HIP_CHECK(hipMemcpyAsync(&t, kscan.p + n, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    totals.push_back(t);
+    if (total + t > n) { overflow = true; break; }
+    if (t) launch_compact_rows(p.d_rec_off.p, keep.p, kscan.p, n, rows_owned->p, total, st);
     total += t;
   }
-  rows_owned->alloc(std::max<uint64_t>(total, 1));
-  uint64_t base = 0;
-  for (size_t k = 0; k < sels.size(); k++) {
-    if (totals[k]) {
-      launch_row_flags(rk, n, sels[k], d_terms.p, keep.p, st);
+  if (overflow) {
+    std::vector<uint64_t> totals;
+    total = 0;
+    for (auto& s : sels) {
+      launch_row_flags(rk, n, s, d_terms.p, keep.p, st);
       launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
-      launch_compact_rows(p.d_rec_off.p, keep.p, kscan.p, n, rows_owned->p, base, st);
+      uint64_t t = 0;
+      HIP_CHECK(hipMemcpyAsync(&t, kscan.p + n, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      totals.push_back(t);
+      total += t;
     }
-    base += totals[k];
+    HIP_CHECK(hipStreamSynchronize(st));
+    rows_owned->alloc(std::max<uint64_t>(total, 1));
+    uint64_t base = 0;
+    for (size_t k = 0; k < sels.size(); k++) {
+      if (totals[k]) {
+        launch_row_flags(rk, n, sels[k], d_terms.p, keep.p, st);
+        launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
+        launch_compact_rows(p.d_rec_off.p, keep.p, kscan.p, n, rows_owned->p, base, st);
+      }
+      base += totals[k];
+    }
   }
   HIP_CHECK(hipStreamSynchronize(st));
   *rows = rows_owned->p;

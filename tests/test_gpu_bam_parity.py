@@ -101,6 +101,7 @@ def test_region_filters(pkg, oracle, golden):
         [("chrom", "=", "chr2"), ("start", "between", (1, 200000000)), ("flags", "!=", 99)],
         [("mapping_quality", "between", (20, 60))],
         [("chrom", "=", "chr1"), ("start", ">", 10), ("start", "<", 5)],
+        [("chrom", "in", ["chr1", "chr1", "chr2", "chr1"])],   # repeated regions: more selected rows than records
     ]
     for filters in cases:
         for target in (1, 3):
