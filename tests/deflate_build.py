@@ -62,12 +62,20 @@ def random_complete_lengths(rng, symbols, max_len=15, skew=0.7):
     n = len(symbols)
     if n == 1:
         return {symbols[0]: 1}
-    leaves = [0]
-    while len(leaves) < n:
-        cand = [i for i, d in enumerate(leaves) if d < max_len]
-        i = max(cand, key=lambda k: leaves[k]) if rng.random() < skew else rng.choice(cand)
-        d = leaves.pop(i)
-        leaves += [d + 1, d + 1]
+    max_len = min(15, max(max_len, (n - 1).bit_length()))
+    while True:
+        leaves = [0]
+        while len(leaves) < n:
+            cand = [i for i, d in enumerate(leaves) if d < max_len]
+            if not cand:
+                break                      # painted into a corner: every leaf is at max_len already
+            i = max(cand, key=lambda k: leaves[k]) if rng.random() < skew else rng.choice(cand)
+            d = leaves.pop(i)
+            leaves += [d + 1, d + 1]
+        if len(leaves) == n:
+            break
+        max_len = min(15, max_len + 1)
+        skew = min(skew, 0.5)
     rng.shuffle(leaves)
     return dict(zip(symbols, leaves))
 
