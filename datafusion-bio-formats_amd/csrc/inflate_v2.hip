@@ -227,6 +227,13 @@ __device__ int v2_build(V2Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
       left -= (int)c;
       if (left < 0) over = 1;
     }
+    // incomplete codes: libdeflate (the inflater the reference links) accepts only an empty distance code or a code
+    // with a single codeword of length 1 (build_decode_table); everything else that leaves code space unused is invalid
+    if (left > 0 && !over) {
+      const bool empty_ok = o == 0 && is_dist;
+      const bool single_ok = o == 1 && count[1] == 1;
+      if (!empty_ok && !single_ok) over = 1;
+    }
     L.b.t_offs[0] = (uint16_t)o;
     L.b.t_first[0] = (uint16_t)over;
   }
@@ -710,6 +717,10 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
           uint32_t next[8];
           uint32_t code = 0;
           for (int l = 1; l <= 7; l++) { code = (code + cnt[l - 1]) << 1; next[l] = code; }
+          // code space of the code-length code: over-subscribed is invalid, incomplete only passes as a single 1-bit code
+          uint32_t used = 0, nsym = 0;
+          for (int l = 1; l <= 7; l++) { used += cnt[l] << (7 - l); nsym += cnt[l]; }
+          if (used > 128u || (used < 128u && !(nsym == 1 && cnt[1] == 1))) L.b.pre_lens[19] = 1;
           for (int s = 0; s < 19; s++) {
             int l = L.b.pre_lens[s];
             if (!l) continue;
@@ -718,6 +729,7 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
           }
         }
         V2_SYNC();
+        if (uni2((uint32_t)L.b.pre_lens[19])) { st = INF_BAD_CODE | (6u << 8); break; }
         {
           const uint32_t total = hlit + hdist;
           uint32_t i = 0, prev = 0;

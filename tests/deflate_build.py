@@ -122,6 +122,11 @@ def dynamic_block(w: BitWriter, tokens, rng, final: bool, max_len=15, skew=0.7, 
     lit_lengths = [ll.get(s, 0) for s in range(max(lit_syms) + 1)]
     lit_lengths += [0] * (257 - len(lit_lengths))
     dist_lengths = [dl.get(s, 0) for s in range(max(dist_syms) + 1)]
+    block_with_lengths(w, tokens, lit_lengths, dist_lengths, final)
+
+
+def block_with_lengths(w: BitWriter, tokens, lit_lengths, dist_lengths, final: bool):
+    """Dynamic block with the given code lengths, valid or not (lit_lengths: >= 257 entries incl. symbol 256)."""
     hlit, hdist = len(lit_lengths), len(dist_lengths)
     # code-length alphabet: symbols 0..15 literally (no repeat codes); a complete code: 13 x 4 bits + 6 x 5 bits
     cl_lengths = [0] * 19

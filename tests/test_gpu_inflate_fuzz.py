@@ -118,3 +118,42 @@ def test_inflate_handcrafted_huffman_codes(pkg, oracle):
     want, _ = oracle.bgzf_inflate_all(data)
     got, _ = pkg.bgzf_inflate(data)
     assert got == want
+
+
+def test_invalid_code_length_sets_are_rejected(pkg):
+    """Headers libdeflate (the reference's inflater) refuses even when the data never touches the bad part: incomplete
+    and over-subscribed literal/length and distance codes.  The payload, ISIZE and CRC are consistent, so only the
+    code-space check can catch them.  A single 1-bit distance code is the one incomplete code that must pass."""
+    import deflate_build as db
+
+    def member(lit, dist, toks):
+        w = db.BitWriter()
+        db.block_with_lengths(w, toks, lit, dist, True)
+        hist = bytearray()
+        db.apply_tokens(hist, toks)
+        body, payload = w.finish(), bytes(hist)
+        total = 18 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + body +
+                struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload))), body, payload
+
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    lit = [0] * 258
+    lit[65], lit[66], lit[256], lit[257] = 1, 2, 3, 3   # complete: 1/2 + 1/4 + 1/8 + 1/8
+    toks = [('L', 65), ('L', 66), ('L', 65), ('M', 3, 1), ('L', 66)]
+    good, body, payload = member(lit, [1], toks)    # one distance code of length 1: incomplete but legal
+    assert zlib.decompress(body, -15) == payload
+    assert pkg.bgzf_inflate(good + eof)[0] == payload
+    cases = []
+    bad = list(lit); bad[256] = 4                    # literal/length code incomplete: 1/2 + 1/4 + 1/16 + 1/8
+    cases.append((bad, [1]))
+    bad = list(lit); bad[67] = 2                     # over-subscribed: 1/2 + 1/4 + 1/4 + 1/8 + 1/8
+    cases.append((bad, [1]))
+    cases.append((lit, [2]))                         # a single distance code of length 2
+    cases.append((lit, [1, 2]))                      # distance code incomplete: 1/2 + 1/4
+    cases.append((lit, [1, 1, 1]))                   # distance code over-subscribed
+    for l, d in cases:
+        m, body, payload = member(l, d, toks)
+        with pytest.raises(zlib.error):
+            zlib.decompress(body, -15)
+        with pytest.raises(pkg.BioscanError):
+            pkg.bgzf_inflate(m + eof)
