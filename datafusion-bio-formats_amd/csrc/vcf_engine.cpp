@@ -12,6 +12,7 @@
 #include <chrono>
 #include <fstream>
 #include <functional>
+#include <map>
 #include <memory>
 
 #include "bgzf_source.h"
@@ -99,6 +100,7 @@ struct VcfProvider : BgzfSource, VcfProviderI {
   bool has_index = false;
   std::string index_path;
   Tbi tbi;
+  std::map<size_t, std::vector<std::pair<uint64_t, uint64_t>>> whole_contig_chunks;  // per contig: merged chunks as inflated offsets (guarded by mu)
   bool index_readable = false;   // the tabix reader accepted the index (a CSI, or an unreadable file, only fails at execute)
   std::string index_error;
   std::vector<std::string> contig_names;
@@ -594,9 +596,25 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       if (idx < 0) continue;  // "does not exist in reference sequences": region skipped (physical_exec.rs:2844-2850)
       RegionQuery q;
       q.region = r;
-      for (auto& ch : bai_query_chunks(p.tbi.idx, (size_t)idx, r.has_start, r.start, r.has_end, r.end)) {
-        const uint64_t a = voff_to_abs(p, ch.first), b = voff_to_abs(p, ch.second);
-        if (b > a) { q.chunks_abs.emplace_back(a, b); mn = std::min(mn, a); mx = std::max(mx, b); }
+      if (!r.has_start && !r.has_end) {
+        // whole-contig query: the merged chunk list only depends on the index, so it is computed once per contig
+        // (for the 1000-sample file of BASELINE config 4 this was 6 ms of every 33 ms scan)
+        auto it = p.whole_contig_chunks.find((size_t)idx);
+        if (it == p.whole_contig_chunks.end()) {
+          std::vector<std::pair<uint64_t, uint64_t>> v;
+          for (auto& ch : bai_query_chunks(p.tbi.idx, (size_t)idx, false, 0, false, 0)) {
+            const uint64_t a = voff_to_abs(p, ch.first), b = voff_to_abs(p, ch.second);
+            if (b > a) v.emplace_back(a, b);
+          }
+          it = p.whole_contig_chunks.emplace((size_t)idx, std::move(v)).first;
+        }
+        q.chunks_abs = it->second;
+        for (auto& c : q.chunks_abs) { mn = std::min(mn, c.first); mx = std::max(mx, c.second); }
+      } else {
+        for (auto& ch : bai_query_chunks(p.tbi.idx, (size_t)idx, r.has_start, r.start, r.has_end, r.end)) {
+          const uint64_t a = voff_to_abs(p, ch.first), b = voff_to_abs(p, ch.second);
+          if (b > a) { q.chunks_abs.emplace_back(a, b); mn = std::min(mn, a); mx = std::max(mx, b); }
+        }
       }
       queries.push_back(std::move(q));
     }
