@@ -276,6 +276,10 @@ struct Plan {
   std::vector<Filter> residual;
   int fq_strategy = 0;  // FASTQ: 0 sequential, 1 BGZF block ranges, 2 plain byte ranges
   std::vector<std::pair<uint64_t, uint64_t>> fq_parts;  // (start, end); end = ~0 for open-ended
+  // member / byte range of each partition (BAI chunk queries + block lookups), computed on first use: re-planning it on
+  // every execute cost 1-3 ms of host time per partition
+  mutable std::mutex range_mu;
+  mutable std::vector<std::pair<bool, DecodeRange>> range_cache;
   int n_partitions() const {
     if (prov && prov->kind == 1) return fq_strategy == 0 ? 1 : (int)fq_parts.size();
     return empty ? 0 : (indexed ? (int)assignments.size() : 1);
@@ -424,7 +428,16 @@ static size_t block_of_coff(const Provider& p, uint64_t c) {
 // partition starts after the last placed record (coordinate-sorted file: everything a BAI indexes).
 // Per-reference unmapped tails scan "from the reference's last chunk until the reference changes",
 // which is only decidable by looking at every later record: those partitions decode the whole file.
+static DecodeRange partition_range_uncached(const Plan& plan, int partition);
 static DecodeRange partition_range(const Plan& plan, int partition) {
+  if (!plan.indexed) return plan.prov->whole_file();
+  std::lock_guard<std::mutex> lk(plan.range_mu);
+  if (plan.range_cache.size() != plan.assignments.size()) plan.range_cache.assign(plan.assignments.size(), {false, DecodeRange{}});
+  auto& slot = plan.range_cache[(size_t)partition];
+  if (!slot.first) { slot.second = partition_range_uncached(plan, partition); slot.first = true; }
+  return slot.second;
+}
+static DecodeRange partition_range_uncached(const Plan& plan, int partition) {
   const Provider& p = *plan.prov;
   if (!plan.indexed) return p.whole_file();
   uint64_t lo = ~0ull, hi = 0;
@@ -622,7 +635,15 @@ static void copy_result_to_host(Result& res, hipStream_t st) {
 static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
   Provider& p = *plan.prov;
   const auto wall0 = std::chrono::steady_clock::now();
-  p.decode(force_decode, partition_range(plan, partition), plan.indexed);
+  const bool laps = getenv("BIOSCAN_LAPS") != nullptr;
+  auto lap = [&](const char* what) {
+    if (laps) fprintf(stderr, "[bioscan] bam partition %d: %-18s at %8.3f ms\n", partition, what,
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+  };
+  const DecodeRange range = partition_range(plan, partition);
+  lap("range planned");
+  p.decode(force_decode, range, plan.indexed);
+  lap("decoded");
   std::lock_guard<std::mutex> lk(p.mu);
   p.set_device();
   hipStream_t st = p.stream;
@@ -636,6 +657,7 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
   uint64_t n = 0;
   select_rows(plan, partition, &rows_owned, &rows, &n);
   res->stats.ms_select = t.stop();
+  lap("rows selected");
   t.start();
   res->n_rows = n;
   res->stats.n_rows = n;
@@ -779,6 +801,7 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
   res->stats.ms_extract = t.stop();
   res->stats.arrow_bytes = arrow_bytes;
   res->stats.ms_total_gpu = p.decode_stats.ms_total_gpu + res->stats.ms_select + res->stats.ms_extract;
+  lap("end");
   res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 
   if (to_host) copy_result_to_host(*res, st);
