@@ -938,9 +938,8 @@ void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st) {
   if (!n_blocks) return;
-  const char* ab = getenv("BIOSCAN_V2_ABLATE");
-  const char* off = getenv("BIOSCAN_V2_OFF");  // bit mask of optional fast paths to switch off (A/B measurements)
-  const uint32_t ablate = ((ab && n_blocks > 64) ? ((uint32_t)atoi(ab) & 0xFFu) : 0u) | (off ? ((uint32_t)atoi(off) << 8) : 0u);
+  const char* ab = getenv("BIOSCAN_V2_ABLATE");  // timing-only phase ablation (tools/ab_ablate.sh): 1 = no resolve, 2 = no write pass
+  const uint32_t ablate = (ab && n_blocks > 64) ? ((uint32_t)atoi(ab) & 0xFFu) : 0u;
   const char* db = getenv("BIOSCAN_DBG_BLOCK");
   const uint32_t dbg_block = db ? (uint32_t)atoi(db) : 0xFFFFFFFFu;
   (void)g_v2_grid;
