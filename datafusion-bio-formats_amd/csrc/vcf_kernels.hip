@@ -916,11 +916,84 @@ __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restr
       }
       if (cur >= 0 && cur < VCF_MAX_DIRECT) ckind = (int)((kmap >> (2 * cur)) & 3u);
     };
-    if (have && len) select();
+    // Fast path (cell of at most 16 bytes -- it sits in the two registers -- and the nibble maps hold every key): the
+    // ':' positions come from one SWAR test, then the cell is walked sub-field by sub-field, each with a tight loop
+    // for its kind.  All lanes of a wave are at the same sub-field together (a row's FORMAT is shared by its
+    // samples), which the byte-by-byte state machine below cannot offer: there a lane at a ':' and a lane inside a
+    // value make the wave execute both branches at every step.
+    const bool fast = have && len != 0 && len <= 16 && S <= VCF_MAX_DIRECT;
+    if (fast) {
+      const uint64_t c8 = 0x3A3A3A3A3A3A3A3Aull;
+      auto movemask = [](uint64_t m) -> uint32_t { return (uint32_t)((((m >> 7) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56); };
+      uint32_t cm = movemask(eq_mask8(w_lo, c8)) | (movemask(eq_mask8(w_hi, c8)) << 8);
+      cm &= len >= 32 ? 0xFFFFFFFFu : ((1u << len) - 1u);
+      uint32_t start = 0;
+      for (;;) {
+        const uint32_t e = cm ? (uint32_t)__builtin_ctz(cm) : len;
+        cm &= cm - 1u;
+        const uint32_t sl = e - start;
+        select();
+        const bool missing = sl == 1 && byte_at(start) == '.';
+        if (cur >= 0 && !missing) {
+          if (ckind == 1) {           // Int32: [+-]?digits
+            int64_t acc = 0;
+            uint32_t ndig = 0;
+            bool neg = false, bad = false;
+            for (uint32_t k = start; k < e; k++) {
+              const uint32_t ch = byte_at(k);
+              const uint32_t dgt = ch - '0';
+              if (dgt <= 9) { if (acc < 100000000000ll) acc = acc * 10 + dgt; ndig++; }
+              else if ((ch == '-' || ch == '+') && k == start) neg = ch == '-';
+              else bad = true;
+            }
+            if (bad || ndig == 0 || (neg ? acc > 2147483648ll : acc > 2147483647ll)) set_err(err, VERR_BAD_INT);
+            else {
+              const uint32_t v = (uint32_t)(int32_t)(neg ? -acc : acc);
+#pragma unroll
+              for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = v; dok |= 1u << s; }
+            }
+          } else if (ckind == 2) {    // Float32: correctly rounded parse of the span
+            float f;
+            const int rc = parse_f32_text(u + a + start, sl, &f);
+            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT);
+            else {
+#pragma unroll
+              for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = __float_as_uint(f); dok |= 1u << s; }
+            }
+          } else if (ckind == 3) {    // GT as a direct string: validated, leading phasing mark dropped
+            uint32_t tl = 0;
+            bool isdot = false, lead0 = false, gt_ok = true;
+            for (uint32_t k = start; k < e; k++) {
+              const uint32_t ch = byte_at(k);
+              if (ch == '/' || ch == '|') {
+                if (k != start) { if (tl == 0 || (!isdot && lead0 && tl > 1)) gt_ok = false; tl = 0; isdot = false; lead0 = false; }
+              } else if (ch == '.') { if (tl) gt_ok = false; isdot = true; tl = 1; }
+              else if (ch >= '0' && ch <= '9') { if (isdot) gt_ok = false; if (tl == 0) lead0 = ch == '0'; tl++; }
+              else gt_ok = false;
+            }
+            uint32_t x = start;
+            const uint32_t c0 = byte_at(start);
+            if (c0 == '/' || c0 == '|') x++;
+            if (!gt_ok || tl == 0 || (!isdot && lead0 && tl > 1) || x >= e) set_err(err, VERR_BAD_GT);
+#pragma unroll
+            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = e - x; dsrc[s] = x; dok |= 1u << s; }
+          } else {                    // span for the typed span kernels (strings, lists)
+            const uint64_t o = (uint64_t)cur * N + c;
+            sp_state[o] = 1;
+            sp_off[o] = a + start;
+            sp_len[o] = sl;
+          }
+        }
+        j++;
+        start = e + 1;
+        if (e >= len) break;
+      }
+    }
+    if (have && len && !fast) select();
     uint32_t start = 0, ndig = 0, tl = 0;
     int64_t acc = 0;
     bool neg = false, bad = false, isdot = false, lead0 = false, gt_ok = true;
-    for (uint32_t k = 0; have && k <= len; k++) {
+    for (uint32_t k = 0; have && !fast && k <= len; k++) {
       const uint32_t ch = k < len ? byte_at(k) : (uint32_t)':';
       if (ch == ':') {
         const uint32_t sl = k - start;

@@ -448,3 +448,84 @@ def test_csi_and_unreadable_indexes(pkg, vo, tmp_path):
     _schema_equal(g4.schema(), o4.schema)
     with pytest.raises(RuntimeError, match="Failed to open indexed VCF"):
         list(g4.scan().execute(0, 8192))
+
+
+def _ms_vcf(cells_rows, fmt="GT:GQ:DP", extra_formats=()):
+    ns = len(cells_rows[0])
+    hdr = ["##fileformat=VCFv4.3", "##contig=<ID=c1,length=1000000>",
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">', '##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="q">',
+           '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="d">', '##FORMAT=<ID=PL,Number=G,Type=Integer,Description="p">',
+           '##FORMAT=<ID=FT,Number=1,Type=String,Description="f">', '##FORMAT=<ID=AF,Number=1,Type=Float,Description="a">']
+    hdr += list(extra_formats)
+    hdr.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"S{i}" for i in range(ns)))
+    lines = []
+    for k, row in enumerate(cells_rows):
+        f = fmt[k] if isinstance(fmt, list) else fmt
+        lines.append(f"c1\t{100 + k}\t.\tA\tT\t.\t.\t.\t{f}\t" + "\t".join(row))
+    return "\n".join(hdr + lines) + "\n"
+
+
+def test_format_cell_corners(pkg, vo, tmp_path):
+    """FORMAT cells the synthetic generator never writes: short and long cells (the 16-byte fast path and the byte-wise
+    path), signs, missing values, trailing fields left out, empty trailing sub-fields, phasing marks in front,
+    multi-digit alleles, keys in any order and keys that are not selected."""
+    rng = random.Random(77)
+    gts = ["0/1", "1|0", ".", "./.", "0", "10/2", "|0|1", "/1", "1/2/3", ".|.", "0|0|0|0", "12|345"]
+    ints = ["0", "7", "99", "250", ".", "-5", "+7", "2147483647", "-2147483648", "007"]
+    pls = ["0,30,300", ".", "0,255,255,0,12,1000", "1"]
+    fts = ["PASS", ".", "q10;s50", "a"]
+    afs = ["0.5", ".", "1e-3", "12.25"]
+    rows, fmts = [], []
+    for k in range(400):
+        keys = rng.choice([["GT", "GQ", "DP"], ["GT", "DP", "GQ"], ["GQ", "GT"], ["GT", "GQ", "DP", "PL"], ["GT", "FT", "GQ", "PL", "DP"],
+                           ["DP"], ["GT", "AF", "DP"], ["PL", "GT", "GQ"]])
+        row = []
+        for s in range(6):
+            vals = {"GT": rng.choice(gts), "GQ": rng.choice(ints), "DP": rng.choice(ints), "PL": rng.choice(pls), "FT": rng.choice(fts),
+                    "AF": rng.choice(afs)}
+            cell = [vals[x] for x in keys]
+            cut = rng.choice([None, None, None, 1, 2])          # trailing fields dropped
+            if cut is not None:
+                cell = cell[:max(1, min(cut, len(cell)))]
+            txt = ":".join(cell)
+            if rng.random() < 0.05:
+                txt = "."
+            row.append(txt)
+        rows.append(row)
+        fmts.append(":".join(keys))
+    p = tmp_path / "cells.vcf"
+    p.write_text(_ms_vcf(rows, fmts))
+    for ff in (["GT", "GQ", "DP"], ["DP", "PL", "GT"], ["GT", "FT", "AF", "GQ", "DP", "PL"], ["GQ"]):
+        assert _parity(pkg, vo, str(p), dict(format_fields=ff)) == 400
+    pz = tmp_path / "cells.vcf.gz"
+    pz.write_bytes(bgzf_compress(p.read_bytes(), 211))
+    assert _parity(pkg, vo, str(pz), dict(format_fields=["GT", "GQ", "DP"], index_path=None)) == 400
+
+
+@pytest.mark.parametrize("cell,fmt", [
+    ("0/x:5:5", "GT:GQ:DP"), ("1/:5:5", "GT:GQ:DP"), ("a:5:5", "GT:GQ:DP"), ("1//2:5:5", "GT:GQ:DP"),
+    ("0/1:1x:5", "GT:GQ:DP"), ("0/1:--1:5", "GT:GQ:DP"), ("0/1::5", "GT:GQ:DP"), ("0/1:5:2147483648", "GT:GQ:DP"),
+    ("0/1:5:-", "GT:GQ:DP"), ("0/1:5:5:", "GT:GQ:DP:GQ2"),
+    ("0/1:99999999999999999999:5", "GT:GQ:DP"), ("0/1:5:5:0,1x,3:abcdefghij", "GT:GQ:DP:PL:FT"),
+])
+def test_format_cell_errors_are_loud_on_both_sides(pkg, vo, tmp_path, cell, fmt):
+    extra = ['##FORMAT=<ID=GQ2,Number=1,Type=Integer,Description="x">']
+    p = tmp_path / "bad.vcf"
+    p.write_text(_ms_vcf([["0/1:1:1", cell]], fmt, extra))
+    ff = fmt.split(":")
+    o = vo.VcfOracle(str(p), format_fields=ff)
+    with pytest.raises(Exception):
+        o.execute(o.scan())
+    g = pkg.VcfTableProvider(str(p), None, ff)
+    with pytest.raises(pkg.BioscanError):
+        list(g.scan().execute(0, 8192))
+
+
+def test_gt_with_leading_zero_allele_is_refused(pkg, tmp_path):
+    """noodles parses allele indices as integers and the reference re-renders them ("01/1" -> "1/1"); the device path
+    copies the GT text, so an allele it could not reproduce byte for byte is refused loudly instead of being passed on."""
+    p = tmp_path / "lz.vcf"
+    p.write_text(_ms_vcf([["0/1:1:1", "01/1:5:5"]]))
+    g = pkg.VcfTableProvider(str(p), None, ["GT", "GQ", "DP"])
+    with pytest.raises(pkg.BioscanError):
+        list(g.scan().execute(0, 8192))
