@@ -802,23 +802,37 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       std::vector<DevBuf<uint32_t>> keeps(queries.size());
       std::vector<DevBuf<uint64_t>> scans(queries.size());
       std::vector<uint64_t> totals(queries.size(), 0), i_los(queries.size(), 0), i_ns(queries.size(), 0);
-      DevBuf<unsigned long long> lb(2);
-      for (size_t qi = 0; qi < queries.size() && !never; qi++) {
+      // two host round trips for all regions together (they used to cost two each): the line ranges of the regions'
+      // chunk spans first, then -- after every region's flags and scan have been queued -- the totals
+      const size_t nq = queries.size();
+      DevBuf<unsigned long long> lb(2 * nq + 2);
+      std::vector<unsigned long long> h_lb(2 * nq + 2, 0);
+      for (size_t qi = 0; qi < nq && !never; qi++) {
         auto& q = queries[qi];
         if (q.chunks_abs.empty()) continue;
         if (q.chunks_abs.size() > 4096) throw Error("region query expands to more than 4096 index chunks");
-        unsigned long long i_lo = 0, i_hi = 0;
-        launch_vcf_line_lower_bound(L, q.chunks_abs.front().first - base, lb.p, st);
-        launch_vcf_line_lower_bound(L, q.chunks_abs.back().second - base, lb.p + 1, st);
-        unsigned long long h2[2];
-        HIP_CHECK(hipMemcpyAsync(h2, lb.p, 16, hipMemcpyDeviceToHost, st));
+        launch_vcf_line_lower_bound(L, q.chunks_abs.front().first - base, lb.p + 2 * qi, st);
+        launch_vcf_line_lower_bound(L, q.chunks_abs.back().second - base, lb.p + 2 * qi + 1, st);
+      }
+      if (nq && !never) {
+        HIP_CHECK(hipMemcpyAsync(h_lb.data(), lb.p, (2 * nq) * 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        i_lo = h2[0]; i_hi = h2[1];
+      }
+      std::vector<DevBuf<uint64_t>> d_chs(nq);
+      uint64_t max_cnt = 0;
+      for (size_t qi = 0; qi < nq && !never; qi++)
+        if (!queries[qi].chunks_abs.empty() && h_lb[2 * qi + 1] > h_lb[2 * qi]) max_cnt = std::max<uint64_t>(max_cnt, h_lb[2 * qi + 1] - h_lb[2 * qi]);
+      DevBuf<uint64_t> tmp2(scan_tmp_elems(std::max<uint64_t>(max_cnt, 1)));  // the scans run one after the other on the stream
+      bool queued = false;
+      for (size_t qi = 0; qi < nq && !never; qi++) {
+        auto& q = queries[qi];
+        if (q.chunks_abs.empty()) continue;
+        const unsigned long long i_lo = h_lb[2 * qi], i_hi = h_lb[2 * qi + 1];
         if (i_hi <= i_lo) continue;
         std::vector<uint64_t> ch;
         for (auto& c : q.chunks_abs) { ch.push_back(c.first - base); ch.push_back(c.second - base); }
-        DevBuf<uint64_t> d_ch(ch.size());
-        HIP_CHECK(hipMemcpyAsync(d_ch.p, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, st));
+        d_chs[qi].alloc(ch.size());
+        HIP_CHECK(hipMemcpyAsync(d_chs[qi].p, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, st));  // pageable source: copied before the call returns
         VcfRowSelect S{};
         S.mode = 1;
         S.n_chunks = (int32_t)q.chunks_abs.size();
@@ -834,14 +848,14 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
         const uint64_t cntl = i_hi - i_lo;
         keeps[qi].alloc(cntl + 1);
         scans[qi].alloc(cntl + 2);
-        launch_vcf_row_flags(u, L, k_pos.p, k_vend.p, k_flags.p, S, d_ch.p, d_terms.p, d_blob.p, keeps[qi].p, st);
-        DevBuf<uint64_t> tmp2(scan_tmp_elems(cntl));
+        launch_vcf_row_flags(u, L, k_pos.p, k_vend.p, k_flags.p, S, d_chs[qi].p, d_terms.p, d_blob.p, keeps[qi].p, st);
         launch_exclusive_scan_u32_to_u64(keeps[qi].p, scans[qi].p, cntl, tmp2.p, st);
         HIP_CHECK(hipMemcpyAsync(&totals[qi], scans[qi].p + cntl, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
+        queued = true;
         i_los[qi] = i_lo;
         i_ns[qi] = cntl;
       }
+      if (queued) HIP_CHECK(hipStreamSynchronize(st));
       uint64_t total = 0;
       for (auto v : totals) total += v;
       n = std::min<uint64_t>(total, cap);
