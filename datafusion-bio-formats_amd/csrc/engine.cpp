@@ -31,13 +31,14 @@ static thread_local std::string g_err;
 // ---- device allocation cache (see common.h) -------------------------------------------------------
 namespace bioscan {
 static std::mutex g_pool_mu;
-static std::multimap<size_t, void*> g_pool;
+static std::multimap<std::pair<int, size_t>, void*> g_pool;  // (device, bytes) -> cached block
 static size_t g_pool_bytes = 0;
 constexpr size_t POOL_MIN = 1;  // every block is cached: hipFree of even a tiny block synchronises the device
+static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 void* dev_pool_alloc(size_t bytes) {
   if (bytes >= POOL_MIN) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool.find(bytes);
+    auto it = g_pool.find({cur_device(), bytes});
     if (it != g_pool.end()) {
       void* p = it->second;
       g_pool.erase(it);
@@ -57,7 +58,7 @@ void* dev_pool_alloc(size_t bytes) {
 void dev_pool_free(void* p, size_t bytes) {
   if (bytes >= POOL_MIN) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.emplace(bytes, p);
+    g_pool.emplace(std::make_pair(cur_device(), bytes), p);
     g_pool_bytes += bytes;
     return;
   }
@@ -65,7 +66,7 @@ void dev_pool_free(void* p, size_t bytes) {
 }
 void dev_pool_trim() {
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (auto& kv : g_pool) (void)hipFree(kv.second);
+  for (auto& kv : g_pool) (void)hipFree(kv.second);  // hipFree takes a pointer of any device
   g_pool.clear();
   g_pool_bytes = 0;
 }
