@@ -309,9 +309,42 @@ __global__ __launch_bounds__(256) void k_scatter_ranges_rows(const uint8_t* __re
     *(rs_u32x4*)(d + cc) = *(const rs_u32x4*)(s + cc);
   }
 }
+// Tiny rows (GT strings, CHROM, REF, ALT ...: a few bytes each): one lane per row, the row travels in a register -- one
+// unaligned 8-byte load (the source buffers have slack), then exactly `len` bytes go out in 4 / 2 / 1-byte pieces, so
+// neighbouring rows written by neighbouring lanes are never touched.  Longer rows loop over 8-byte chunks with an
+// overlapping tail.  (The output-centric kernel spends a binary search per output byte on such rows.)
+struct __attribute__((packed, aligned(1))) rs_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) rs_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) rs_u16 { uint16_t v; };
+__global__ __launch_bounds__(256) void k_scatter_ranges_tiny(const uint8_t* __restrict__ u, const uint64_t* __restrict__ src, uint64_t n,
+                                                              const uint64_t* __restrict__ off64, uint8_t* __restrict__ dst) {
+  const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t o = off64[r];
+  const uint32_t len = (uint32_t)(off64[r + 1] - o);
+  if (!len) return;
+  const uint8_t* s = u + src[r];
+  uint8_t* d = dst + o;
+  if (len >= 8) {
+    for (uint32_t c = 0; c < len; c += 8) {
+      const uint32_t cc = c + 8 <= len ? c : len - 8;
+      ((rs_u64*)(d + cc))->v = ((const rs_u64*)(s + cc))->v;
+    }
+    return;
+  }
+  uint64_t w = ((const rs_u64*)s)->v;
+  uint32_t k = 0;
+  if (len & 4) { ((rs_u32*)d)->v = (uint32_t)w; w >>= 32; k = 4; }
+  if (len & 2) { ((rs_u16*)(d + k))->v = (uint16_t)w; w >>= 16; k += 2; }
+  if (len & 1) d[k] = (uint8_t)w;
+}
 void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
                            hipStream_t st) {
   if (!n) return;
+  if (!getenv("BIOSCAN_SCATTER_V1") && total_bytes <= 8 * n) {
+    hipLaunchKernelGGL(k_scatter_ranges_tiny, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
+    return;
+  }
   // the average row length picks the shape: tiny fields (CHROM, REF, ALT ...) keep the output-centric kernel,
   // medium rows get 4 lanes each, reads 16 lanes each
   if (getenv("BIOSCAN_SCATTER_V1") || total_bytes < 16 * n)
