@@ -25,8 +25,8 @@ __device__ __forceinline__ uint32_t ld_u16(const uint8_t* p) { return (uint32_t)
 // =================================================================================================
 // exclusive scan u32 -> u64 (three-kernel, 2048 elements per block)
 // =================================================================================================
-constexpr int SCAN_T = 256;
-constexpr int SCAN_PER = 8;
+constexpr int SCAN_T = 1024;  // 2 elements per thread: a lane stores 16 contiguous bytes, a wave 1 KiB
+constexpr int SCAN_PER = 2;
 constexpr int SCAN_BLOCK = SCAN_T * SCAN_PER;
 
 size_t scan_tmp_elems(uint64_t n) { return (size_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK) + 2; }
