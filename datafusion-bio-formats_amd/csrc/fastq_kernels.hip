@@ -74,6 +74,7 @@ constexpr int NL_NEXT_SHIFT = 48;
 constexpr int NL_CHUNK = 16384;
 constexpr int NL_PER_THREAD = 64;
 struct __attribute__((packed, aligned(1))) nl_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) nl_u64x2 { uint64_t a, b; };
 
 // bit 8k+7 of the result is set iff byte k of w equals '\n'
 __device__ __forceinline__ uint64_t nl_mask8(uint64_t w) {
@@ -85,14 +86,28 @@ __device__ __forceinline__ uint64_t nl_mask8(uint64_t w) {
 __device__ __forceinline__ uint32_t nl_thread_masks(const uint8_t* __restrict__ u, uint64_t a, uint64_t hi, uint64_t m[8],
                                                      uint64_t* words = nullptr) {
   uint32_t n = 0;
+  uint64_t wv[8];
+  if (a + 64 <= hi) {  // whole 64 bytes inside the range: four 16-byte loads
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const nl_u64x2 v = *(const nl_u64x2*)(u + a + 16 * k);
+      wv[2 * k] = v.a; wv[2 * k + 1] = v.b;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint64_t p = a + 8 * k;
+      uint64_t w = 0;
+      if (p + 8 <= hi) w = ((const nl_u64*)(u + p))->v;
+      else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
+      wv[k] = w;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint64_t p = a + 8 * k;
-    uint64_t w = 0;
-    if (p + 8 <= hi) w = ((const nl_u64*)(u + p))->v;
-    else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
-    m[k] = p < hi ? nl_mask8(w) : 0ull;
-    if (words) words[k] = w;
+    m[k] = p < hi ? nl_mask8(wv[k]) : 0ull;
+    if (words) words[k] = wv[k];
     n += (uint32_t)__popcll(m[k]);
   }
   return n;
