@@ -21,6 +21,7 @@ constexpr int WAVE = 64;
 constexpr int DL_CHUNK = 16384;
 constexpr int DL_PER_THREAD = 64;
 struct __attribute__((packed, aligned(1))) dl_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) dl_u64x2 { uint64_t a, b; };
 struct __attribute__((packed, aligned(1))) dl_u32 { uint32_t v; };
 
 // bit 8k+7 of the result is set iff byte k of w equals c (c replicated in `pat`)
@@ -32,12 +33,27 @@ __device__ __forceinline__ uint64_t eq_mask8(uint64_t w, uint64_t pat) {
 __device__ __forceinline__ void dl_thread_masks(const uint8_t* __restrict__ u, uint64_t a, uint64_t hi, uint64_t mn[8], uint64_t mt[8],
                                                 uint32_t* n_nl, uint32_t* n_tab) {
   uint32_t cn = 0, ct = 0;
+  uint64_t wv[8];
+  if (a + 64 <= hi) {  // whole 64 bytes inside the range: four 16-byte loads
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const dl_u64x2 v = *(const dl_u64x2*)(u + a + 16 * k);
+      wv[2 * k] = v.a; wv[2 * k + 1] = v.b;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint64_t p = a + 8 * k;
+      uint64_t w = 0;
+      if (p + 8 <= hi) w = ((const dl_u64*)(u + p))->v;
+      else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
+      wv[k] = w;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const uint64_t p = a + 8 * k;
-    uint64_t w = 0;
-    if (p + 8 <= hi) w = ((const dl_u64*)(u + p))->v;
-    else if (p < hi) { for (uint64_t q = p; q < hi; q++) w |= (uint64_t)u[q] << (8 * (q - p)); }
+    const uint64_t w = wv[k];
     uint64_t a_n = 0, a_t = 0;
     if (p < hi) {
       a_n = eq_mask8(w, 0x0A0A0A0A0A0A0A0Aull);
