@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_scatter_ranges_tiny(const uint8_t* __re
 void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
                            hipStream_t st) {
   if (!n) return;
-  if (!getenv("BIOSCAN_SCATTER_V1") && total_bytes <= 8 * n) {
+  if (!getenv("BIOSCAN_SCATTER_V1") && total_bytes < 16 * n) {
     hipLaunchKernelGGL(k_scatter_ranges_tiny, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
     return;
   }
@@ -366,6 +366,8 @@ void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, co
     hipLaunchKernelGGL(k_scatter_ranges, dim3((uint32_t)((n + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0, st, u, src, n, off64, dst);
   else if (total_bytes < 48 * n)
     hipLaunchKernelGGL(k_scatter_ranges_rows<4>, dim3((uint32_t)((n * 4 + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
+  else if (total_bytes < 144 * n)   // e.g. 101-base reads: 7 of 8 lanes busy instead of 7 of 16
+    hipLaunchKernelGGL(k_scatter_ranges_rows<8>, dim3((uint32_t)((n * 8 + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
   else
     hipLaunchKernelGGL(k_scatter_ranges_rows<16>, dim3((uint32_t)((n * 16 + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
 }
