@@ -112,3 +112,51 @@ def test_region_filters(pkg, oracle, golden):
                 got = list(plan.execute(p, 1000))
                 _, want = orc.execute_partition(parts[p].regions, None, residual, 1000)
                 _cmp_batches(got, want, (filters, target, p))
+
+
+@pytest.mark.parametrize("fname", ["multi_chrom_large.bam", "nanopore_custom_tags.bam"])
+def test_binary_cigar_option(pkg, oracle, golden, fname):
+    """bio.bam.binary_cigar=true: cigar is a Binary column of the raw little-endian ops (alignment_utils.rs:554-558)."""
+    path = os.path.join(golden, fname)
+    prov = pkg.BamTableProvider(path, None, True, None, binary_cigar=True)
+    orc = oracle.BamOracle(path, zero_based=True, binary_cigar=True)
+    assert prov.schema().equals(orc.schema, check_metadata=False)
+    assert prov.schema().field("cigar").type == pa.binary()
+    assert prov.schema().metadata[b"bio.bam.binary_cigar"] == b"true"
+    for target in (1, 3):
+        plan = prov.scan(target_partitions=target)
+        parts, residual = orc.scan(target_partitions=target)
+        assert plan.num_partitions() == len(parts)
+        for p in range(len(parts)):
+            got = list(plan.execute(p, 500))
+            _, want = orc.execute_partition(parts[p].regions, None, residual, 500)
+            _cmp_batches(got, want, (fname, "binary_cigar", target, p))
+
+
+@pytest.mark.parametrize("fname,tags", [("10x_pbmc_tags.bam", ["CB", "xf", "ts", "NH", "ZZ"]), ("nanopore_custom_tags.bam", ["de", "tp", "rl", "NM"])])
+def test_tag_type_inference_options(pkg, oracle, golden, fname, tags):
+    """Schema and values with inference on (sample sizes 1 and 100), off, and with hints (table_provider.rs:72-126):
+    inferred > hint > registry > Utf8."""
+    path = os.path.join(golden, fname)
+    for kw in (dict(infer_tag_types=True, infer_tag_sample_size=1), dict(infer_tag_types=True, infer_tag_sample_size=100),
+               dict(infer_tag_types=False), dict(infer_tag_types=False, tag_type_hints=[f"{tags[1]}:Z", f"{tags[2]}:i"]),
+               dict(infer_tag_types=True, infer_tag_sample_size=3, tag_type_hints=[f"{tags[0]}:Z"])):
+        try:
+            orc = oracle.BamOracle(path, zero_based=True, tag_fields=tags, index_path=None, **kw)
+            want_err = None
+        except Exception as e:  # noqa: BLE001
+            orc, want_err = None, e
+        if want_err is not None:
+            with pytest.raises(Exception):
+                pkg.BamTableProvider(path, None, True, tags, index_path="", **kw)
+            continue
+        prov = pkg.BamTableProvider(path, None, True, tags, index_path="", **kw)
+        assert prov.schema().equals(orc.schema, check_metadata=True), (kw, prov.schema(), orc.schema)
+        try:
+            _, want = orc.execute_sequential(None, 8192)
+        except Exception:  # a hint that contradicts the data: both sides refuse
+            with pytest.raises(RuntimeError):
+                list(prov.scan().execute(0, 8192))
+            continue
+        got = list(prov.scan().execute(0, 8192))
+        _cmp_batches(got, want, (fname, kw))
