@@ -729,12 +729,11 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
           }
         }
         V2_SYNC();
-        if (uni2((uint32_t)L.b.pre_lens[19])) { st = INF_BAD_CODE | (6u << 8); break; }
         {
           const uint32_t total = hlit + hdist;
           uint32_t i = 0, prev = 0;
-          int bad = 0;
-          while (i < total) {
+          int bad = (int)uni2((uint32_t)L.b.pre_lens[19]);  // invalid code-length code (set by the table build above)
+          while (i < total && !bad) {
             ub_refill(in, lane);
             uint32_t e = uni2(L.b.pre_fast[(uint32_t)in.bb & 127]);
             uint32_t l = e & 7, sym = e >> 3;
