@@ -385,12 +385,12 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
     }
     bool bad = false;                                      // (an unassigned code is a pointer to STOP_BAD)
     if (MODE == 1) { if (is_lit && !V2_G(opos >= win_base, 2, opos)) out[opos] = (uint8_t)(e >> 4); }
-    if (MODE == 2) { if (is_lit) L.win[opos - win_base] = (uint8_t)(e >> 4); }
+    if (MODE == 2) { if (is_lit) (L.win - win_base)[opos] = (uint8_t)(e >> 4); }  // base pointer folded: one VALU less than an index subtraction
     if (is_len) mlen = WRITE ? val : val + (1u << 20);   // count passes carry the match count in the same accumulator
     bool okm = is_dist;
     if (WRITE) {
       if (okm && val > opos) { bad = true; okm = false; }
-      if (okm && !V2_G(mpos >= V2_SCRATCH_STRIDE, 3, mpos)) mlist[mpos] = (unsigned long long)opos | ((unsigned long long)mlen << 32) | ((unsigned long long)val << 44);
+      if (okm && !V2_G(mpos >= V2_SCRATCH_STRIDE, 3, mpos)) { uint2 ent; ent.x = opos; ent.y = mlen | (val << 12); ((uint2*)mlist)[mpos] = ent; }  // = opos | mlen << 32 | val << 44
       mpos += okm ? 1u : 0u;
     }
     const uint32_t produced = is_lit ? 1u : (okm ? mlen : 0u);
