@@ -36,7 +36,7 @@ void BgzfSource::load_file() {
   long sz = ftell(f);
   fseek(f, 0, SEEK_SET);
   file_len = (size_t)sz;
-  file.alloc(file_len + 4096);
+  file.alloc(file_len + 4096, /*use_pool=*/false);  // released right after the upload: not worth caching
   size_t got = 0;
   while (got < file_len) {
     size_t r = fread(file.p + got, 1, std::min<size_t>(file_len - got, 1u << 30), f);

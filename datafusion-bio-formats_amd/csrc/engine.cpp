@@ -70,6 +70,65 @@ void dev_pool_trim() {
   g_pool.clear();
   g_pool_bytes = 0;
 }
+// ---- pinned host block cache ----
+static std::mutex g_hpool_mu;
+static std::multimap<size_t, void*> g_hpool;  // class size -> pinned block
+static size_t g_hpool_bytes = 0;
+static size_t host_class(size_t bytes) {
+  if (bytes <= 4096) return 4096;
+  size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));  // highest power of two <= bytes
+  const size_t step = top >> 2;                                                  // four classes per octave
+  return (bytes + step - 1) / step * step;
+}
+static size_t host_pool_limit() {
+  static const size_t lim = [] {
+    const char* e = getenv("BIOSCAN_HOST_POOL_GB");
+    return (size_t)(e ? atof(e) : 64.0) << 30;
+  }();
+  return lim;
+}
+void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned) {
+  const size_t c = host_class(bytes);
+  {
+    std::lock_guard<std::mutex> lk(g_hpool_mu);
+    auto it = g_hpool.find(c);
+    if (it != g_hpool.end()) {
+      void* p = it->second;
+      g_hpool.erase(it);
+      g_hpool_bytes -= c;
+      *cap = c; *pinned = true;
+      return p;
+    }
+  }
+  void* p = nullptr;
+  if (hipHostMalloc(&p, c, hipHostMallocDefault) == hipSuccess) { *cap = c; *pinned = true; return p; }
+  (void)hipGetLastError();
+  host_pool_trim();  // pinned memory exhausted: give the cached blocks back and try once more, then fall back to pageable
+  if (hipHostMalloc(&p, c, hipHostMallocDefault) == hipSuccess) { *cap = c; *pinned = true; return p; }
+  (void)hipGetLastError();
+  p = malloc(c);
+  if (!p) throw Error("out of host memory");
+  *cap = c; *pinned = false;
+  return p;
+}
+void host_pool_free(void* p, size_t cap, bool pinned) {
+  if (!pinned) { free(p); return; }
+  {
+    std::lock_guard<std::mutex> lk(g_hpool_mu);
+    if (g_hpool_bytes + cap <= host_pool_limit()) {
+      g_hpool.emplace(cap, p);
+      g_hpool_bytes += cap;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+void host_pool_trim() {
+  std::lock_guard<std::mutex> lk(g_hpool_mu);
+  for (auto& kv : g_hpool) (void)hipHostFree(kv.second);
+  g_hpool.clear();
+  g_hpool_bytes = 0;
+}
 }  // namespace bioscan
 
 namespace {
@@ -1734,6 +1793,7 @@ void bioscan_plan_close(bioscan_plan* p) { delete p; }
 void bioscan_provider_close(bioscan_provider* p) {
   delete p;
   dev_pool_trim();
+  host_pool_trim();
 }
 
 int bioscan_provider_make_resident(bioscan_provider* p) {
