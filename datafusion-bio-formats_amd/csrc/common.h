@@ -89,9 +89,10 @@ struct DevBuf {
 
 // host buffer: pinned when the driver grants it, pageable otherwise (8 ranks pinning 16 GB each can exceed the
 // node's locked-memory budget; a pageable source only makes the one-off upload slower)
-// Cache of pinned host blocks (size classes with <= 25 % slack): hipHostMalloc / hipHostFree of the gigabytes a
-// partition's columns take costs far more than the PCIe copy itself (measured: 5.2 GB of Arrow buffers, 1.1-1.6 s with
-// fresh pinned allocations per execute against ~0.15 s of copy time), so result buffers are recycled.
+// Cache of host blocks (size classes with <= 25 % slack) for result buffers.  They are plain malloc'd memory: pinning
+// gigabytes per execute cost far more than the PCIe copy itself (5.2 GB of Arrow buffers: 1.1-1.6 s with fresh pinned
+// allocations against ~0.15 s of copy time), a fresh pageable block takes the copy at 17 GB/s and a recycled one --
+// its pages already touched -- at the full link rate.
 void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned);
 void host_pool_free(void* p, size_t cap, bool pinned);
 void host_pool_trim();
@@ -118,7 +119,7 @@ struct HostBuf {
       p = (uint8_t*)host_pool_alloc(bytes ? bytes : 1, &cap, &pinned);
       return;
     }
-    cap = bytes ? bytes : 1;
+    cap = bytes ? bytes : 1;  // the file image: read once, uploaded once -- pinned memory is the faster path for that (3.3 s against 6.2 s for 16.5 GB)
     if (hipHostMalloc((void**)&p, cap, hipHostMallocDefault) == hipSuccess) { pinned = true; return; }
     (void)hipGetLastError();
     p = (uint8_t*)malloc(cap);
