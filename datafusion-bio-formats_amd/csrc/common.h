@@ -1,6 +1,7 @@
 // common.h -- shared host-side definitions (Arrow C Data Interface structs, HIP RAII, errors).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <stdexcept>
@@ -100,13 +101,13 @@ void host_pool_trim();
 struct HostBuf {
   uint8_t* p = nullptr;
   size_t n = 0, cap = 0;
-  bool pinned = false, pooled = false;
+  bool pinned = false, pooled = false, mapped = false;
   HostBuf() = default;
   HostBuf(const HostBuf&) = delete;
   HostBuf& operator=(const HostBuf&) = delete;
-  HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), pinned(o.pinned), pooled(o.pooled) { o.p = nullptr; o.n = 0; }
+  HostBuf(HostBuf&& o) noexcept : p(o.p), n(o.n), cap(o.cap), pinned(o.pinned), pooled(o.pooled), mapped(o.mapped) { o.p = nullptr; o.n = 0; }
   HostBuf& operator=(HostBuf&& o) noexcept {
-    if (this != &o) { reset(); p = o.p; n = o.n; cap = o.cap; pinned = o.pinned; pooled = o.pooled; o.p = nullptr; o.n = 0; }
+    if (this != &o) { reset(); p = o.p; n = o.n; cap = o.cap; pinned = o.pinned; pooled = o.pooled; mapped = o.mapped; o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~HostBuf() { reset(); }
@@ -126,8 +127,17 @@ struct HostBuf {
     pinned = false;
     if (!p) throw Error("out of host memory");
   }
+  // read-only view of a file (no copy: the pages come straight from the page cache and are uploaded from there)
+  bool map_file(int fd, size_t bytes) {
+    reset();
+    void* m = mmap(nullptr, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return false;
+    p = (uint8_t*)m; n = bytes; cap = bytes; mapped = true; pooled = false; pinned = false;
+    return true;
+  }
   void reset() {
     if (!p) return;
+    if (mapped) { munmap(p, cap); p = nullptr; n = 0; cap = 0; mapped = false; return; }
     if (pooled) host_pool_free(p, cap, pinned);
     else if (pinned) (void)hipHostFree(p);
     else free(p);
