@@ -189,3 +189,33 @@ def test_synthetic_fastq_partitions(pkg, fo, tmp_path):
             _cmp(got[p], want, (target, p))
             n += sum(b.num_rows for b in got[p])
         assert n == meta["n_records"]
+
+
+def test_random_line_lengths_and_line_ends(pkg, fo, tmp_path):
+    """Randomised record shapes so that '\\n', '\\r', '@' and '+' land on every position of the newline kernels' 64-byte
+    lane chunks and 16 KiB tiles (the index entries carry the bytes around each newline), plain and BGZF."""
+    import random
+    rng = random.Random(2025)
+    recs = []
+    for i in range(30000):
+        name = "".join(rng.choice("abcXYZ09:._/") for _ in range(rng.randint(1, 40)))
+        desc = rng.choice(["", " d", "\tq=1 z", " " + "x" * rng.randint(1, 70)])
+        ln = rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 101, 150, rng.randint(1, 300)])
+        seq = "".join(rng.choice("ACGTN") for _ in range(ln))
+        qual = "".join(rng.choice("@+IJ#5?~!") for _ in range(ln))
+        eol = rng.choice(["\n", "\n", "\r\n"])
+        recs.append(f"@{name}{desc}{eol}{seq}{eol}+{eol}{qual}{eol}")
+    text = "".join(recs).encode()
+    plain = str(tmp_path / "rnd.fastq")
+    open(plain, "wb").write(text)
+    path = str(tmp_path / "rnd.fastq.bgz")
+    cuts = [text[o:o + 60000] for o in range(0, len(text), 60000)]
+    open(path, "wb").write(_bgzf(cuts))
+    for p_ in (plain, path):
+        orc = fo.FastqOracle(p_)
+        strat, parts = orc.scan(1)
+        prov, plan, got = _run_gpu(pkg, p_, 1, bs=8192)
+        assert plan.num_partitions() == len(parts) == 1
+        _, want = orc.execute(strat, parts[0], batch_size=8192)
+        _cmp(got[0], want, (p_, "random"))
+        assert sum(b.num_rows for b in got[0]) == 30000
