@@ -81,6 +81,8 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
     sync()
     elapsed = time.perf_counter() - t0
     rows, ubytes = float(st["n_rows"]), float(st["inflated_bytes"])
+    if int(st["n_rows"]) != int(meta["n_records"]):  # full-size property: every read the generator wrote comes back
+        raise SystemExit(f"rank {rank}: the scan returned {st['n_rows']} rows, the generator wrote {meta['n_records']} reads")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -420,6 +422,9 @@ def main():
         extract_ms.append(stats["ms_extract"])
     sync()
     elapsed = time.perf_counter() - t0
+    # full-size property: every record the generator wrote comes back (and K2 has checked the CRC32 of every member)
+    if (args.mode == "sequential" or world == 1) and int(stats["n_rows"]) != int(meta["n_records"]):
+        raise SystemExit(f"rank {rank}: the scan returned {stats['n_rows']} rows, the generator wrote {meta['n_records']} records")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
