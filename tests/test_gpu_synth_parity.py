@@ -88,3 +88,40 @@ def test_multi_gpu_sharding_reproduces_single_gpu_order(pkg, synth):
                 for b in rank_plan.execute(p, 8192):
                     got.extend(zip(b.column(0).to_pylist(), b.column(1).to_pylist()))
         assert got == single, world
+
+
+def test_large_file_properties(pkg):
+    """Size-independent properties on a file too large for a value-by-value comparison (65 536 members by default;
+    BIOSCAN_TEST_LARGE_BLOCKS=650000 is BASELINE.json's config 2): every member's CRC32 and ISIZE hold (K2 / K1 gates,
+    a failure raises), the record chain ends exactly at the end of the inflated stream, every record the generator wrote
+    comes back, a second run gives the same totals, and the BAI plan returns the same number of rows in total."""
+    blocks = int(os.environ.get("BIOSCAN_TEST_LARGE_BLOCKS", "65536"))
+    exe = os.path.join(ROOT, "tools", "_build", "synth_bam")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(base, f"bioscan_large_{os.getpid()}.bam")
+    try:
+        meta = json.loads(subprocess.check_output([exe, path, str(blocks), "11", str(min(16, os.cpu_count() or 1))]).decode())
+        prov = pkg.BamTableProvider(path, index_path="")
+        prov.make_resident()
+        plan = prov.scan(target_partitions=1)
+        first = plan.execute_device(0, 8192)
+        assert first["n_rows"] == first["n_records"] == meta["n_records"]
+        assert first["inflated_bytes"] >= meta["inflated_bytes"]          # + the header member(s)
+        assert first["compressed_bytes"] == meta["compressed_bytes"]
+        again = plan.execute_device(0, 8192)
+        for k in ("n_rows", "n_records", "n_blocks", "inflated_bytes", "arrow_bytes"):
+            assert again[k] == first[k], k
+        count = prov.scan(projection=[], target_partitions=1).execute_device(0, 8192)
+        assert count["n_rows"] == meta["n_records"]
+        del prov, plan
+        indexed = pkg.BamTableProvider(path)
+        iplan = indexed.scan(projection=[0, 2], target_partitions=8)
+        assert sum(iplan.execute_device(p, 8192)["n_rows"] for p in range(iplan.num_partitions())) == meta["n_records"]
+    finally:
+        for p in (path, path + ".bai"):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass
