@@ -219,3 +219,39 @@ def test_random_line_lengths_and_line_ends(pkg, fo, tmp_path):
         _, want = orc.execute(strat, parts[0], batch_size=8192)
         _cmp(got[0], want, (p_, "random"))
         assert sum(b.num_rows for b in got[0]) == 30000
+
+
+def test_large_file_properties(pkg):
+    """Size-independent properties on a file too large for a value-by-value comparison (32 768 members by default,
+    BIOSCAN_TEST_LARGE_BLOCKS overrides): CRC32 + ISIZE of every member (a failure raises), every generated read comes
+    back from the unsplit scan, a second run gives the same totals, and the GZI plan of 8 partitions neither loses nor
+    duplicates a read (fastq/tests/parallel_read_test.rs: same rows for 1 and N partitions)."""
+    import json
+    import subprocess
+    blocks = int(os.environ.get("BIOSCAN_TEST_LARGE_BLOCKS", "32768"))
+    exe = os.path.join(ROOT, "tools", "_build", "synth_fastq")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(base, f"bioscan_large_{os.getpid()}.fastq.bgz")
+    try:
+        meta = json.loads(subprocess.check_output([exe, path, str(blocks), "13", str(min(16, os.cpu_count() or 1))]).decode())
+        prov = pkg.FastqTableProvider(path)
+        plan = prov.scan(target_partitions=1)
+        first = plan.execute_device(0, 8192)
+        assert first["n_rows"] == meta["n_records"]
+        assert first["inflated_bytes"] == meta["inflated_bytes"]
+        again = plan.execute_device(0, 8192)
+        for k in ("n_rows", "n_blocks", "inflated_bytes", "arrow_bytes"):
+            assert again[k] == first[k], k
+        split = prov.scan(target_partitions=8)
+        assert split.num_partitions() == 8
+        parts = [split.execute_device(p, 8192) for p in range(8)]
+        assert sum(s["n_rows"] for s in parts) == meta["n_records"]
+        assert all(s["n_rows"] > 0 for s in parts)
+    finally:
+        for p in (path, path + ".gzi"):
+            try:
+                os.unlink(p)
+            except OSError:
+                pass

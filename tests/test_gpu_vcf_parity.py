@@ -529,3 +529,51 @@ def test_gt_with_leading_zero_allele_is_refused(pkg, tmp_path):
     g = pkg.VcfTableProvider(str(p), None, ["GT", "GQ", "DP"])
     with pytest.raises(pkg.BioscanError):
         list(g.scan().execute(0, 8192))
+
+
+def test_large_file_properties(pkg, tmp_path):
+    """Size-independent properties on files too large for a value-by-value comparison (BIOSCAN_TEST_LARGE_LINES overrides
+    the 4 M-site default; 60 000 000 is BASELINE config 3): CRC32 + ISIZE of every member (a failure raises), every
+    generated line comes back, `chrom = 'chr1'` returns exactly the generator's count, a second run gives the same
+    totals, and the tabix plans of 8 and 16 partitions return the same number of rows in total; the multi-sample form
+    returns lines x samples list cells and the same UDF checksum on a second run."""
+    n_lines = int(os.environ.get("BIOSCAN_TEST_LARGE_LINES", "4000000"))
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    path = os.path.join(base, f"bioscan_large_{os.getpid()}.vcf.gz")
+    spath = os.path.join(base, f"bioscan_large_{os.getpid()}_s.vcf.gz")
+    try:
+        meta = _synth(tmp_path, "sites", path, n_lines, 17, min(16, os.cpu_count() or 1))
+        seq = pkg.VcfTableProvider(path, index_path="")
+        plan = seq.scan(target_partitions=1)
+        first = plan.execute_device(0, 8192)
+        assert first["n_rows"] == n_lines
+        again = plan.execute_device(0, 8192)
+        for k in ("n_rows", "n_blocks", "inflated_bytes", "arrow_bytes"):
+            assert again[k] == first[k], k
+        del seq, plan
+        prov = pkg.VcfTableProvider(path)
+        for target in (8, 16):
+            p = prov.scan(target_partitions=target)
+            assert sum(p.execute_device(i, 8192)["n_rows"] for i in range(p.num_partitions())) == n_lines, target
+        p = prov.scan(filters=[("chrom", "=", "chr1")], target_partitions=8)
+        assert sum(p.execute_device(i, 8192)["n_rows"] for i in range(p.num_partitions())) == meta["n_lines_chr1"]
+        del prov, p
+
+        lines, samples = max(2000, n_lines // 200), 500
+        _synth(tmp_path, "samples", spath, lines, samples, 19, min(16, os.cpu_count() or 1))
+        ms = pkg.VcfTableProvider(spath, index_path="")
+        mplan = ms.scan(target_partitions=1)
+        a = mplan.execute_device_udf(0, "GQ", "list_avg")
+        b = mplan.execute_device_udf(0, "GQ", "list_avg")
+        assert a["scan"]["n_rows"] == lines and a["udf"]["n_rows"] == lines
+        for k in ("n_rows", "n_elements", "count_a", "count_b", "sum"):
+            assert a["udf"][k] == b["udf"][k], k
+        assert a["udf"]["n_elements"] == lines * samples
+        c = mplan.execute_device_udf(0, "DP", "list_gte", 0)
+        assert c["udf"]["n_elements"] == lines * samples and c["udf"]["count_a"] + c["udf"]["count_b"] == lines * samples
+    finally:
+        for f in (path, path + ".tbi", spath, spath + ".tbi"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
