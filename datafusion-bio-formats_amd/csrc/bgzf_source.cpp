@@ -141,6 +141,10 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
   for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
   fprintf(stderr, "[bioscan]   LZ77 matches %u (%.1f per round), %.1f %% with a source inside the round's window\n", h[14], h[2] ? (double)h[14] / h[2] : 0.0,
           h[14] ? 100.0 * h[15] / h[14] : 0.0);
+  if (h[20])  // -DV2_FIXSTAT builds only: how much of the wave each fix pass of the cascade re-decodes
+    for (int k = 0; k < 4; k++)
+      fprintf(stderr, "[bioscan]   fix pass %d%s: run in %.1f %% of rounds, %.2f lanes re-decoded per run\n", k + 1, k == 3 ? "+" : "",
+              h[2] ? 100.0 * h[20 + k] / h[2] : 0.0, h[20 + k] ? (double)h[16 + k] / h[20 + k] : 0.0);
 }
 
 void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {

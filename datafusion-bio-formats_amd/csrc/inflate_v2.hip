@@ -619,6 +619,9 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
   const int lane = threadIdx.x & 63;
   unsigned long long* mlist = scratch + ((size_t)blockIdx.x * V2_WAVES_PER_WG + (threadIdx.x >> 6)) * scratch_stride;
   uint32_t dbg_rounds = 0, dbg_passes = 0, dbg_matches = 0, dbg_near = 0;
+#ifdef V2_FIXSTAT
+  uint32_t fs_lanes[4] = {0, 0, 0, 0}, fs_iters[4] = {0, 0, 0, 0};  // lanes re-decoded by / runs of the 1st, 2nd, 3rd, later fix pass
+#endif
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = 0;
 #define TICK() (t0 = dbg ? clock64() : 0)
@@ -807,6 +810,9 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
           const bool alive = lane > 0 && lane <= first_stop;
           const bool changed = alive && pe != start;
           if (__ballot(changed) == 0ull) break;
+#ifdef V2_FIXSTAT
+          { const int k = it < 3 ? it : 3; fs_lanes[k] += (uint32_t)__popcll(__ballot(changed)); fs_iters[k]++; }
+#endif
           if (changed) start = pe;
           // a lane whose corrected start already lies beyond its limit owns no symbols
           if (changed && start >= limit) { end = start; nout = 0; nmatch = 0; flags = 0; }
@@ -914,6 +920,9 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
     for (int i = 0; i < 5; i++) atomicAdd((unsigned long long*)(dbg + 2) + i, tc[i]);
     atomicAdd(&dbg[12], dbg_matches);
     atomicAdd(&dbg[13], dbg_near);
+#ifdef V2_FIXSTAT
+    for (int k = 0; k < 4; k++) { atomicAdd(&dbg[14 + k], fs_lanes[k]); atomicAdd(&dbg[18 + k], fs_iters[k]); }
+#endif
   }
 }
 
