@@ -98,3 +98,53 @@ def test_two_rank_sharded_vcf_scan():
     assert c0 == c1 == 10000.0
     rows = s0 + s1
     assert len(set(rows)) == 10000 and rows == sorted(rows, key=lambda t: (t[0], t[1]))
+
+
+def _fastq_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from conftest import load_pkg
+    import fastq_oracle
+    pkg = load_pkg()
+    o = fastq_oracle.FastqOracle(os.path.join(ROOT, "tests", "golden", "sample.fastq.bgz"))
+    strat, parts = o.scan(6)                                  # GZI block ranges -> 6 partitions
+    mine = pkg.shard_partitions_in_order([1] * len(parts), world)[rank]
+    names = []
+    for p in mine:
+        _, bs = o.execute(strat, parts[p])
+        for x in bs:
+            names += x.column("name").to_pylist()
+    c = torch.tensor([float(len(names))], dtype=torch.float64)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    q.put((rank, strat, mine, names, float(c.item())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_fastq_scan():
+    """FASTQ: GZI partitions shard across ranks with no exchange; every read is owned by exactly one rank and the
+    rank-order concatenation is the file order (fastq/tests/parallel_read_test.rs: 2000 reads, no duplicates)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fastq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+    (r0, st0, m0, n0, c0), (r1, st1, m1, n1, c1) = out
+    assert st0 == st1 == "bgzf"
+    assert m0 + m1 == list(range(len(m0) + len(m1))) and m0 and m1
+    assert c0 == c1 == 2000.0
+    assert len(set(n0 + n1)) == 2000
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fastq_oracle
+    o = fastq_oracle.FastqOracle(os.path.join(ROOT, "tests", "golden", "sample.fastq.bgz"))
+    strat, parts = o.scan(1)
+    whole = [n for b in o.execute(strat, parts[0])[1] for n in b.column("name").to_pylist()]
+    assert n0 + n1 == whole
