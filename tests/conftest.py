@@ -31,6 +31,20 @@ def load_oracle():
     return bam_oracle
 
 
+def scratch_dir(need_bytes):
+    """A directory with room for a generated input of `need_bytes` (tmpfs first: the files are read back at once);
+    the test is skipped when neither /dev/shm nor /tmp can hold it."""
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK):
+                v = os.statvfs(cand)
+                if v.f_bavail * v.f_frsize > need_bytes * 1.3:
+                    return cand
+        except OSError:
+            pass
+    pytest.skip("no scratch space for %d MB" % (need_bytes >> 20))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

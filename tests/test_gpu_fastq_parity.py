@@ -232,7 +232,8 @@ def test_large_file_properties(pkg):
     exe = os.path.join(ROOT, "tools", "_build", "synth_fastq")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
-    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    from conftest import scratch_dir
+    base = scratch_dir(blocks * 27000)
     path = os.path.join(base, f"bioscan_large_{os.getpid()}.fastq.bgz")
     try:
         meta = json.loads(subprocess.check_output([exe, path, str(blocks), "13", str(min(16, os.cpu_count() or 1))]).decode())

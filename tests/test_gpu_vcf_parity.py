@@ -538,7 +538,8 @@ def test_large_file_properties(pkg, tmp_path):
     totals, and the tabix plans of 8 and 16 partitions return the same number of rows in total; the multi-sample form
     returns lines x samples list cells and the same UDF checksum on a second run."""
     n_lines = int(os.environ.get("BIOSCAN_TEST_LARGE_LINES", "4000000"))
-    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    from conftest import scratch_dir
+    base = scratch_dir(n_lines * 45)
     path = os.path.join(base, f"bioscan_large_{os.getpid()}.vcf.gz")
     spath = os.path.join(base, f"bioscan_large_{os.getpid()}_s.vcf.gz")
     try:
