@@ -363,12 +363,20 @@ __device__ __forceinline__ void v2_pass(V2Lds& L, bool active, uint32_t start, u
 #endif
     const bool in_lit = tb < DIST_BASE;
     const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
-    const uint32_t e = *(const uint16_t*)(T + tb + (__builtin_amdgcn_ubfe(w, 0u, mb) << 1));
+    // the load is written out: selected by the compiler, the 16-bit LDS read is followed by an `and 0xffff` the
+    // hardware has already done (ds_read_u16 zero-extends)
+    uint32_t e;
+    {
+      const uint32_t ea = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)T + tb + (__builtin_amdgcn_ubfe(w, 0u, mb) << 1);
+      asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(ea));
+    }
     __builtin_assume(e < 65536u);
     const uint32_t l = e & 15u;                            // code length (pointer: index width of the sub-table)
     const bool ptr = e >= E_SUB;                           // pointer to a second-level table (or a null slot)
-    const bool lenlike = e >= E_HI && !ptr;                // length / distance entry (the `and` is a scalar op)
     const bool is_lit = e < 0x1000u;                       // literal entries are 0x001 .. 0xFFF
+    // length / distance entry: no entry lies in 0x1000 .. 0x3FFF, so it is "neither of the two" -- computed on the lane
+    // masks (one scalar op); written as a lane predicate the compiler turns it back into a vector range test
+    const bool lenlike = __builtin_amdgcn_inverse_ballot_w64(~(__ballot(is_lit) | __ballot(ptr)));
     const bool is_len = lenlike && in_lit;
     const bool is_dist = lenlike && !is_len;
     const uint32_t base = L.be_lut[(e >> 8) & 63u];
