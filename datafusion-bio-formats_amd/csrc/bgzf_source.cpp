@@ -63,11 +63,12 @@ void BgzfSource::frame() {
     if (d[o] != 0x1f || d[o + 1] != 0x8b || d[o + 2] != 8 || !(d[o + 3] & 4))
       throw Error("BGZF: invalid block header at offset " + std::to_string(o));
     uint32_t xlen = d[o + 10] | (d[o + 11] << 8);
+    if (o + 12 + (uint64_t)xlen + 8 > file_len) throw Error("BGZF: truncated block header at offset " + std::to_string(o));
     uint64_t p = o + 12, pe = o + 12 + xlen;
     int64_t bsize = -1;
     while (p + 4 <= pe) {
       uint32_t slen = d[p + 2] | (d[p + 3] << 8);
-      if (d[p] == 66 && d[p + 1] == 67 && slen == 2) bsize = (int64_t)(d[p + 4] | (d[p + 5] << 8)) + 1;
+      if (d[p] == 66 && d[p + 1] == 67 && slen == 2 && p + 6 <= pe) bsize = (int64_t)(d[p + 4] | (d[p + 5] << 8)) + 1;
       p += 4 + slen;
     }
     if (bsize < 0 || o + (uint64_t)bsize > file_len || (uint64_t)bsize < 12 + xlen + 8)
@@ -100,9 +101,9 @@ void BgzfSource::make_resident() {
   {
     hipDeviceProp_t pr;
     HIP_CHECK(hipGetDeviceProperties(&pr, device));
-    const char* g = getenv("BIOSCAN_V2_WG_PER_CU");
-    v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)(g ? atoi(g) : v2_resident_wg_per_cu());
-    if (getenv("BIOSCAN_DEBUG")) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", g ? atoi(g) : v2_resident_wg_per_cu(), pr.multiProcessorCount);
+    const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : v2_resident_wg_per_cu();
+    v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
+    if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
     v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
     d_v2_ctr.alloc(32);
     d_v2_scratch.alloc(((size_t)v2_grid + 8) * V2_SCRATCH_STRIDE);
@@ -114,13 +115,9 @@ void BgzfSource::make_resident() {
 
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
-  if (getenv("BIOSCAN_INFLATE_V1")) {
-    launch_bgzf_inflate(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, stream);
-  } else {
-    HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
-    launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
-                           V2_SCRATCH_STRIDE, v2_grid, getenv("BIOSCAN_DEBUG") ? d_v2_ctr.p + 2 : nullptr, stream);
-  }
+  HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
+  launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
+                         V2_SCRATCH_STRIDE, v2_grid, env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
 }
 
 void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
@@ -128,7 +125,7 @@ void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
 }
 
 void BgzfSource::report_v2_debug(uint32_t nb) {
-  if (!getenv("BIOSCAN_DEBUG") || getenv("BIOSCAN_INFLATE_V1")) return;
+  if (!env_knobs().debug) return;
   uint32_t h[32];
   HIP_CHECK(hipMemcpy(h, d_v2_ctr.p, 128, hipMemcpyDeviceToHost));
   unsigned long long tc[5];
@@ -148,7 +145,6 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
 }
 
 void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {
-  if (getenv("BIOSCAN_V2_ABLATE")) return;  // timing-only ablation builds produce wrong bytes on purpose
   // the first failing member is found on the device: 8 bytes come back instead of the whole status array
   DevBuf<uint32_t> res(1);
   launch_first_bad_status(d_status.p + b0, nb, res.p, stream);

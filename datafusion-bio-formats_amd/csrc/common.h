@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <exception>
 #include <stdexcept>
 #include <string>
 
@@ -53,12 +54,28 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(x) ::bioscan::hip_check((x), #x, __FILE__, __LINE__)
 
+// Environment knobs, read ONCE per process (first use).  None of them changes what a scan computes:
+//   BIOSCAN_DEBUG=1            diagnostics on stderr (K1 pass counters, record-chain rounds)
+//   BIOSCAN_LAPS=1             host wall-clock laps of execute() on stderr
+//   BIOSCAN_K1_WAVES_PER_CU=n  persistent-grid size of K1 (default: the occupancy API's answer)
+//   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 64)
+//   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 65536)
+struct EnvKnobs {
+  bool debug = false, laps = false;
+  int k1_waves_per_cu = 0;
+  double host_pool_gb = 64.0;
+  double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
+  uint32_t chunk_members = 65536;
+};
+const EnvKnobs& env_knobs();
+
 // Size-keyed cache of large device allocations: a scan allocates the same column / scratch sizes for
 // every partition and every step, and hipMalloc / hipFree of tens of GB per scan is driver work that
 // does not belong on the hot path.  Blocks >= 1 MiB are returned here instead of to the driver and
 // handed out again on an exact size match; dev_pool_trim() releases everything (provider close).
 void* dev_pool_alloc(size_t bytes);
-void dev_pool_free(void* p, size_t bytes);
+void dev_pool_free(void* p, size_t bytes, int device);
+int dev_pool_device();  // current HIP device (recorded at allocation)
 void dev_pool_trim();
 
 // device buffer with value semantics off (move only)
@@ -66,13 +83,14 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  int dev = 0;  // device the block lives on
   DevBuf() = default;
   explicit DevBuf(size_t count) { alloc(count); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), dev(o.dev) { o.p = nullptr; o.n = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { reset(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { reset(); p = o.p; n = o.n; dev = o.dev; o.p = nullptr; o.n = 0; }
     return *this;
   }
   ~DevBuf() { reset(); }
@@ -80,10 +98,11 @@ struct DevBuf {
     reset();
     n = count;
     size_t bytes = (count ? count : 1) * sizeof(T);
+    dev = dev_pool_device();
     p = (T*)dev_pool_alloc(bytes);
   }
   void reset() {
-    if (p) { dev_pool_free(p, (n ? n : 1) * sizeof(T)); p = nullptr; n = 0; }
+    if (p) { dev_pool_free(p, (n ? n : 1) * sizeof(T), std::uncaught_exceptions() > 0 ? -1 : dev); p = nullptr; n = 0; }
   }
   size_t bytes() const { return n * sizeof(T); }
 };

@@ -30,9 +30,23 @@ static thread_local std::string g_err;
 
 // ---- device allocation cache (see common.h) -------------------------------------------------------
 namespace bioscan {
+const EnvKnobs& env_knobs() {
+  static const EnvKnobs k = [] {
+    EnvKnobs v;
+    if (const char* e = getenv("BIOSCAN_DEBUG")) v.debug = e[0] && e[0] != '0';
+    if (const char* e = getenv("BIOSCAN_LAPS")) v.laps = e[0] && e[0] != '0';
+    if (const char* e = getenv("BIOSCAN_K1_WAVES_PER_CU")) v.k1_waves_per_cu = atoi(e);
+    if (const char* e = getenv("BIOSCAN_HOST_POOL_GB")) v.host_pool_gb = atof(e);
+    if (const char* e = getenv("BIOSCAN_DEV_POOL_GB")) v.dev_pool_gb = atof(e);
+    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS")) v.chunk_members = (uint32_t)std::max(64, atoi(e));
+    return v;
+  }();
+  return k;
+}
 static std::mutex g_pool_mu;
 static std::multimap<std::pair<int, size_t>, void*> g_pool;  // (device, bytes) -> cached block
 static size_t g_pool_bytes = 0;
+static size_t dev_pool_limit() { return (size_t)(env_knobs().dev_pool_gb * (double)(1ull << 30)); }
 constexpr size_t POOL_MIN = 1;  // every block is cached: hipFree of even a tiny block synchronises the device
 static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 void* dev_pool_alloc(size_t bytes) {
@@ -55,15 +69,22 @@ void* dev_pool_alloc(size_t bytes) {
   HIP_CHECK(e);
   return p;
 }
-void dev_pool_free(void* p, size_t bytes) {
-  if (bytes >= POOL_MIN) {
+void dev_pool_free(void* p, size_t bytes, int device) {
+  // `device` is the one the block was allocated on (recorded by DevBuf): a block is freed from Arrow release
+  // callbacks and destructors on threads whose current device may be anything.
+  // device < 0: released while an exception unwinds -- kernels that read the block may still be in flight, so it goes
+  // back to the driver (hipFree waits for the device) instead of into the cache where another stream could pick it up
+  if (bytes >= POOL_MIN && device >= 0) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.emplace(std::make_pair(cur_device(), bytes), p);
-    g_pool_bytes += bytes;
-    return;
+    if (g_pool_bytes + bytes <= dev_pool_limit()) {
+      g_pool.emplace(std::make_pair(device, bytes), p);
+      g_pool_bytes += bytes;
+      return;
+    }
   }
-  (void)hipFree(p);
+  (void)hipFree(p);  // over the cap (or unwinding): back to the driver
 }
+int dev_pool_device() { return cur_device(); }
 void dev_pool_trim() {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (auto& kv : g_pool) (void)hipFree(kv.second);  // hipFree takes a pointer of any device
@@ -80,13 +101,7 @@ static size_t host_class(size_t bytes) {
   const size_t step = top >> 2;                                                  // four classes per octave
   return (bytes + step - 1) / step * step;
 }
-static size_t host_pool_limit() {
-  static const size_t lim = [] {
-    const char* e = getenv("BIOSCAN_HOST_POOL_GB");
-    return (size_t)(e ? atof(e) : 64.0) << 30;
-  }();
-  return lim;
-}
+static size_t host_pool_limit() { return (size_t)(env_knobs().host_pool_gb * (double)(1ull << 30)); }
 void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned) {
   const size_t c = host_class(bytes);
   {
@@ -220,8 +235,8 @@ struct Provider : BgzfSource {
   // Full decode: inflate every block, find every record, build the key table.  Cached.
   // Decode members [r.b_lo, r.b_hi): inflate, CRC-check, find every record that starts in
   // [r.first_rel, r.stop_rel) of the range's inflated bytes, build the key table.  One range is cached.
+  // caller holds `mu` and keeps holding it until the last kernel that reads d_u / the record table has finished
   void decode(bool force, const DecodeRange& r, bool need_keys) {
-    std::lock_guard<std::mutex> lk(mu);
     if (decoded && !force && r == dec_range && (have_keys || !need_keys)) return;
     decode_locked(r, need_keys);
   }
@@ -243,10 +258,6 @@ struct Provider : BgzfSource {
     launch_inflate(d_u.p, nb_r, r.b_lo);
     s.ms_inflate = t.stop();
     report_v2_debug(nb_r);
-    if (getenv("BIOSCAN_V2_ABLATE")) {
-      fprintf(stderr, "[bioscan] ablate=%s inflate_ms=%.3f\n", getenv("BIOSCAN_V2_ABLATE"), s.ms_inflate);
-      throw Error("ablation run: timing only");
-    }
     // CRC32 validation (noodles-bgzf checks every block).  Measured: running it on a second, low-priority
     // stream beside the chain / extract kernels does not shorten the step on MI355X (the extract kernels are
     // bandwidth-bound and the CRC kernel just time-slices with them), so it stays in line.
@@ -274,7 +285,7 @@ struct Provider : BgzfSource {
       uint32_t nfix = 0;
       HIP_CHECK(hipMemcpyAsync(&nfix, ctr.p, 4, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
-      if (getenv("BIOSCAN_DEBUG")) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
+      if (env_knobs().debug) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
       if (nfix == 0) break;
       if ((uint64_t)iter > nseg + 2) throw Error("record boundary scan did not converge");
       launch_seg_walk(d_u.p, stop, nseg, cb, 1, stream);
@@ -295,6 +306,7 @@ struct Provider : BgzfSource {
       HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipMemcpyAsync(lx, lastx.p, 16, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
+      if (errf == 2) throw Error("BAM read error: invalid record (variable-length fields exceed block_size)");
       if (errf) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
       const uint64_t last = lx[1];
       if (last == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
@@ -696,16 +708,18 @@ static void copy_result_to_host(Result& res, hipStream_t st) {
 static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
   Provider& p = *plan.prov;
   const auto wall0 = std::chrono::steady_clock::now();
-  const bool laps = getenv("BIOSCAN_LAPS") != nullptr;
+  const bool laps = env_knobs().laps;
   auto lap = [&](const char* what) {
     if (laps) fprintf(stderr, "[bioscan] bam partition %d: %-18s at %8.3f ms\n", partition, what,
                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
   };
   const DecodeRange range = partition_range(plan, partition);
   lap("range planned");
+  // One critical section from the decode to the last extract kernel: the provider caches ONE decoded range, and another
+  // thread executing a different partition of the same plan would otherwise replace it between the two steps.
+  std::lock_guard<std::mutex> lk(p.mu);
   p.decode(force_decode, range, plan.indexed);
   lap("decoded");
-  std::lock_guard<std::mutex> lk(p.mu);
   p.set_device();
   hipStream_t st = p.stream;
   auto res = std::make_shared<Result>();
@@ -793,20 +807,13 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
     for (int k : var_idx) if (core_col[k] >= 0) finish_var(res->cols[core_col[k]], 1);
     auto off_of = [&](int idx) -> const uint64_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_off64.p : nullptr; };
     auto dat_of = [&](int idx) -> uint8_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_values.p : nullptr; };
-    const bool v1 = getenv("BIOSCAN_SEQQUAL_V1") != nullptr;
     // name rides with sequence / quality in the row-centric kernel; chrom, cigar, mate_chrom stay one row per lane
-    if ((v1 && core_col[0] >= 0) || core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
-      launch_scatter_small(p.d_u.p, rows, 0, n, v1 ? off_of(0) : nullptr, v1 ? dat_of(0) : nullptr, off_of(1), dat_of(1), off_of(5),
-                           dat_of(5), off_of(7), dat_of(7), p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(),
-                           p.binary_cigar ? 1 : 0, ov, st);
+    if (core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
+      launch_scatter_small(p.d_u.p, rows, 0, n, nullptr, nullptr, off_of(1), dat_of(1), off_of(5), dat_of(5), off_of(7), dat_of(7),
+                           p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(), p.binary_cigar ? 1 : 0, ov, st);
     DevBuf<uint32_t> wide(1);
     HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    if (v1) {
-      if (core_col[9] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(9), dat_of(9), 0, wide.p, st);
-      if (core_col[10] >= 0) launch_scatter_seqqual(p.d_u.p, rows, n, off_of(10), dat_of(10), 1, wide.p, st);
-    } else {
-      launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
-    }
+    launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
     if (core_col[10] >= 0) {
       if (read_err(wide, st)) {
         // exact path for qualities >= 95 (two-byte UTF-8 chars)

@@ -277,28 +277,6 @@ void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, ui
 }
 
 // ---- generic range scatter: row i copies len_i bytes from u[src_i..] to dst[off64_i..] -----------------
-// Output-centric like k_scatter_seqqual: 256 rows per workgroup, threads sweep the OUTPUT bytes.
-constexpr int RS_ROWS = 256;
-__global__ __launch_bounds__(256) void k_scatter_ranges(const uint8_t* __restrict__ u, const uint64_t* __restrict__ src,
-                                                         uint64_t n, const uint64_t* __restrict__ off64,
-                                                         uint8_t* __restrict__ dst) {
-  __shared__ uint64_t s_off[RS_ROWS + 1];
-  __shared__ uint64_t s_src[RS_ROWS];
-  const uint64_t r0 = (uint64_t)blockIdx.x * RS_ROWS;
-  const uint32_t nr = (uint32_t)((n - r0) < RS_ROWS ? (n - r0) : RS_ROWS);
-  for (uint32_t k = threadIdx.x; k <= nr; k += 256) s_off[k] = off64[r0 + k];
-  for (uint32_t k = threadIdx.x; k < nr; k += 256) s_src[k] = src[r0 + k];
-  __syncthreads();
-  const uint64_t b0 = s_off[0], b1 = s_off[nr];
-  for (uint64_t j = b0 + threadIdx.x; j < b1; j += 256) {
-    uint32_t lo = 0, hi = nr;
-    while (lo + 1 < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_off[mid] <= j) lo = mid; else hi = mid;
-    }
-    dst[j] = u[s_src[lo] + (j - s_off[lo])];
-  }
-}
 // Row-centric variant: G lanes per row (G = 4 for short fields, 16 for reads), 64 / G rows in flight per
 // wave; each lane moves 16-byte chunks, a partial last chunk is served by the overlapping 16 bytes that end at
 // the row's end, rows shorter than 16 bytes are copied by their first lane.  No binary search, no LDS.
@@ -356,15 +334,13 @@ __global__ __launch_bounds__(256) void k_scatter_ranges_tiny(const uint8_t* __re
 void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
                            hipStream_t st) {
   if (!n) return;
-  if (!getenv("BIOSCAN_SCATTER_V1") && total_bytes < 16 * n) {
+  if (total_bytes < 16 * n) {
     hipLaunchKernelGGL(k_scatter_ranges_tiny, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
     return;
   }
-  // the average row length picks the shape: tiny fields (CHROM, REF, ALT ...) keep the output-centric kernel,
-  // medium rows get 4 lanes each, reads 16 lanes each
-  if (getenv("BIOSCAN_SCATTER_V1") || total_bytes < 16 * n)
-    hipLaunchKernelGGL(k_scatter_ranges, dim3((uint32_t)((n + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0, st, u, src, n, off64, dst);
-  else if (total_bytes < 48 * n)
+  // the average row length picks the shape: tiny fields (CHROM, REF, ALT ...) one row per lane (above), medium rows
+  // 4 lanes each, reads 8 or 16 lanes each
+  if (total_bytes < 48 * n)
     hipLaunchKernelGGL(k_scatter_ranges_rows<4>, dim3((uint32_t)((n * 4 + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);
   else if (total_bytes < 144 * n)   // e.g. 101-base reads: 7 of 8 lanes busy instead of 7 of 16
     hipLaunchKernelGGL(k_scatter_ranges_rows<8>, dim3((uint32_t)((n * 8 + 255) / 256)), dim3(256), 0, st, u, src, n, off64, dst);

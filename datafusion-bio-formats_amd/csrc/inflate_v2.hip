@@ -805,7 +805,9 @@ __global__ __launch_bounds__(WAVE * V2_WAVES_PER_WG, V2_WAVES_PER_EU) void k_bgz
         const uint32_t limit = rel0 + (uint32_t)(lane + 1) * subb;
         uint32_t start = bnd, end = bnd, nout = 0, nmatch = 0, flags = 0;
         {
-          const uint32_t ov = lane == 0 ? 0u : (uint32_t)V2_OV_BITS;
+          // lanes too close to the round's start for a full pre-roll begin at the round's exact first bit instead
+          const uint32_t room = (uint32_t)lane * subb;
+          const uint32_t ov = room < (uint32_t)V2_OV_BITS ? room : (uint32_t)V2_OV_BITS;
           uint32_t first = bnd;
           v2_pass<0, true>(L, true, bnd - ov, limit, end, nout, nmatch, flags, nullptr, 0, nullptr, 0, 0, bnd, first, base32 + wb);
           start = first;  // counts are valid from here
@@ -954,10 +956,14 @@ void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st) {
   if (!n_blocks) return;
-  const char* ab = getenv("BIOSCAN_V2_ABLATE");  // timing-only phase ablation (tools/ab_ablate.sh): 1 = no resolve, 2 = no write pass
-  const uint32_t ablate = (ab && n_blocks > 64) ? ((uint32_t)atoi(ab) & 0xFFu) : 0u;
-  const char* db = getenv("BIOSCAN_DBG_BLOCK");
-  const uint32_t dbg_block = db ? (uint32_t)atoi(db) : 0xFFFFFFFFu;
+  // timing-only phase ablation is a compile-time build (make EXTRA=-DV2_ABLATE=n, tools/ab_ablate.sh): 1 = no resolve,
+  // 2 = no write pass.  Such a library produces wrong bytes on purpose and must never ship.
+#ifdef V2_ABLATE
+  const uint32_t ablate = n_blocks > 64 ? (uint32_t)(V2_ABLATE) & 0xFFu : 0u;
+#else
+  const uint32_t ablate = 0u;
+#endif
+  const uint32_t dbg_block = 0xFFFFFFFFu;
   (void)g_v2_grid;
   hipMemsetAsync(counter, 0, 4, st);
   uint32_t g = grid < n_blocks ? grid : n_blocks;

@@ -19,8 +19,6 @@ enum InflateStatus : uint32_t {
 // ---- K1: BGZF inflate -------------------------------------------------------------------------
 // comp: compressed file bytes (padded by >= 1 KiB readable slack), blk_coff[i] = byte offset of
 // BGZF member i, blk_uoff[i] = offset of its payload in `out`; blk_uoff[n] = total.
-void launch_bgzf_inflate(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
-                         uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
 // K1 v2 (inflate_v2.hip): wave-parallel Huffman decode, persistent grid.  counter: 1 u32; scratch:
 // grid * scratch_stride u64 match-list entries; dbg: 2 u32 counters (rounds, passes) or nullptr.
 constexpr uint32_t V2_SCRATCH_STRIDE = 19456;
@@ -114,10 +112,8 @@ void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0,
                           const uint64_t* off_mate, uint8_t* d_mate,
                           const uint8_t* ref_names, const uint32_t* ref_name_off, int32_t n_ref, int32_t binary_cigar,
                           RowOverride ov, hipStream_t st);
-// which: 0 = sequence (4-bit -> ASCII), 1 = quality (+33).  qual_wide: set to 1 when a quality byte
-// maps to a 2-byte UTF-8 char (q+33 >= 128): caller re-runs the exact wide path.
-void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst,
-                            int which, uint32_t* qual_wide, hipStream_t st);
+// name + sequence (4-bit -> ASCII) + quality (+33) of a row in one pass.  qual_wide: set to 1 when a quality byte maps to a
+// 2-byte UTF-8 char (q+33 >= 128): the caller re-runs the exact wide path.
 void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
                                  const uint64_t* off_qual, uint8_t* d_qual, const uint64_t* off_name, uint8_t* d_name,
                                  uint32_t* qual_wide, hipStream_t st);

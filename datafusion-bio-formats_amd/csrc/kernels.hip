@@ -257,10 +257,19 @@ __global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
     return;
   }
   uint64_t o = base[s];
+  bool bad = false;
   while (p < E) {
     rec_off[o++] = p;
-    p += 4 + (uint64_t)ld_u32(u + p);
+    // Every later kernel trusts l_read_name / n_cigar_op / l_seq: check once, here, that the variable-length fields fit
+    // inside block_size (noodles fails such a record with an I/O error; a CRC-valid member can still carry one).
+    const uint8_t* r = u + p;
+    const uint32_t bs = ld_u32(r);
+    const uint32_t lrn = r[12], ncig = ld_u16(r + 16);
+    const int32_t lseq = ld_i32(r + 20);
+    if (lrn == 0 || lseq < 0 || 32ull + lrn + 4ull * ncig + (((uint64_t)(uint32_t)lseq + 1) >> 1) + (uint64_t)(uint32_t)lseq > (uint64_t)bs) bad = true;
+    p += 4 + (uint64_t)bs;
   }
+  if (bad) atomicExch(cb.err, 2u);
 }
 
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref, ChainBuffers cb, hipStream_t st) {
@@ -636,111 +645,10 @@ void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0,
 }
 
 // =================================================================================================
-// K7b: sequence / quality, output-centric: a workgroup owns 256 consecutive rows, stages their
-// output offsets in LDS, and its threads sweep the rows' OUTPUT bytes so stores are coalesced
-// (consecutive lanes -> consecutive bytes of the Arrow values buffer).
-// =================================================================================================
-constexpr int SQ_ROWS = 256;
 struct __attribute__((packed, aligned(1))) u32x4u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) u64u { uint64_t v; };
 
-__device__ __forceinline__ uint8_t seqqual_byte(const uint8_t* sp, uint32_t k, int which, bool* wide) {
-  if (which == 0) {
-    const uint8_t b = sp[k >> 1];
-    const uint32_t nib = (k & 1u) ? (b & 15u) : (b >> 4);
-    return (uint8_t)"=ACMGRSVTWYHKDBN"[nib];
-  }
-  const uint32_t q = ((uint32_t)sp[k] + 33u) & 0xFFu;
-  *wide = *wide || q >= 128u;
-  return (uint8_t)q;
-}
-
-__global__ __launch_bounds__(256) void k_scatter_seqqual(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
-                                                          uint64_t n, const uint64_t* __restrict__ off64,
-                                                          uint8_t* __restrict__ dst, int which, uint32_t* qual_wide) {
-  __shared__ uint64_t s_off[SQ_ROWS + 1];
-  __shared__ uint64_t s_src[SQ_ROWS];
-  __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first)
-  const uint64_t r0 = (uint64_t)blockIdx.x * SQ_ROWS;
-  const uint32_t nr = (uint32_t)((n - r0) < SQ_ROWS ? (n - r0) : SQ_ROWS);
-  for (uint32_t k = threadIdx.x; k <= nr; k += 256) s_off[k] = off64[r0 + k];
-  for (uint32_t k = threadIdx.x; k < nr; k += 256) {
-    const uint8_t* r = u + rows[r0 + k];
-    const uint32_t lrn = r[12];
-    const uint32_t ncig = ld_u16(r + 16);
-    const int32_t lseq = ld_i32(r + 20);
-    uint64_t src = rows[r0 + k] + 36 + lrn + 4ull * ncig;
-    if (which == 1) src += (uint64_t)((lseq + 1) / 2);
-    s_src[k] = src;
-  }
-  {
-    const char* lut = "=ACMGRSVTWYHKDBN";
-    s_pair[threadIdx.x] = (uint16_t)((uint8_t)lut[threadIdx.x >> 4] | ((uint16_t)(uint8_t)lut[threadIdx.x & 15] << 8));
-  }
-  __syncthreads();
-  const uint64_t b0 = s_off[0], b1 = s_off[nr];
-  bool wide = false;
-  // 16-byte aligned chunks of the OUTPUT; chunk c covers bytes [16c, 16c+16)
-  for (uint64_t j0 = (b0 & ~15ull) + (uint64_t)threadIdx.x * 16; j0 < b1; j0 += 256 * 16) {
-    const uint64_t ja = j0 < b0 ? b0 : j0;
-    const uint64_t jb = j0 + 16 < b1 ? j0 + 16 : b1;
-    // row of the first byte: last row with off <= ja (empty rows share offsets and are skipped)
-    uint32_t lo = 0, hi = nr;
-    while (lo + 1 < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_off[mid] <= ja) lo = mid; else hi = mid;
-    }
-    if (ja == j0 && jb == j0 + 16 && j0 + 16 <= s_off[lo + 1]) {
-      // fast path: the whole chunk lies inside row `lo`
-      const uint32_t k0 = (uint32_t)(j0 - s_off[lo]);
-      const uint8_t* sp = u + s_src[lo];
-      uint32_t o[4];
-      if (which == 1) {
-        const u32x4u v = *(const u32x4u*)(sp + k0);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          // any byte >= 95 maps to a 2-byte UTF-8 char: flag it (the exact wide path redoes the column)
-          if ((((w[q] & 0x7F7F7F7Fu) + 0x21212121u) | w[q]) & 0x80808080u) wide = true;
-          o[q] = w[q] + 0x21212121u;
-        }
-      } else {
-        // 16 bases = nibbles k0 .. k0+15 of the packed sequence
-        const uint8_t* bp = sp + (k0 >> 1);
-        uint64_t v = ((const u64u*)bp)->v;
-        if (k0 & 1u) {
-          const uint64_t nxt = (v >> 8) | ((uint64_t)bp[8] << 56);
-          v = ((v << 4) & 0xF0F0F0F0F0F0F0F0ull) | ((nxt >> 4) & 0x0F0F0F0F0F0F0F0Full);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const uint32_t p0 = s_pair[(uint32_t)(v >> (16 * q)) & 0xFFu];
-          const uint32_t p1 = s_pair[(uint32_t)(v >> (16 * q + 8)) & 0xFFu];
-          o[q] = p0 | (p1 << 16);
-        }
-      }
-      uint4 ov;
-      ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
-      *(uint4*)(dst + j0) = ov;  // values buffer is 256-byte aligned: aligned 16-byte store
-    } else {
-      // chunk crosses a row boundary or the workgroup's range edge: per-byte path
-      uint32_t row = lo;
-      for (uint64_t j = ja; j < jb; j++) {
-        while (row + 1 < nr && s_off[row + 1] <= j) row++;
-        dst[j] = seqqual_byte(u + s_src[row], (uint32_t)(j - s_off[row]), which, &wide);
-      }
-    }
-  }
-  if (which == 1 && wide) atomicExch(qual_wide, 1u);
-}
-void launch_scatter_seqqual(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, int which,
-                            uint32_t* qual_wide, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_scatter_seqqual, dim3((uint32_t)((n + SQ_ROWS - 1) / SQ_ROWS)), dim3(256), 0, st, u, rows, n, off64, dst,
-                     which, qual_wide);
-}
-
-// K7c: sequence + quality in ONE pass, one wave per row (8 rows per wave, grid-stride free): the packed
+// K7b: name + sequence + quality in ONE pass, one wave per row (8 rows per wave, grid-stride free): the packed
 // bases and the qualities of a record are adjacent (225 contiguous bytes for a 150 bp read), so the wave
 // reads them once with 2- and 4-byte lane accesses and writes both Arrow value buffers with 4-byte stores
 // to consecutive addresses.  Replaces two output-centric k_scatter_seqqual launches (which re-read most of

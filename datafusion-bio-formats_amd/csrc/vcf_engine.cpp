@@ -554,7 +554,7 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
   if (batch_size_in <= 0) throw Error("batch_size must be positive");
   std::lock_guard<std::mutex> lk(p.mu);
   const auto wall0 = std::chrono::steady_clock::now();
-  const bool dbg_wall = getenv("BIOSCAN_LAPS") != nullptr;
+  const bool dbg_wall = env_knobs().laps;
   auto lap = [&](const char* what) {
     if (dbg_wall) fprintf(stderr, "[bioscan] vcf execute: %-22s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
   };

@@ -3,6 +3,7 @@ bam/src/physical_exec.rs:412-540): empty sequence, odd / long sequences, no CIGA
 missing mates, read names of length 1 and 254, quality bytes >= 95 (two UTF-8 bytes each), records that span BGZF
 members, negative template lengths, records with many aux fields, tiny and single-record files."""
 import random
+import struct
 
 import pytest
 
@@ -76,3 +77,43 @@ def test_tiny_files(pkg, oracle, tmp_path):
         _, want = orc.execute_sequential(None, 8192)
         _cmp_batches(got, want, ("tiny", n))
         assert sum(b.num_rows for b in got) == n
+
+
+def _patched(rec: bytes, **fields) -> bytes:
+    """record() bytes with raw header fields overwritten (block_size stays what it was)."""
+    b = bytearray(rec)
+    if "l_read_name" in fields:
+        b[12] = fields["l_read_name"]
+    if "n_cigar" in fields:
+        struct.pack_into("<H", b, 16, fields["n_cigar"])
+    if "l_seq" in fields:
+        struct.pack_into("<i", b, 20, fields["l_seq"])
+    return bytes(b)
+
+
+@pytest.mark.parametrize("patch", [{"n_cigar": 65535}, {"l_seq": -5}, {"l_seq": 2 ** 31 - 1}, {"l_read_name": 0}, {"l_seq": 100000}])
+def test_malformed_record_is_an_error(pkg, tmp_path, patch):
+    """A CRC-valid member can carry a record whose variable-length fields do not fit in block_size: noodles fails
+    such a record; the GPU path must report it instead of reading past the inflated buffer."""
+    rng = random.Random(1)
+    recs = _records(rng, 24)
+    recs[13] = _patched(bb.record(name="bad", seq="ACGT" * 10, cigar=((40, "M"),)), **patch)
+    path = str(tmp_path / "malformed.bam")
+    open(path, "wb").write(bb.bam(REFS, recs))
+    prov = pkg.BamTableProvider(path, None, True, None, index_path="")
+    for proj in (None, [], [0], [3, 5]):
+        with pytest.raises(pkg.BioscanError, match="invalid record"):
+            list(prov.scan(projection=proj).execute(0, 8192))
+
+
+def test_truncated_bgzf_header_is_an_error(pkg, tmp_path):
+    """A file that ends inside a member's gzip extra field (page-multiple size, so nothing readable follows the mapping)."""
+    rng = random.Random(2)
+    good = bb.bam(REFS, _records(rng, 24))
+    hdr = b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 60000) + b"BC\x02\0"
+    data = good + hdr
+    data += b"\0" * ((-len(data)) % 4096)
+    path = str(tmp_path / "trunc.bam")
+    open(path, "wb").write(data)
+    with pytest.raises(pkg.BioscanError, match="truncated block header|invalid block"):
+        pkg.BamTableProvider(path, None, True, None, index_path="")
