@@ -101,12 +101,19 @@ void BgzfSource::make_resident() {
   {
     hipDeviceProp_t pr;
     HIP_CHECK(hipGetDeviceProperties(&pr, device));
-    const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : v2_resident_wg_per_cu();
+#ifdef BIOSCAN_K1_V2
+    const int occ = v2_resident_wg_per_cu();
+    const size_t stride = V2_SCRATCH_STRIDE;
+#else
+    const int occ = v3_resident_wg_per_cu();
+    const size_t stride = V3_SCRATCH_STRIDE;
+#endif
+    const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
     v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
     if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
     v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
     d_v2_ctr.alloc(32);
-    d_v2_scratch.alloc(((size_t)v2_grid + 8) * V2_SCRATCH_STRIDE);
+    d_v2_scratch.alloc(((size_t)v2_grid + 8) * stride);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   file.reset();  // the compressed bytes now live in HBM; the host image is not read again
@@ -116,8 +123,13 @@ void BgzfSource::make_resident() {
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
+#ifdef BIOSCAN_K1_V2   // A/B build of the r01 kernel (make EXTRA=-DBIOSCAN_K1_V2); the shipped library runs v3
   launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
                          V2_SCRATCH_STRIDE, v2_grid, env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
+#else
+  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p, v2_grid,
+                         env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
+#endif
 }
 
 void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
@@ -136,6 +148,8 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
   for (int i = 0; i < 5; i++) tot += (double)tc[i];
   const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
   for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+  fprintf(stderr, "[bioscan]   write mini-rounds %u (%.2f per round), lanes idle behind END-OF-BLOCK %.1f per round, %u mini-rounds through HBM\n", h[24], h[2] ? (double)h[24] / h[2] : 0.0,
+          h[2] ? (double)h[25] / h[2] : 0.0, h[26]);
   fprintf(stderr, "[bioscan]   LZ77 matches %u (%.1f per round), %.1f %% with a source inside the round's window\n", h[14], h[2] ? (double)h[14] / h[2] : 0.0,
           h[14] ? 100.0 * h[15] / h[14] : 0.0);
   if (h[20])  // -DV2_FIXSTAT builds only: how much of the wave each fix pass of the cascade re-decodes

@@ -26,6 +26,15 @@ int v2_resident_wg_per_cu();  // occupancy of k_bgzf_inflate_v2 (workgroups per 
 void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st);
+// K1 (inflate_v3.hip): long sub-streams, checkpointed count passes, segment mini-rounds.  Per-wave scratch stride in
+// u64: the match list of one mini-round (V3_ML_ENTRIES) followed by the checkpoint rows of one round.
+constexpr uint32_t V3_ML_ENTRIES = 1536;
+constexpr uint32_t V3_CK_DWORDS = 24 * 3 * 64;  // V3_CK_MAX rows x (pos, acc, state) x 64 lanes
+constexpr uint32_t V3_SCRATCH_STRIDE = V3_ML_ENTRIES + V3_CK_DWORDS / 2;
+int v3_resident_wg_per_cu();
+void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
+                            uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
+                            uint32_t grid, uint32_t* dbg, hipStream_t st);
 // K2: CRC32 of each inflated block vs the BGZF trailer (validation mode).
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
                        const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
