@@ -110,6 +110,8 @@ void BgzfSource::make_resident() {
 #endif
     const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
     v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
+    v2_grid_max = v2_grid;
+    k1_scratch_stride = stride;
     if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
     v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
     d_v2_ctr.alloc(32);
@@ -130,6 +132,59 @@ void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p, v2_grid,
                          env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
 #endif
+}
+
+K1Ctx::~K1Ctx() {
+  if (stream) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(device);
+    (void)hipStreamSynchronize(stream);  // nothing of this context may still be running when its scratch goes back to the pool
+    (void)hipStreamDestroy(stream);
+    (void)hipSetDevice(prev);
+  }
+}
+
+void BgzfSource::init_ctx(K1Ctx& c, uint32_t max_members) {
+  make_resident();
+  set_device();
+  c.device = device;
+  if (!c.stream) HIP_CHECK(hipStreamCreate(&c.stream));
+  c.grid = std::min<uint32_t>(v2_grid_max, std::max<uint32_t>(max_members, 1));
+  if (!c.ctr.p) c.ctr.alloc(32);
+  const size_t need = ((size_t)c.grid + 8) * k1_scratch_stride;
+  if (c.scratch.n < need) c.scratch.alloc(need);
+  if (c.status.n < max_members) c.status.alloc(std::max<uint32_t>(max_members, 1));
+}
+
+void BgzfSource::launch_inflate(K1Ctx& c, uint8_t* dst, uint32_t nb, uint32_t b0) {
+  uint8_t* base = dst - blk_uoff[b0];
+  HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
+#ifdef BIOSCAN_K1_V2
+  launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, V2_SCRATCH_STRIDE, c.grid,
+                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
+#else
+  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, c.grid,
+                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
+#endif
+}
+
+void BgzfSource::launch_crc(K1Ctx& c, const uint8_t* dst, uint32_t nb, uint32_t b0) {
+  launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, c.status.p, c.stream);
+}
+
+void BgzfSource::check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb) {
+  DevBuf<uint32_t> res(1);
+  launch_first_bad_status(c.status.p, nb, res.p, c.stream);
+  uint32_t i = 0xFFFFFFFFu;
+  HIP_CHECK(hipMemcpyAsync(&i, res.p, 4, hipMemcpyDeviceToHost, c.stream));
+  HIP_CHECK(hipStreamSynchronize(c.stream));
+  if (i != 0xFFFFFFFFu) {
+    uint32_t st = 0;
+    HIP_CHECK(hipMemcpy(&st, c.status.p + i, 4, hipMemcpyDeviceToHost));
+    throw Error(std::string(what) + " read error: BGZF block " + std::to_string(b0 + i) + " at offset " +
+                std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st & 0xFF) + " (code " + std::to_string(st) + ")");
+  }
 }
 
 void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {

@@ -14,6 +14,23 @@ namespace bioscan {
 
 const char* inflate_status_str(uint32_t s);
 
+// What one execution needs besides the resident file to run K1 / K2 on its own: a stream, the member counter, the
+// per-wave scratch and a status slot per member of a launch.  Streams of one provider each own one, so partitions
+// execute concurrently without sharing any mutable device state (bio-format-bam/src/physical_exec.rs:878-881: every
+// execute opens its own reader).
+struct K1Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf<uint32_t> ctr;
+  DevBuf<unsigned long long> scratch;
+  DevBuf<uint32_t> status;  // status[i] = member b0 + i of the last launch
+  uint32_t grid = 0;
+  K1Ctx() = default;
+  K1Ctx(const K1Ctx&) = delete;
+  K1Ctx& operator=(const K1Ctx&) = delete;
+  ~K1Ctx();
+};
+
 struct BgzfSource {
   std::string path;
   const char* what = "BAM";  // format name used in error messages
@@ -32,7 +49,8 @@ struct BgzfSource {
   DevBuf<uint32_t> d_status;
   DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..] debug counters
   DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
-  uint32_t v2_grid = 0;
+  uint32_t v2_grid = 0, v2_grid_max = 0;  // persistent grid of K1 (waves): for this file / for any launch
+  size_t k1_scratch_stride = 0;
   DevBuf<uint8_t> d_u;  // inflated bytes of the range decoded last
 
   ~BgzfSource();
@@ -46,6 +64,11 @@ struct BgzfSource {
   void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
   void report_v2_debug(uint32_t nb);
   void check_inflate_status(uint32_t b0, uint32_t nb);
+  // the same three steps on a caller-owned context (its stream, its scratch, status relative to b0)
+  void init_ctx(K1Ctx& c, uint32_t max_members);
+  void launch_inflate(K1Ctx& c, uint8_t* dst, uint32_t nb, uint32_t b0);
+  void launch_crc(K1Ctx& c, const uint8_t* dst, uint32_t nb, uint32_t b0);
+  void check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb);
   // Inflate blocks [0, b1) into a temporary device buffer and copy to the host (header / sampling).
   std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1);
 };

@@ -59,13 +59,15 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 //   BIOSCAN_LAPS=1             host wall-clock laps of execute() on stderr
 //   BIOSCAN_K1_WAVES_PER_CU=n  persistent-grid size of K1 (default: the occupancy API's answer)
 //   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 64)
-//   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 65536)
+//   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 16384)
+//   BIOSCAN_CHUNK_MEMBERS_DEVICE=n  the same for bioscan_execute_device (default 1048576)
 struct EnvKnobs {
   bool debug = false, laps = false;
   int k1_waves_per_cu = 0;
   double host_pool_gb = 64.0;
   double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
-  uint32_t chunk_members = 65536;
+  uint32_t chunk_members = 16384;          // BGZF members per pipeline chunk of a host stream (~1.3 GB of Arrow buffers for short reads)
+  uint32_t chunk_members_device = 1u << 20;  // device-resident execution keeps every chunk in HBM anyway: large chunks, short K1 tails
 };
 const EnvKnobs& env_knobs();
 
@@ -113,7 +115,7 @@ struct DevBuf {
 // gigabytes per execute cost far more than the PCIe copy itself (5.2 GB of Arrow buffers: 1.1-1.6 s with fresh pinned
 // allocations against ~0.15 s of copy time), a fresh pageable block takes the copy at 17 GB/s and a recycled one --
 // its pages already touched -- at the full link rate.
-void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned);
+void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned, bool want_pinned = false);
 void host_pool_free(void* p, size_t cap, bool pinned);
 void host_pool_trim();
 
@@ -131,12 +133,12 @@ struct HostBuf {
   }
   ~HostBuf() { reset(); }
   // use_pool = false for one-off blocks that should go back to the system at once (the file image before upload)
-  void alloc(size_t bytes, bool use_pool = true) {
+  void alloc(size_t bytes, bool use_pool = true, bool want_pinned = false) {
     reset();
     n = bytes;
     pooled = use_pool;
     if (use_pool) {
-      p = (uint8_t*)host_pool_alloc(bytes ? bytes : 1, &cap, &pinned);
+      p = (uint8_t*)host_pool_alloc(bytes ? bytes : 1, &cap, &pinned, want_pinned);
       return;
     }
     cap = bytes ? bytes : 1;  // the file image: read once, uploaded once -- pinned memory is the faster path for that (3.3 s against 6.2 s for 16.5 GB)

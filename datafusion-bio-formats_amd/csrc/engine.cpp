@@ -38,7 +38,8 @@ const EnvKnobs& env_knobs() {
     if (const char* e = getenv("BIOSCAN_K1_WAVES_PER_CU")) v.k1_waves_per_cu = atoi(e);
     if (const char* e = getenv("BIOSCAN_HOST_POOL_GB")) v.host_pool_gb = atof(e);
     if (const char* e = getenv("BIOSCAN_DEV_POOL_GB")) v.dev_pool_gb = atof(e);
-    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS")) v.chunk_members = (uint32_t)std::max(64, atoi(e));
+    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS")) v.chunk_members = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS_DEVICE")) v.chunk_members_device = (uint32_t)std::max(1, atoi(e));
     return v;
   }();
   return k;
@@ -102,24 +103,31 @@ static size_t host_class(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 static size_t host_pool_limit() { return (size_t)(env_knobs().host_pool_gb * (double)(1ull << 30)); }
-void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned) {
+// Two kinds of cached host blocks.  Pageable ones serve one-shot copies (a fresh pageable block takes a copy at 17 GB/s and
+// a recycled one -- its pages already touched -- at the link rate, tools/experiments/d2h_paths.cpp).  Pinned ones serve the
+// chunk pipeline of a stream: hipMemcpyAsync only overlaps with the next chunk's kernels when the destination is pinned,
+// and pinning costs ~0.15 s per GB once, which the cache amortises (a stream recycles two or three chunk-sized blocks).
+static std::multimap<size_t, void*> g_hpool_pinned;
+void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned, bool want_pinned) {
   const size_t c = host_class(bytes);
   {
     std::lock_guard<std::mutex> lk(g_hpool_mu);
-    auto it = g_hpool.find(c);
-    if (it != g_hpool.end()) {
+    auto& pool = want_pinned ? g_hpool_pinned : g_hpool;
+    auto it = pool.find(c);
+    if (it != pool.end()) {
       void* p = it->second;
-      g_hpool.erase(it);
+      pool.erase(it);
       g_hpool_bytes -= c;
-      *cap = c; *pinned = false;
+      *cap = c; *pinned = want_pinned;
       return p;
     }
   }
-  // Plain (pageable) memory on purpose -- measured on this platform for 4 GiB (tools/experiments/d2h_paths.cpp): a
-  // fresh pinned block costs 0.60 s to allocate and 0.39 s to free around a 0.08 s copy; a fresh malloc'd block takes
-  // the copy at 17 GB/s (0.25 s, page faults included) and, once its pages have been touched, at the same 52 GB/s as
-  // pinned memory.  Cached blocks keep their pages, so the steady state is the full link rate either way.
-  void* p = malloc(c);
+  void* p = nullptr;
+  if (want_pinned) {
+    if (hipHostMalloc(&p, c, hipHostMallocDefault) == hipSuccess) { *cap = c; *pinned = true; return p; }
+    (void)hipGetLastError();  // the locked-memory budget is exhausted: a pageable block still works, the copy just blocks
+  }
+  p = malloc(c);
   if (!p) {
     host_pool_trim();
     p = malloc(c);
@@ -131,8 +139,8 @@ void* host_pool_alloc(size_t bytes, size_t* cap, bool* pinned) {
 void host_pool_free(void* p, size_t cap, bool pinned) {
   {
     std::lock_guard<std::mutex> lk(g_hpool_mu);
-    if (!pinned && g_hpool_bytes + cap <= host_pool_limit()) {
-      g_hpool.emplace(cap, p);
+    if (g_hpool_bytes + cap <= host_pool_limit()) {
+      (pinned ? g_hpool_pinned : g_hpool).emplace(cap, p);
       g_hpool_bytes += cap;
       return;
     }
@@ -143,6 +151,8 @@ void host_pool_trim() {
   std::lock_guard<std::mutex> lk(g_hpool_mu);
   for (auto& kv : g_hpool) free(kv.second);
   g_hpool.clear();
+  for (auto& kv : g_hpool_pinned) (void)hipHostFree(kv.second);
+  g_hpool_pinned.clear();
   g_hpool_bytes = 0;
 }
 }  // namespace bioscan
@@ -172,13 +182,12 @@ struct StageTimer {
 struct DecodeRange {
   uint32_t b_lo = 0, b_hi = 0;
   uint64_t first_rel = 0, stop_rel = 0;  // relative to the range's first inflated byte
-  bool operator==(const DecodeRange& o) const {
-    return b_lo == o.b_lo && b_hi == o.b_hi && first_rel == o.first_rel && stop_rel == o.stop_rel;
-  }
 };
 
 // -------------------------------------------------------------------------------------------------
-// Provider
+// Provider: the file resident in HBM, its header, schema and index.  Immutable once opened -- every execute() owns
+// its stream, scratch and buffers (BamExecState below), as every execute of the reference owns its reader
+// (bio-format-bam/src/physical_exec.rs:878-881).
 // -------------------------------------------------------------------------------------------------
 struct Provider : BgzfSource {
   int kind = 0;              // 0 = BAM, 1 = FASTQ
@@ -189,6 +198,7 @@ struct Provider : BgzfSource {
   bool binary_cigar = false;
   std::vector<std::string> tag_fields;
   bool has_tag_fields = false;
+  uint32_t chunk_members = 0;  // 0 = default
 
   BamHeader hdr;
   std::vector<FieldDef> fields;  // full schema
@@ -198,16 +208,8 @@ struct Provider : BgzfSource {
   std::string index_path;
   Bai bai;
 
-  bool decoded = false;
-  bool have_keys = false;
-  DecodeRange dec_range;
-  DevBuf<uint64_t> d_rec_off;
-  uint64_t n_rec = 0;
-  DevBuf<int32_t> k_refid, k_pos, k_end1;
-  DevBuf<uint32_t> k_fm;
   DevBuf<uint8_t> d_ref_names;
   DevBuf<uint32_t> d_ref_name_off, d_ref_name_len;
-  bioscan_scan_stats decode_stats{};
 
   DecodeRange whole_file() const {
     DecodeRange r;
@@ -216,7 +218,12 @@ struct Provider : BgzfSource {
     return r;
   }
 
-  void upload_ref_names() {
+  // file + reference-name table in HBM (idempotent; the only provider state an execute waits for)
+  void prepare_device() {
+    std::lock_guard<std::mutex> lk(mu);
+    make_resident();
+    if (d_ref_name_off.p) return;
+    set_device();
     std::vector<uint32_t> off{0}, len;
     std::string blob;
     for (auto& n : hdr.ref_names) {
@@ -225,113 +232,20 @@ struct Provider : BgzfSource {
       len.push_back((uint32_t)n.size());
     }
     d_ref_names.alloc(std::max<size_t>(blob.size(), 1));
-    d_ref_name_off.alloc(off.size());
     d_ref_name_len.alloc(std::max<size_t>(len.size(), 1));
+    DevBuf<uint32_t> o(off.size());
     if (!blob.empty()) HIP_CHECK(hipMemcpy(d_ref_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(d_ref_name_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(o.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
     if (!len.empty()) HIP_CHECK(hipMemcpy(d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
+    d_ref_name_off = std::move(o);  // published last: its pointer is the "ready" flag read above
   }
+};
 
-  // Full decode: inflate every block, find every record, build the key table.  Cached.
-  // Decode members [r.b_lo, r.b_hi): inflate, CRC-check, find every record that starts in
-  // [r.first_rel, r.stop_rel) of the range's inflated bytes, build the key table.  One range is cached.
-  // caller holds `mu` and keeps holding it until the last kernel that reads d_u / the record table has finished
-  void decode(bool force, const DecodeRange& r, bool need_keys) {
-    if (decoded && !force && r == dec_range && (have_keys || !need_keys)) return;
-    decode_locked(r, need_keys);
-  }
-  void decode_locked(const DecodeRange& r, bool need_keys) {
-    make_resident();
-    set_device();
-    decoded = false;
-    const uint32_t nb_r = r.b_hi - r.b_lo;
-    const uint64_t ulen = blk_uoff[r.b_hi] - blk_uoff[r.b_lo];  // shadows the file total on purpose
-    const uint64_t stop = r.stop_rel;
-    bioscan_scan_stats s{};
-    s.n_blocks = nb_r;
-    s.compressed_bytes = blk_coff[r.b_hi] - blk_coff[r.b_lo];
-    s.inflated_bytes = ulen;
-    StageTimer t(stream), tt(stream);
-    tt.start();
-    if (d_u.n < ulen + 64) d_u.alloc(ulen + 64);
-    t.start();
-    launch_inflate(d_u.p, nb_r, r.b_lo);
-    s.ms_inflate = t.stop();
-    report_v2_debug(nb_r);
-    // CRC32 validation (noodles-bgzf checks every block).  Measured: running it on a second, low-priority
-    // stream beside the chain / extract kernels does not shorten the step on MI355X (the extract kernels are
-    // bandwidth-bound and the CRC kernel just time-slices with them), so it stays in line.
-    t.start();
-    launch_crc(d_u.p, nb_r, r.b_lo);
-    s.ms_crc = t.stop();
-    check_inflate_status(r.b_lo, nb_r);
-
-    // ---- record chain: records starting in [first_rec, stop) ----
-    t.start();
-    const uint64_t first_rec = r.first_rel;
-    if (first_rec > stop || stop > ulen) throw Error("BAM read error: record range extends past end of data");
-    const uint64_t nseg = std::max<uint64_t>((stop + SEG_BYTES - 1) / SEG_BYTES, 1);
-    DevBuf<uint64_t> entry(nseg), exit_(nseg), base(nseg + 1), tmp(scan_tmp_elems(nseg));
-    DevBuf<uint32_t> count(nseg), dirty(nseg), ctr(2);
-    HIP_CHECK(hipMemsetAsync(ctr.p, 0, 8, stream));
-    HIP_CHECK(hipMemsetAsync(dirty.p, 0, nseg * 4, stream));
-    ChainBuffers cb{entry.p, exit_.p, count.p, dirty.p, ctr.p, ctr.p + 1};
-    launch_seg_guess(d_u.p, stop, first_rec, nseg, (int32_t)hdr.ref_names.size(), cb, stream);
-    launch_seg_walk(d_u.p, stop, nseg, cb, 0, stream);
-    for (int iter = 0;; iter++) {
-      s.chain_iterations = (uint64_t)iter + 1;
-      HIP_CHECK(hipMemsetAsync(ctr.p, 0, 4, stream));
-      launch_seg_verify(stop, first_rec, nseg, cb, stream);
-      uint32_t nfix = 0;
-      HIP_CHECK(hipMemcpyAsync(&nfix, ctr.p, 4, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
-      if (env_knobs().debug) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
-      if (nfix == 0) break;
-      if ((uint64_t)iter > nseg + 2) throw Error("record boundary scan did not converge");
-      launch_seg_walk(d_u.p, stop, nseg, cb, 1, stream);
-    }
-    launch_exclusive_scan_u32_to_u64(count.p, base.p, nseg, tmp.p, stream);
-    uint64_t total = 0;
-    HIP_CHECK(hipMemcpyAsync(&total, base.p + nseg, 8, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    n_rec = total;
-    if (d_rec_off.n < n_rec + 1) d_rec_off.alloc(n_rec + 1);
-    launch_seg_emit(d_u.p, stop, nseg, cb, base.p, d_rec_off.p, stream);
-    // last exit must be exactly the end of the stream
-    {
-      DevBuf<unsigned long long> lastx(2);
-      launch_last_exit(exit_.p, nseg, lastx.p, stream);
-      unsigned long long lx[2] = {0, 0};
-      uint32_t errf = 0;
-      HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipMemcpyAsync(lx, lastx.p, 16, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
-      if (errf == 2) throw Error("BAM read error: invalid record (variable-length fields exceed block_size)");
-      if (errf) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
-      const uint64_t last = lx[1];
-      if (last == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
-      if (first_rec < stop && last != stop) throw Error("BAM read error: unexpected end of record stream");
-    }
-    s.ms_chain = t.stop();
-    s.n_records = n_rec;
-    // ---- key table ----
-    have_keys = false;
-    if (need_keys) {
-      if (k_refid.n < n_rec) {
-        k_refid.alloc(n_rec); k_pos.alloc(n_rec); k_end1.alloc(n_rec); k_fm.alloc(n_rec);
-      }
-      RecKeys rk{k_refid.p, k_pos.p, k_end1.p, k_fm.p};
-      t.start();
-      launch_rec_keys(d_u.p, d_rec_off.p, n_rec, rk, stream);
-      s.ms_keys = t.stop();
-      have_keys = true;
-    }
-    if (!d_ref_name_off.p) upload_ref_names();
-    s.ms_total_gpu = tt.stop();
-    decode_stats = s;
-    dec_range = r;
-    decoded = true;
-  }
+// One step of a partition: the records of `range` that pass `sel` (reference: one region query, one unmapped-tail scan,
+// the no-coor scan, or the sequential scan of the whole file).
+struct WorkItem {
+  DecodeRange range;
+  RowSelect sel{};
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -349,10 +263,10 @@ struct Plan {
   std::vector<Filter> residual;
   int fq_strategy = 0;  // FASTQ: 0 sequential, 1 BGZF block ranges, 2 plain byte ranges
   std::vector<std::pair<uint64_t, uint64_t>> fq_parts;  // (start, end); end = ~0 for open-ended
-  // member / byte range of each partition (BAI chunk queries + block lookups), computed on first use: re-planning it on
-  // every execute cost 1-3 ms of host time per partition
-  mutable std::mutex range_mu;
-  mutable std::vector<std::pair<bool, DecodeRange>> range_cache;
+  // work list of each partition (BAI chunk queries + block lookups), computed on first use: re-planning it on every
+  // execute cost 1-3 ms of host time per partition
+  mutable std::mutex work_mu;
+  mutable std::vector<std::pair<bool, std::vector<WorkItem>>> work_cache;
   int n_partitions() const {
     if (prov && prov->kind == 1) return fq_strategy == 0 ? 1 : (int)fq_parts.size();
     return empty ? 0 : (indexed ? (int)assignments.size() : 1);
@@ -360,7 +274,8 @@ struct Plan {
 };
 
 // -------------------------------------------------------------------------------------------------
-// Result columns
+// Result columns.  A Result holds the Arrow buffers of ONE CHUNK of a partition's rows.  `phase` rows of its first
+// batch were produced by the previous chunk: batch b covers rows [max(0, b*bs - phase), (b+1)*bs - phase).
 // -------------------------------------------------------------------------------------------------
 struct Column {
   FieldDef fd;
@@ -371,6 +286,7 @@ struct Column {
   DevBuf<int32_t> d_off32;    // nb*(bs+1)
   DevBuf<uint64_t> d_valid;   // ceil(n/64) words
   DevBuf<uint32_t> d_len;     // scratch lengths
+  DevBuf<uint64_t> d_base;    // per batch: first byte / element (copied to h_batch_base)
   uint64_t total_bytes = 0;   // var: bytes; list: elements
   // host
   HostBuf h_values, h_off32, h_valid;
@@ -389,16 +305,25 @@ struct Column {
 struct Result {
   uint64_t n_rows = 0;
   uint32_t batch_size = 8192;
+  uint32_t phase = 0;
   std::vector<Column> cols;
   bool on_host = false;
+  int device = 0;
+  hipEvent_t copied = nullptr;  // recorded behind the chunk's D2H copies (copy stream); null once waited for
   bioscan_scan_stats stats{};
-  uint64_t n_batches() const { return (n_rows + batch_size - 1) / batch_size; }
-};
-
-struct Stream {
-  std::shared_ptr<Result> res;
-  uint64_t next = 0;
-  Provider* prov = nullptr;
+  uint64_t n_batches() const { return n_rows ? (n_rows + phase + batch_size - 1) / batch_size : 0; }
+  uint64_t batch_row0(uint64_t b) const { return b ? b * batch_size - phase : 0; }
+  uint64_t batch_rows(uint64_t b) const { return std::min<uint64_t>((b + 1) * (uint64_t)batch_size - phase, n_rows) - batch_row0(b); }
+  ~Result() {
+    if (copied) {
+      int prev = 0;
+      (void)hipGetDevice(&prev);
+      (void)hipSetDevice(device);
+      (void)hipEventSynchronize(copied);  // the copies write into host blocks that go back to the cache right after this
+      (void)hipEventDestroy(copied);
+      (void)hipSetDevice(prev);
+    }
+  }
 };
 
 static int list_elem_code(ArrowKind k) { return (int)k - (int)AK_LIST_INT8; }
@@ -496,46 +421,15 @@ static size_t block_of_coff(const Provider& p, uint64_t c) {
   return (size_t)(it - p.blk_coff.begin());
 }
 
-// The members a partition has to inflate: the span of the BAI chunks of its regions.
-// Mapped regions -> noodles' merged chunk list (reg2bins, linear-index floor).  The no-coor
-// partition starts after the last placed record (coordinate-sorted file: everything a BAI indexes).
-// Per-reference unmapped tails scan "from the reference's last chunk until the reference changes",
-// which is only decidable by looking at every later record: those partitions decode the whole file.
-static DecodeRange partition_range_uncached(const Plan& plan, int partition);
-static DecodeRange partition_range(const Plan& plan, int partition) {
-  if (!plan.indexed) return plan.prov->whole_file();
-  std::lock_guard<std::mutex> lk(plan.range_mu);
-  if (plan.range_cache.size() != plan.assignments.size()) plan.range_cache.assign(plan.assignments.size(), {false, DecodeRange{}});
-  auto& slot = plan.range_cache[(size_t)partition];
-  if (!slot.first) { slot.second = partition_range_uncached(plan, partition); slot.first = true; }
-  return slot.second;
-}
-static DecodeRange partition_range_uncached(const Plan& plan, int partition) {
-  const Provider& p = *plan.prov;
-  if (!plan.indexed) return p.whole_file();
-  uint64_t lo = ~0ull, hi = 0;
-  bool to_eof = false;
-  for (auto& r : plan.assignments[partition].regions) {
-    if (r.unmapped_tail) {
-      if (r.chrom != "*") return p.whole_file();
-      if (!(p.bai.has_no_coor && p.bai.n_no_coor > 0)) continue;
-      uint64_t seek = 0;
-      for (auto& rf : p.bai.refs)
-        for (auto& b : rf.bins)
-          for (auto& c : b.second) seek = std::max(seek, c.second);
-      if (seek == 0) return p.whole_file();
-      lo = std::min(lo, seek);
-      to_eof = true;
-      continue;
-    }
-    long ref = -1;
-    for (size_t i = 0; i < p.hdr.ref_names.size(); i++) if (p.hdr.ref_names[i] == r.chrom) { ref = (long)i; break; }
-    if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
-    auto chunks = bai_query_chunks(p.bai, (size_t)ref, r.has_start, r.start, r.has_end, r.end);
-    for (auto& c : chunks) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
-  }
+
+// -------------------------------------------------------------------------------------------------
+// Work list of a partition (bio-format-bam/src/physical_exec.rs:864-1258): regions in assignment order.  A mapped
+// region decodes the members spanned by noodles' merged chunk list of its query (reg2bins, linear-index floor); the
+// no-coor scan starts behind the last placed record; the unmapped tail of a reference starts at that reference's last
+// chunk end and runs until the reference changes (the executor stops it there).
+// -------------------------------------------------------------------------------------------------
+static DecodeRange range_from_voffs(const Provider& p, uint64_t lo, uint64_t hi, bool to_eof) {
   DecodeRange d;
-  if (lo == ~0ull) return d;  // nothing to read
   d.b_lo = (uint32_t)block_of_coff(p, lo >> 16);
   const uint64_t base = p.blk_uoff[d.b_lo];
   d.first_rel = (lo & 0xFFFF);
@@ -550,215 +444,436 @@ static DecodeRange partition_range_uncached(const Plan& plan, int partition) {
   return d;
 }
 
-// Select the rows of one partition, in region order (file order inside a region).
-static void select_rows(const Plan& plan, int partition, DevBuf<uint64_t>* rows_owned, const uint64_t** rows, uint64_t* n_rows) {
-  Provider& p = *plan.prov;
-  hipStream_t st = p.stream;
+static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition, size_t n_terms) {
+  const Provider& p = *plan.prov;
+  std::vector<WorkItem> items;
   if (!plan.indexed) {
-    *rows = p.d_rec_off.p;
-    *n_rows = p.n_rec;
-    return;
+    WorkItem w;
+    w.range = p.whole_file();
+    w.sel.mode = 0;
+    items.push_back(w);
+    return items;
   }
-  const auto& regions = plan.assignments[partition].regions;
-  std::vector<FilterTerm> terms;
-  const bool satisfiable = build_terms(plan, &terms);
-  DevBuf<FilterTerm> d_terms(std::max<size_t>(terms.size(), 1));
-  if (!terms.empty()) HIP_CHECK(hipMemcpy(d_terms.p, terms.data(), terms.size() * sizeof(FilterTerm), hipMemcpyHostToDevice));
-  const uint64_t n = p.n_rec;
-  RecKeys rk{p.k_refid.p, p.k_pos.p, p.k_end1.p, p.k_fm.p};
-  DevBuf<uint32_t> keep(std::max<uint64_t>(n, 1));
-  DevBuf<uint64_t> kscan(n + 1), tmp(scan_tmp_elems(n));
-  DevBuf<unsigned long long> d_idx(2);
-  std::vector<RowSelect> sels;
-  for (auto& r : regions) {
-    RowSelect s{};
-    s.zero_based = p.zero_based ? 1 : 0;
-    s.n_terms = (int32_t)terms.size();
+  auto ref_index = [&](const std::string& name) -> long {
+    for (size_t i = 0; i < p.hdr.ref_names.size(); i++) if (p.hdr.ref_names[i] == name) return (long)i;
+    return -1;
+  };
+  for (auto& r : plan.assignments[partition].regions) {
+    WorkItem w;
+    w.sel.zero_based = p.zero_based ? 1 : 0;
+    w.sel.n_terms = (int32_t)n_terms;
     if (r.unmapped_tail) {
+      uint64_t seek = 0;
+      bool have = false;
       if (r.chrom == "*") {
         if (!(p.bai.has_no_coor && p.bai.n_no_coor > 0)) continue;
-        s.mode = 3;
+        w.sel.mode = 3;
+        for (auto& rf : p.bai.refs)
+          for (auto& b : rf.bins)
+            for (auto& c : b.second) { seek = std::max(seek, c.second); have = true; }
       } else {
-        long ref = -1;
-        for (size_t i = 0; i < p.hdr.ref_names.size(); i++) if (p.hdr.ref_names[i] == r.chrom) { ref = (long)i; break; }
+        const long ref = ref_index(r.chrom);
         if (ref < 0) throw Error("Reference '" + r.chrom + "' not found in BAM header");
         if ((size_t)ref >= p.bai.refs.size()) throw Error("Reference index " + std::to_string(ref) + " not found in BAI index");
-        uint64_t seek = 0;
-        bool have = false;
+        w.sel.mode = 2;
+        w.sel.ref = (int32_t)ref;
         for (auto& b : p.bai.refs[ref].bins) for (auto& c : b.second) { seek = have ? std::max(seek, c.second) : c.second; have = true; }
-        if (!have) {
+        if (!have)
           for (auto& rf : p.bai.refs) if (!rf.intervals.empty()) { seek = have ? std::max(seek, rf.intervals.back()) : rf.intervals.back(); have = true; }
-        }
-        uint64_t uo = (have && seek) ? voff_to_uoff(p, seek) : p.hdr.first_record_offset;
-        unsigned long long h[2];
-        launch_lower_bound_u64(p.d_rec_off.p, n, uo, d_idx.p, st);
-        HIP_CHECK(hipMemcpyAsync(h, d_idx.p, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        uint64_t i0 = h[0];
-        h[0] = n;
-        HIP_CHECK(hipMemcpyAsync(d_idx.p, h, 8, hipMemcpyHostToDevice, st));
-        launch_find_first(p.k_refid.p, n, i0, (int32_t)ref, 1, d_idx.p, st);
-        HIP_CHECK(hipMemcpyAsync(h, d_idx.p, 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-        uint64_t first = h[0];
-        uint64_t last = n;
-        if (first < n) {
-          h[0] = n;
-          HIP_CHECK(hipMemcpyAsync(d_idx.p, h, 8, hipMemcpyHostToDevice, st));
-          launch_find_first(p.k_refid.p, n, first + 1, (int32_t)ref, 0, d_idx.p, st);
-          HIP_CHECK(hipMemcpyAsync(h, d_idx.p, 8, hipMemcpyDeviceToHost, st));
-          HIP_CHECK(hipStreamSynchronize(st));
-          last = h[0];
-        }
-        s.mode = 2;
-        s.ref = (int32_t)ref;
-        s.i_lo = first;
-        s.i_hi = last;
       }
+      w.range = (have && seek) ? range_from_voffs(p, seek, 0, true) : p.whole_file();
     } else {
-      long ref = -1;
-      for (size_t i = 0; i < p.hdr.ref_names.size(); i++) if (p.hdr.ref_names[i] == r.chrom) { ref = (long)i; break; }
+      const long ref = ref_index(r.chrom);
       if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
-      s.mode = 1;
-      s.ref = (int32_t)ref;
-      s.start1 = r.has_start ? (int64_t)r.start : 0;
-      s.end1 = r.has_end ? (int64_t)r.end : INT64_MAX;
-      s.q_start1 = r.has_start ? (int64_t)r.start : 1;
+      auto chunks = bai_query_chunks(p.bai, (size_t)ref, r.has_start, r.start, r.has_end, r.end);
+      if (chunks.empty()) continue;  // nothing indexed for the region
+      uint64_t lo = ~0ull, hi = 0;
+      for (auto& c : chunks) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
+      w.range = range_from_voffs(p, lo, hi, false);
+      w.sel.mode = 1;
+      w.sel.ref = (int32_t)ref;
+      w.sel.start1 = r.has_start ? (int64_t)r.start : 0;
+      w.sel.end1 = r.has_end ? (int64_t)r.end : INT64_MAX;
+      w.sel.q_start1 = r.has_start ? (int64_t)r.start : 1;
     }
-    sels.push_back(s);
+    items.push_back(w);
   }
-  if (!satisfiable) sels.clear();
-  // One pass per selection: flags, scan, compaction straight behind the rows of the previous selections.  A record
-  // belongs to one region unless the caller's regions overlap, so n rows of capacity are enough; if they are not,
-  // the totals are taken first and the selections are run again into an exact allocation.
-  uint64_t total = 0;
-  bool overflow = false;
-  rows_owned->alloc(std::max<uint64_t>(n, 1));
-  for (auto& s : sels) {
-    launch_row_flags(rk, n, s, d_terms.p, keep.p, st);
-    launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
-    uint64_t t = 0;
-    HIP_CHECK(hipMemcpyAsync(&t, kscan.p + n, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (total + t > n) { overflow = true; break; }
-    if (t) launch_compact_rows(p.d_rec_off.p, keep.p, kscan.p, n, rows_owned->p, total, st);
-    total += t;
-  }
-  if (overflow) {
-    std::vector<uint64_t> totals;
-    total = 0;
-    for (auto& s : sels) {
-      launch_row_flags(rk, n, s, d_terms.p, keep.p, st);
-      launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
-      uint64_t t = 0;
-      HIP_CHECK(hipMemcpyAsync(&t, kscan.p + n, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      totals.push_back(t);
-      total += t;
-    }
-    HIP_CHECK(hipStreamSynchronize(st));
-    rows_owned->alloc(std::max<uint64_t>(total, 1));
-    uint64_t base = 0;
-    for (size_t k = 0; k < sels.size(); k++) {
-      if (totals[k]) {
-        launch_row_flags(rk, n, sels[k], d_terms.p, keep.p, st);
-        launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n, tmp.p, st);
-        launch_compact_rows(p.d_rec_off.p, keep.p, kscan.p, n, rows_owned->p, base, st);
-      }
-      base += totals[k];
-    }
-  }
-  HIP_CHECK(hipStreamSynchronize(st));
-  *rows = rows_owned->p;
-  *n_rows = total;
+  return items;
+}
+static std::vector<WorkItem> build_work(const Plan& plan, int partition, size_t n_terms) {
+  std::lock_guard<std::mutex> lk(plan.work_mu);
+  const size_t np = (size_t)std::max(plan.n_partitions(), 1);
+  if (plan.work_cache.size() != np) plan.work_cache.assign(np, {false, {}});
+  auto& slot = plan.work_cache[(size_t)partition];
+  if (!slot.first) { slot.second = build_work_uncached(plan, partition, n_terms); slot.first = true; }
+  return slot.second;
 }
 
-// D2H of a partition's Arrow buffers (bioscan_next then exports zero-copy windows of them)
-static void copy_result_to_host(Result& res, hipStream_t st) {
+// -------------------------------------------------------------------------------------------------
+// D2H of a chunk's Arrow buffers.  The copies run on `copy_st` behind an event of the compute stream, into pinned
+// blocks, so they overlap with the next chunk's kernels; finish_copy() waits for them and drops the device buffers.
+// -------------------------------------------------------------------------------------------------
+static void start_copy_to_host(Result& res, hipStream_t st, hipStream_t copy_st) {
   const uint64_t n = res.n_rows, nb = res.n_batches(), nwords = (n + 63) / 64;
   const uint32_t batch_size = res.batch_size;
+  for (auto& col : res.cols)
+    if (col.d_off32.p && n) {
+      col.d_base.alloc(nb);
+      launch_batch_bases(col.d_off64.p, nb, batch_size, res.phase, col.d_base.p, st);
+    }
+  hipEvent_t ready;
+  HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(ready, st));
+  HIP_CHECK(hipStreamWaitEvent(copy_st, ready, 0));
+  (void)hipEventDestroy(ready);
   for (auto& col : res.cols) {
     if (col.d_values.p && n) {
       uint64_t bytes = col.is_var() ? col.total_bytes : col.is_list() ? col.total_bytes * col.list_elem_bytes() : n * 4;
-      col.h_values.alloc(std::max<uint64_t>(bytes, 1));
-      if (bytes) HIP_CHECK(hipMemcpyAsync(col.h_values.p, col.d_values.p, bytes, hipMemcpyDeviceToHost, st));
+      col.h_values.alloc(std::max<uint64_t>(bytes, 1), true, true);
+      if (bytes) HIP_CHECK(hipMemcpyAsync(col.h_values.p, col.d_values.p, bytes, hipMemcpyDeviceToHost, copy_st));
     }
     if (col.d_off32.p && n) {
       uint64_t bytes = nb * ((uint64_t)batch_size + 1) * 4;
-      col.h_off32.alloc(bytes);
-      HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, st));
+      col.h_off32.alloc(bytes, true, true);
+      HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, copy_st));
       col.h_batch_base.resize(nb);
-      DevBuf<uint64_t> d_base(nb);
-      launch_batch_bases(col.d_off64.p, nb, batch_size, d_base.p, st);
-      HIP_CHECK(hipMemcpyAsync(col.h_batch_base.data(), d_base.p, nb * 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));  // d_base is released at the end of this scope
+      HIP_CHECK(hipMemcpyAsync(col.h_batch_base.data(), col.d_base.p, nb * 8, hipMemcpyDeviceToHost, copy_st));
     }
     if (col.d_valid.p && n) {
-      col.h_valid.alloc(nwords * 8 + 8);
-      HIP_CHECK(hipMemcpyAsync(col.h_valid.p, col.d_valid.p, nwords * 8, hipMemcpyDeviceToHost, st));
+      col.h_valid.alloc(nwords * 8 + 8, true, true);
+      HIP_CHECK(hipMemcpyAsync(col.h_valid.p, col.d_valid.p, nwords * 8, hipMemcpyDeviceToHost, copy_st));
     }
   }
-  HIP_CHECK(hipStreamSynchronize(st));
+  HIP_CHECK(hipEventCreateWithFlags(&res.copied, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(res.copied, copy_st));
+}
+static void finish_copy(Result& res) {
+  if (res.copied) {
+    HIP_CHECK(hipEventSynchronize(res.copied));
+    (void)hipEventDestroy(res.copied);
+    res.copied = nullptr;
+  }
   for (auto& col : res.cols) {
-    col.d_values.reset(); col.d_off64.reset(); col.d_off32.reset(); col.d_valid.reset();
+    col.d_values.reset(); col.d_off64.reset(); col.d_off32.reset(); col.d_valid.reset(); col.d_base.reset();
   }
   res.on_host = true;
 }
+static void copy_result_to_host(Result& res, hipStream_t st) {  // one-shot form (FASTQ): same stream, waited for at once
+  start_copy_to_host(res, st, st);
+  finish_copy(res);
+}
 
-static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, uint32_t batch_size, bool force_decode, bool to_host) {
-  Provider& p = *plan.prov;
-  const auto wall0 = std::chrono::steady_clock::now();
-  const bool laps = env_knobs().laps;
-  auto lap = [&](const char* what) {
-    if (laps) fprintf(stderr, "[bioscan] bam partition %d: %-18s at %8.3f ms\n", partition, what,
-                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
-  };
-  const DecodeRange range = partition_range(plan, partition);
-  lap("range planned");
-  // One critical section from the decode to the last extract kernel: the provider caches ONE decoded range, and another
-  // thread executing a different partition of the same plan would otherwise replace it between the two steps.
-  std::lock_guard<std::mutex> lk(p.mu);
-  p.decode(force_decode, range, plan.indexed);
-  lap("decoded");
-  p.set_device();
-  hipStream_t st = p.stream;
-  auto res = std::make_shared<Result>();
-  res->batch_size = batch_size;
-  res->stats = p.decode_stats;
-  StageTimer t(st);
-  t.start();
-  DevBuf<uint64_t> rows_owned;
-  const uint64_t* rows = nullptr;
-  uint64_t n = 0;
-  select_rows(plan, partition, &rows_owned, &rows, &n);
-  res->stats.ms_select = t.stop();
-  lap("rows selected");
-  t.start();
-  res->n_rows = n;
-  res->stats.n_rows = n;
-  const uint64_t nwords = (n + 63) / 64;
-  const uint64_t nb = res->n_batches();
+// -------------------------------------------------------------------------------------------------
+// BamExecState: the chunk pipeline of ONE execute() -- the analogue of the reference's per-partition reader + builders
+// (bio-format-bam/src/physical_exec.rs:857-862: one batch in flight per partition).  The partition's work items are
+// streamed in chunks of `chunk_members` BGZF members: inflate + CRC32, record chain (the record that straddles the end
+// of a chunk is carried over as bytes), row selection, field extract into the chunk's own Arrow buffers, D2H on a second
+// stream while the next chunk runs.  HBM footprint: two inflated chunk buffers + one chunk of Arrow buffers per result
+// in flight -- O(chunk), independent of the file size.
+// -------------------------------------------------------------------------------------------------
+struct BamExecState {
+  const Plan& plan;
+  Provider& p;
+  const uint32_t batch_size;
+  const bool to_host;
+  const uint32_t chunk_members;
+  K1Ctx k1;
+  hipStream_t st = nullptr, copy_st = nullptr;
+  std::vector<WorkItem> items;
+  size_t item = 0;
+  // position inside the current item
+  bool item_open = false;
+  uint32_t next_member = 0;
+  uint64_t skip = 0;        // bytes of the next chunk in front of its first record (BAM header / chunk offset of the range start)
+  uint64_t consumed = 0;    // inflated bytes of the item's range handed to chunks so far
+  uint64_t carry_len = 0;   // bytes of a record cut by the previous chunk's end, at the head of ubuf[cur]
+  bool tail_seen = false, tail_done = false;
+  DevBuf<uint8_t> ubuf[2];
+  int cur = 0;
+  uint64_t rows_emitted = 0;
+  bool satisfiable = true;
+  std::vector<FilterTerm> terms;
+  DevBuf<FilterTerm> d_terms;
+  DevBuf<uint16_t> d_tags;
+  bioscan_scan_stats total{};
+  std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
 
-  // ---- columns ----
-  res->cols.resize(plan.out_fields.size());
-  for (size_t c = 0; c < plan.out_fields.size(); c++) {
-    res->cols[c].fd = plan.out_fields[c];
-    res->cols[c].n_rows = n;
+  BamExecState(const Plan& pl, int partition, uint32_t bs, bool host)
+      : plan(pl), p(*pl.prov), batch_size(bs), to_host(host),
+        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device) {
+    p.prepare_device();
+    p.set_device();
+    satisfiable = build_terms(plan, &terms);
+    items = build_work(plan, partition, terms.size());
+    if (!satisfiable) items.clear();
+    p.init_ctx(k1, std::min<uint32_t>(chunk_members, std::max<uint32_t>(p.n_blocks(), 1)));
+    st = k1.stream;
+    if (to_host) HIP_CHECK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
+    d_terms.alloc(std::max<size_t>(terms.size(), 1));
+    if (!terms.empty()) HIP_CHECK(hipMemcpyAsync(d_terms.p, terms.data(), terms.size() * sizeof(FilterTerm), hipMemcpyHostToDevice, st));
+    const int nt = (int)p.tag_fields.size();
+    if (nt) {
+      std::vector<uint16_t> tg(nt);
+      for (int k = 0; k < nt; k++) tg[k] = (uint16_t)((uint8_t)p.tag_fields[k][0] | ((uint16_t)(uint8_t)p.tag_fields[k][1] << 8));
+      d_tags.alloc(nt);
+      HIP_CHECK(hipMemcpyAsync(d_tags.p, tg.data(), nt * 2, hipMemcpyHostToDevice, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above go out of scope
   }
-  // map core columns (first occurrence wins; duplicates in a projection share by copy below)
-  int core_col[12];
-  for (int k = 0; k < 12; k++) core_col[k] = -1;
-  std::vector<std::pair<int, int>> tag_cols;  // (output col, tag index)
-  for (size_t c = 0; c < plan.out_fields.size(); c++) {
-    int src = plan.has_projection ? plan.projection[c] : (int)c;
-    if (src < 12) { if (core_col[src] < 0) core_col[src] = (int)c; }
-    else tag_cols.emplace_back((int)c, src - 12);
+  ~BamExecState() {
+    if (copy_st) {
+      int prev = 0;
+      (void)hipGetDevice(&prev);
+      (void)hipSetDevice(p.device);
+      (void)hipStreamSynchronize(copy_st);
+      (void)hipStreamDestroy(copy_st);
+      (void)hipSetDevice(prev);
+    }
   }
-  DevBuf<uint32_t> err(1);
-  HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
-  uint64_t arrow_bytes = 0;
 
-  if (n) {
+  // Next chunk of rows of the partition (never an empty one), or nullptr when the partition is exhausted.
+  std::shared_ptr<Result> next_chunk() {
+    p.set_device();
+    for (;;) {
+      if (!item_open) {
+        if (item >= items.size()) return nullptr;
+        const WorkItem& w = items[item];
+        next_member = w.range.b_lo;
+        skip = w.range.first_rel;
+        consumed = 0;
+        carry_len = 0;
+        tail_seen = false;
+        tail_done = false;
+        item_open = true;
+        if (w.range.b_hi <= w.range.b_lo || w.range.first_rel >= w.range.stop_rel) { item_open = false; item++; continue; }
+      }
+      auto res = run_chunk(items[item]);
+      if (!item_open) item++;
+      if (res && res->n_rows) return res;
+    }
+  }
+
+  std::shared_ptr<Result> run_chunk(const WorkItem& w) {
+    StageTimer t(st);
+    bioscan_scan_stats s{};
+    // ---- members of this chunk; the item ends with the member that holds stop_rel ----
+    const uint32_t m0 = next_member, m1 = std::min<uint32_t>(w.range.b_hi, m0 + chunk_members);
+    const uint64_t range_u0 = p.blk_uoff[w.range.b_lo];
+    const uint64_t chunk_bytes = p.blk_uoff[m1] - p.blk_uoff[m0];
+    const bool last = m1 == w.range.b_hi || consumed + chunk_bytes >= w.range.stop_rel;
+    const uint64_t take = last ? w.range.stop_rel - consumed : chunk_bytes;  // bytes of the chunk inside the record window
+    uint8_t* u = ubuf[cur].p;
+    if (ubuf[cur].n < carry_len + chunk_bytes + 64) {
+      DevBuf<uint8_t> g(carry_len + chunk_bytes + 64);
+      if (carry_len) HIP_CHECK(hipMemcpyAsync(g.p, ubuf[cur].p, carry_len, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      ubuf[cur] = std::move(g);
+      u = ubuf[cur].p;
+    }
+    s.n_blocks = m1 - m0;
+    s.compressed_bytes = p.blk_coff[m1] - p.blk_coff[m0];
+    s.inflated_bytes = chunk_bytes;
+    t.start();
+    p.launch_inflate(k1, u + carry_len, m1 - m0, m0);
+    s.ms_inflate = t.stop();
+    // CRC32 validation (noodles-bgzf checks every block)
+    t.start();
+    p.launch_crc(k1, u + carry_len, m1 - m0, m0);
+    s.ms_crc = t.stop();
+    p.check_inflate_status(k1, m0, m1 - m0);
+    (void)range_u0;
+
+    // ---- record chain over [0, L): records starting in [first_rec, L); a record cut by L is carried ----
+    t.start();
+    const uint64_t L = carry_len + take;
+    uint64_t n_rec = 0, end_of_records = L;
+    DevBuf<uint64_t> rec_off;
+    if (skip >= take + carry_len) {
+      skip -= take;  // still inside the BAM header
+    } else {
+      const uint64_t first_rec = skip;
+      skip = 0;
+      const uint64_t nseg = std::max<uint64_t>((L + SEG_BYTES - 1) / SEG_BYTES, 1);
+      DevBuf<uint64_t> entry(nseg), exit_(nseg), base(nseg + 1), tmp(scan_tmp_elems(nseg));
+      DevBuf<uint32_t> count(nseg), dirty(nseg), ctr(2);
+      HIP_CHECK(hipMemsetAsync(ctr.p, 0, 8, st));
+      HIP_CHECK(hipMemsetAsync(dirty.p, 0, nseg * 4, st));
+      ChainBuffers cb{entry.p, exit_.p, count.p, dirty.p, ctr.p, ctr.p + 1};
+      const int partial = last ? 0 : 1;
+      launch_seg_guess(u, L, first_rec, nseg, (int32_t)p.hdr.ref_names.size(), cb, st);
+      launch_seg_walk(u, L, nseg, cb, 0, partial, st);
+      for (int iter = 0;; iter++) {
+        s.chain_iterations = (uint64_t)iter + 1;
+        HIP_CHECK(hipMemsetAsync(ctr.p, 0, 4, st));
+        launch_seg_verify(L, first_rec, nseg, cb, st);
+        uint32_t nfix = 0;
+        HIP_CHECK(hipMemcpyAsync(&nfix, ctr.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (env_knobs().debug) fprintf(stderr, "[bioscan] record chain verify round %d: %u segment(s) corrected of %llu\n", iter, nfix, (unsigned long long)nseg);
+        if (nfix == 0) break;
+        if ((uint64_t)iter > nseg + 2) throw Error("record boundary scan did not converge");
+        launch_seg_walk(u, L, nseg, cb, 1, partial, st);
+      }
+      launch_exclusive_scan_u32_to_u64(count.p, base.p, nseg, tmp.p, st);
+      DevBuf<unsigned long long> lastx(2);
+      launch_last_exit(exit_.p, nseg, lastx.p, st);
+      uint64_t total_rec = 0;
+      unsigned long long lx[2] = {0, 0};
+      HIP_CHECK(hipMemcpyAsync(&total_rec, base.p + nseg, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(lx, lastx.p, 16, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      n_rec = total_rec;
+      rec_off.alloc(n_rec + 1);
+      launch_seg_emit(u, L, nseg, cb, base.p, rec_off.p, st);
+      uint32_t errf = 0;
+      HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (errf == 2) throw Error("BAM read error: invalid record (variable-length fields exceed block_size)");
+      const uint64_t lastv = lx[1];
+      if (errf || lastv == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
+      if (lastv != SEG_NONE && (lastv & SEG_PARTIAL)) end_of_records = lastv & ~SEG_PARTIAL;
+      else if (lastv == SEG_NONE) end_of_records = first_rec < L ? first_rec : L;  // no complete record: everything is carried
+      else end_of_records = lastv;
+      if (last && first_rec < L && end_of_records != L) throw Error("BAM read error: unexpected end of record stream");
+      if (end_of_records > L) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
+    }
+    s.ms_chain = t.stop();
+    s.n_records = n_rec;
+
+    // ---- rows of this chunk ----
+    t.start();
+    DevBuf<uint64_t> rows_owned;
+    const uint64_t* rows = rec_off.p;
+    uint64_t n_rows = n_rec;
+    bool stop_item = last;
+    if (w.sel.mode != 0 && n_rec) {
+      DevBuf<int32_t> k_refid(n_rec), k_pos(n_rec), k_end1(n_rec);
+      DevBuf<uint32_t> k_fm(n_rec);
+      RecKeys rk{k_refid.p, k_pos.p, k_end1.p, k_fm.p};
+      StageTimer tk(st);
+      tk.start();
+      launch_rec_keys(u, rec_off.p, n_rec, rk, st);
+      s.ms_keys = tk.stop();
+      RowSelect sel = w.sel;
+      bool any = true;
+      if (sel.mode == 2) {
+        // unmapped tail of a reference (physical_exec.rs:1036-1135): from the first record of the reference at / after the
+        // seek position until the reference changes; chunks before the first such record hold nothing, the chunk in which
+        // the reference changes is the last one
+        DevBuf<unsigned long long> d_idx(1);
+        unsigned long long h = n_rec;
+        uint64_t first = 0;
+        if (!tail_seen) {
+          HIP_CHECK(hipMemcpyAsync(d_idx.p, &h, 8, hipMemcpyHostToDevice, st));
+          launch_find_first(k_refid.p, n_rec, 0, sel.ref, 1, d_idx.p, st);
+          HIP_CHECK(hipMemcpyAsync(&h, d_idx.p, 8, hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+          first = h;
+          if (first < n_rec) tail_seen = true; else any = false;
+        }
+        uint64_t lastr = n_rec;
+        if (tail_seen && any) {
+          h = n_rec;
+          HIP_CHECK(hipMemcpyAsync(d_idx.p, &h, 8, hipMemcpyHostToDevice, st));
+          launch_find_first(k_refid.p, n_rec, first, sel.ref, 0, d_idx.p, st);
+          HIP_CHECK(hipMemcpyAsync(&h, d_idx.p, 8, hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+          lastr = h;
+          if (lastr < n_rec) stop_item = true;  // the reference changed: the scan ends here
+        }
+        sel.i_lo = first;
+        sel.i_hi = lastr;
+      }
+      n_rows = 0;
+      if (any) {
+        DevBuf<uint32_t> keep(n_rec);
+        DevBuf<uint64_t> kscan(n_rec + 1), tmp(scan_tmp_elems(n_rec));
+        launch_row_flags(rk, n_rec, sel, d_terms.p, keep.p, st);
+        launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n_rec, tmp.p, st);
+        uint64_t tsel = 0;
+        HIP_CHECK(hipMemcpyAsync(&tsel, kscan.p + n_rec, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        n_rows = tsel;
+        rows_owned.alloc(std::max<uint64_t>(n_rows, 1));
+        if (n_rows) launch_compact_rows(rec_off.p, keep.p, kscan.p, n_rec, rows_owned.p, 0, st);
+        HIP_CHECK(hipStreamSynchronize(st));  // keep / kscan are released at the end of this scope
+      }
+      rows = rows_owned.p;
+    }
+    s.ms_select = t.stop();
+
+    // ---- field extract -> the chunk's Arrow buffers ----
+    std::shared_ptr<Result> res;
+    if (n_rows) {
+      t.start();
+      res = extract(u, rows, n_rows, (uint32_t)(rows_emitted % batch_size), &s);
+      s.ms_extract = t.stop();
+      rows_emitted += n_rows;
+    }
+    s.n_rows = n_rows;
+    s.ms_total_gpu = s.ms_inflate + s.ms_crc + s.ms_chain + s.ms_select + s.ms_extract;
+    accumulate(s);
+    if (res) {
+      res->stats = s;
+      if (to_host) start_copy_to_host(*res, st, copy_st);
+    }
+
+    // ---- advance: carry the cut record into the other buffer ----
+    consumed += chunk_bytes;
+    next_member = m1;
+    if (stop_item) {
+      item_open = false;
+      carry_len = 0;
+    } else {
+      const uint64_t c = L - end_of_records;
+      const int nxt = cur ^ 1;
+      const uint64_t next_bytes = p.blk_uoff[std::min<uint32_t>(w.range.b_hi, m1 + chunk_members)] - p.blk_uoff[m1];
+      if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
+      if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
+      carry_len = c;
+      cur = nxt;
+    }
+    // every kernel that reads this chunk's scratch (record table, keys, row list) has to be done before the scratch
+    // is released at the end of this scope; the Arrow buffers live on in `res`
+    HIP_CHECK(hipStreamSynchronize(st));
+    return res;
+  }
+
+  void accumulate(const bioscan_scan_stats& s) {
+    total.n_blocks += s.n_blocks; total.compressed_bytes += s.compressed_bytes; total.inflated_bytes += s.inflated_bytes;
+    total.arrow_bytes += s.arrow_bytes; total.n_records += s.n_records; total.n_rows += s.n_rows;
+    total.ms_inflate += s.ms_inflate; total.ms_crc += s.ms_crc; total.ms_chain += s.ms_chain; total.ms_keys += s.ms_keys;
+    total.ms_select += s.ms_select; total.ms_extract += s.ms_extract; total.ms_total_gpu += s.ms_total_gpu;
+    total.chain_iterations = std::max(total.chain_iterations, s.chain_iterations);
+    total.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  }
+
+  // Arrow column buffers (device) of `n` rows whose records start at u + rows[i]
+  std::shared_ptr<Result> extract(const uint8_t* u, const uint64_t* rows, uint64_t n, uint32_t phase, bioscan_scan_stats* s) {
+    auto res = std::make_shared<Result>();
+    res->batch_size = batch_size;
+    res->phase = phase;
+    res->device = p.device;
+    res->n_rows = n;
+    const uint64_t nwords = (n + 63) / 64;
+    const uint64_t nb = res->n_batches();
+    res->cols.resize(plan.out_fields.size());
+    for (size_t c = 0; c < plan.out_fields.size(); c++) {
+      res->cols[c].fd = plan.out_fields[c];
+      res->cols[c].n_rows = n;
+    }
+    // map core columns (a projection never repeats a column: bioscan_scan rejects duplicates)
+    int core_col[12];
+    for (int k = 0; k < 12; k++) core_col[k] = -1;
+    std::vector<std::pair<int, int>> tag_cols;  // (output col, tag index)
+    for (size_t c = 0; c < plan.out_fields.size(); c++) {
+      int src = plan.has_projection ? plan.projection[c] : (int)c;
+      if (src < 12) { if (core_col[src] < 0) core_col[src] = (int)c; }
+      else tag_cols.emplace_back((int)c, src - 12);
+    }
+    DevBuf<uint32_t> err(1);
+    HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
+    uint64_t arrow_bytes = 0;
     CoreCols cc{};
     auto fixed = [&](int idx) -> uint32_t* {
       if (core_col[idx] < 0) return nullptr;
@@ -786,7 +901,7 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
     cc.len_name = lens(0); cc.len_chrom = lens(1); cc.len_cigar = lens(5); cc.len_mate_chrom = lens(7);
     cc.len_seq = lens(9); cc.len_qual = lens(10);
     RowOverride ov{};
-    launch_extract_fixed(p.d_u.p, rows, 0, n, cc, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
+    launch_extract_fixed(u, rows, 0, n, cc, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
                          p.binary_cigar ? 1 : 0, ov, err.p, st);
     throw_extract_err(read_err(err, st));
 
@@ -800,7 +915,7 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
       col.total_bytes = tot;
       col.d_values.alloc(std::max<uint64_t>(tot * elem_bytes, 1));
       col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
-      launch_batch_offsets(col.d_off64.p, n, batch_size, col.d_off32.p, st);
+      launch_batch_offsets(col.d_off64.p, n, batch_size, phase, col.d_off32.p, st);
       arrow_bytes += tot * elem_bytes + nb * ((uint64_t)batch_size + 1) * 4;
     };
     const int var_idx[6] = {0, 1, 5, 7, 9, 10};
@@ -809,32 +924,28 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
     auto dat_of = [&](int idx) -> uint8_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_values.p : nullptr; };
     // name rides with sequence / quality in the row-centric kernel; chrom, cigar, mate_chrom stay one row per lane
     if (core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
-      launch_scatter_small(p.d_u.p, rows, 0, n, nullptr, nullptr, off_of(1), dat_of(1), off_of(5), dat_of(5), off_of(7), dat_of(7),
+      launch_scatter_small(u, rows, 0, n, nullptr, nullptr, off_of(1), dat_of(1), off_of(5), dat_of(5), off_of(7), dat_of(7),
                            p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(), p.binary_cigar ? 1 : 0, ov, st);
     DevBuf<uint32_t> wide(1);
     HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    launch_scatter_seqqual_rows(p.d_u.p, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
+    launch_scatter_seqqual_rows(u, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
     if (core_col[10] >= 0) {
       if (read_err(wide, st)) {
         // exact path for qualities >= 95 (two-byte UTF-8 chars)
         Column& col = res->cols[core_col[10]];
         arrow_bytes -= col.total_bytes;
-        launch_qual_wide_len(p.d_u.p, rows, 0, n, col.d_len.p, st);
+        launch_qual_wide_len(u, rows, 0, n, col.d_len.p, st);
         finish_var(col, 1);
         arrow_bytes -= nb * ((uint64_t)batch_size + 1) * 4;
-        launch_qual_wide_scatter(p.d_u.p, rows, n, col.d_off64.p, col.d_values.p, st);
+        launch_qual_wide_scatter(u, rows, n, col.d_off64.p, col.d_values.p, st);
       }
     }
     // ---- tags ----
     if (!tag_cols.empty()) {
       const int nt = (int)p.tag_fields.size();
-      std::vector<uint16_t> tg(nt);
-      for (int k = 0; k < nt; k++) tg[k] = (uint16_t)((uint8_t)p.tag_fields[k][0] | ((uint16_t)(uint8_t)p.tag_fields[k][1] << 8));
-      DevBuf<uint16_t> d_tg(nt);
-      HIP_CHECK(hipMemcpyAsync(d_tg.p, tg.data(), nt * 2, hipMemcpyHostToDevice, st));
       DevBuf<uint32_t> loc((uint64_t)nt * n);
       DevBuf<uint8_t> typ((uint64_t)nt * n);
-      launch_tag_locate(p.d_u.p, rows, n, d_tg.p, nt, loc.p, typ.p, err.p, st);
+      launch_tag_locate(u, rows, n, d_tags.p, nt, loc.p, typ.p, err.p, st);
       for (auto& tc : tag_cols) {
         Column& col = res->cols[tc.first];
         const uint32_t* l = loc.p + (uint64_t)tc.second * n;
@@ -845,36 +956,30 @@ static std::shared_ptr<Result> run_partition(const Plan& plan, int partition, ui
           col.d_values.alloc(n * 4);
           arrow_bytes += n * 4;
           int kind = col.fd.kind == AK_INT32 ? TAG_INT32 : col.fd.kind == AK_UINT32 ? TAG_UINT32 : TAG_FLOAT32;
-          launch_tag_fixed(p.d_u.p, rows, 0, n, l, ty, kind, (uint32_t*)col.d_values.p, col.d_valid.p, err.p, st);
+          launch_tag_fixed(u, rows, 0, n, l, ty, kind, (uint32_t*)col.d_values.p, col.d_valid.p, err.p, st);
         } else if (col.fd.kind == AK_UTF8) {
           col.d_len.alloc(n);
-          launch_tag_utf8_len(p.d_u.p, rows, 0, n, l, ty, col.d_len.p, col.d_valid.p, err.p, st);
+          launch_tag_utf8_len(u, rows, 0, n, l, ty, col.d_len.p, col.d_valid.p, err.p, st);
           finish_var(col, 1);
-          launch_tag_utf8_scatter(p.d_u.p, rows, n, l, ty, col.d_off64.p, col.d_valid.p, 0, col.d_values.p, st);
+          launch_tag_utf8_scatter(u, rows, n, l, ty, col.d_off64.p, col.d_valid.p, 0, col.d_values.p, st);
         } else if (col.is_list()) {
           col.d_len.alloc(n);
           int elem = list_elem_code(col.fd.kind);
-          launch_tag_list_len(p.d_u.p, rows, 0, n, l, ty, elem, col.d_len.p, col.d_valid.p, err.p, st);
+          launch_tag_list_len(u, rows, 0, n, l, ty, elem, col.d_len.p, col.d_valid.p, err.p, st);
           finish_var(col, col.list_elem_bytes());
-          launch_tag_list_scatter(p.d_u.p, rows, n, l, ty, elem, col.d_off64.p, col.d_values.p, err.p, st);
+          launch_tag_list_scatter(u, rows, n, l, ty, elem, col.d_off64.p, col.d_values.p, err.p, st);
         } else {
           throw Error("unsupported tag column type");
         }
       }
+      throw_extract_err(read_err(err, st));  // loc / typ are released at the end of this scope
     }
     throw_extract_err(read_err(err, st));
     for (auto& col : res->cols) col.d_len.reset();
+    s->arrow_bytes = arrow_bytes;
+    return res;
   }
-  // duplicate projected columns: not supported (DataFusion never sends duplicates)
-  res->stats.ms_extract = t.stop();
-  res->stats.arrow_bytes = arrow_bytes;
-  res->stats.ms_total_gpu = p.decode_stats.ms_total_gpu + res->stats.ms_select + res->stats.ms_extract;
-  lap("end");
-  res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-
-  if (to_host) copy_result_to_host(*res, st);
-  return res;
-}
+};
 
 // -------------------------------------------------------------------------------------------------
 // FASTQ (bio-format-fastq/src/physical_exec.rs)
@@ -888,6 +993,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
   hipStream_t st = p.stream;
   auto res = std::make_shared<Result>();
   res->batch_size = batch_size;
+  res->device = p.device;
   res->cols.resize(plan.out_fields.size());
   for (size_t c = 0; c < plan.out_fields.size(); c++) res->cols[c].fd = plan.out_fields[c];
   const bool bgzf = p.fq_compression == 1;
@@ -938,7 +1044,6 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       p.launch_crc(p.d_u.p, b_hi - b_start, b_start);
       res->stats.ms_crc += t.stop();
       p.check_inflate_status(b_start, b_hi - b_start);
-      p.decoded = false;  // the BAM cache (if any) no longer describes d_u
       u = p.d_u.p;
       res->stats.n_blocks = b_hi - b_start;
       res->stats.compressed_bytes = p.blk_coff[b_hi] - p.blk_coff[b_start];
@@ -1062,7 +1167,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       col.total_bytes = tot;
       col.d_values.alloc(std::max<uint64_t>(tot, 1));
       col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
-      launch_batch_offsets(col.d_off64.p, n, batch_size, col.d_off32.p, st);
+      launch_batch_offsets(col.d_off64.p, n, batch_size, 0, col.d_off32.p, st);
       launch_scatter_ranges(u, srcs[k].p, n, col.d_off64.p, col.d_values.p, tot, st);
       arrow_bytes += tot + nb * ((uint64_t)batch_size + 1) * 4;
       col.d_len.reset();
@@ -1166,6 +1271,7 @@ struct ArrayPriv {
   std::vector<ArrowArray*> children;
   std::vector<std::unique_ptr<ArrowArray>> owned;
   std::vector<uint8_t> local_valid;  // repacked validity when the batch is not byte aligned
+  std::vector<std::unique_ptr<uint8_t[]>> own;  // buffers of a batch stitched from several chunks
 };
 static void release_array(ArrowArray* a) {
   if (!a || !a->release) return;
@@ -1201,8 +1307,8 @@ static int64_t count_nulls(const uint8_t* bits, uint64_t bit0, uint64_t nbits) {
 
 static void export_batch(const std::shared_ptr<Result>& res, uint64_t b, ArrowArray* out) {
   const uint64_t bs = res->batch_size;
-  const uint64_t r0 = b * bs;
-  const uint64_t rows = std::min<uint64_t>(bs, res->n_rows - r0);
+  const uint64_t r0 = res->batch_row0(b);
+  const uint64_t rows = res->batch_rows(b);
   ArrayPriv* top = init_array(out, res, (int64_t)rows);
   top->buffers.push_back(nullptr);
   for (auto& col : res->cols) {
@@ -1249,6 +1355,152 @@ static void export_batch(const std::shared_ptr<Result>& res, uint64_t b, ArrowAr
   }
   finish_array(out);
 }
+
+// A batch whose rows come from more than one chunk (the tail batch of one chunk + the head batch of the next, or several
+// small chunks): the pieces -- each a whole device batch of its chunk -- are concatenated into buffers the exported
+// array owns.  At most one batch per chunk takes this path.
+struct Piece {
+  std::shared_ptr<Result> res;
+  uint64_t b;
+};
+static void export_pieces(const std::vector<Piece>& pieces, ArrowArray* out) {
+  if (pieces.size() == 1) { export_batch(pieces[0].res, pieces[0].b, out); return; }
+  uint64_t rows = 0;
+  for (auto& pc : pieces) rows += pc.res->batch_rows(pc.b);
+  const Result& first = *pieces[0].res;
+  ArrayPriv* top = init_array(out, nullptr, (int64_t)rows);
+  top->buffers.push_back(nullptr);
+  for (size_t c = 0; c < first.cols.size(); c++) {
+    const Column& c0 = first.cols[c];
+    std::unique_ptr<ArrowArray> ca(new ArrowArray);
+    ArrayPriv* pr = init_array(ca.get(), nullptr, (int64_t)rows);
+    auto new_buf = [&](ArrayPriv* owner, size_t bytes) -> uint8_t* {
+      owner->own.emplace_back(new uint8_t[bytes ? bytes : 1]);
+      return owner->own.back().get();
+    };
+    // validity
+    int64_t nulls = 0;
+    const void* vptr = nullptr;
+    if (c0.fd.nullable) {
+      uint8_t* vb = new_buf(pr, (rows + 7) / 8);
+      memset(vb, 0, (rows + 7) / 8);
+      uint64_t o = 0;
+      for (auto& pc : pieces) {
+        const Column& col = pc.res->cols[c];
+        const uint64_t r0 = pc.res->batch_row0(pc.b), nr = pc.res->batch_rows(pc.b);
+        for (uint64_t i = 0; i < nr; i++, o++) {
+          const uint64_t sidx = r0 + i;
+          const bool v = !col.h_valid.p || ((col.h_valid.p[sidx >> 3] >> (sidx & 7)) & 1);
+          if (v) vb[o >> 3] |= (uint8_t)(1u << (o & 7)); else nulls++;
+        }
+      }
+      if (nulls) vptr = vb;
+    }
+    ca->null_count = nulls;
+    pr->buffers.push_back(vptr);
+    if (c0.is_var() || c0.is_list()) {
+      const uint32_t eb = c0.is_list() ? c0.list_elem_bytes() : 1;
+      uint64_t total = 0;
+      for (auto& pc : pieces) {
+        const Column& col = pc.res->cols[c];
+        const int32_t* off = (const int32_t*)(col.h_off32.p + pc.b * ((uint64_t)pc.res->batch_size + 1) * 4);
+        total += (uint64_t)off[pc.res->batch_rows(pc.b)];
+      }
+      int32_t* ob = (int32_t*)new_buf(pr, (rows + 1) * 4);
+      uint8_t* vals = new_buf(pr, total * eb);
+      uint64_t o = 0, acc = 0;
+      for (auto& pc : pieces) {
+        const Column& col = pc.res->cols[c];
+        const uint64_t nr = pc.res->batch_rows(pc.b);
+        const int32_t* off = (const int32_t*)(col.h_off32.p + pc.b * ((uint64_t)pc.res->batch_size + 1) * 4);
+        for (uint64_t i = 0; i < nr; i++) ob[o++] = (int32_t)(acc + (uint64_t)off[i]);
+        const uint64_t len = (uint64_t)off[nr];
+        if (len) memcpy(vals + acc * eb, col.h_values.p + col.h_batch_base[pc.b] * eb, len * eb);
+        acc += len;
+      }
+      ob[o] = (int32_t)acc;
+      pr->buffers.push_back(ob);
+      if (c0.is_var()) {
+        pr->buffers.push_back(vals);
+      } else {
+        std::unique_ptr<ArrowArray> item(new ArrowArray);
+        ArrayPriv* ip = init_array(item.get(), nullptr, (int64_t)acc);
+        ip->buffers.push_back(nullptr);
+        ip->buffers.push_back(vals);
+        finish_array(item.get());
+        pr->children.push_back(item.get());
+        pr->owned.push_back(std::move(item));
+      }
+    } else {
+      uint8_t* vals = new_buf(pr, rows * 4);
+      uint64_t o = 0;
+      for (auto& pc : pieces) {
+        const Column& col = pc.res->cols[c];
+        const uint64_t r0 = pc.res->batch_row0(pc.b), nr = pc.res->batch_rows(pc.b);
+        memcpy(vals + o * 4, col.h_values.p + r0 * 4, nr * 4);
+        o += nr;
+      }
+      pr->buffers.push_back(vals);
+    }
+    finish_array(ca.get());
+    top->children.push_back(ca.get());
+    top->owned.push_back(std::move(ca));
+  }
+  finish_array(out);
+}
+
+// SendableRecordBatchStream: batches of exactly batch_size rows (the last one short) cut out of the chunk results of
+// a producer.  While the consumer works through chunk k the producer has already run chunk k + 1 and chunk k's D2H has
+// been in flight since before that.
+struct Stream {
+  Provider* prov = nullptr;
+  std::unique_ptr<BamExecState> exec;   // BAM: chunk producer; null for a FASTQ stream (one result) or once exhausted
+  std::shared_ptr<Result> cur, ahead;
+  bool started = false, on_host = true;
+  uint64_t cur_batch = 0;
+  std::vector<Piece> pending;           // whole device batches that do not fill a batch yet
+  uint64_t pending_rows = 0;
+  std::vector<std::shared_ptr<Result>> device_results;  // execute_device: the chunks stay in HBM until the stream is closed
+  bioscan_scan_stats stats{};
+
+  bool fetch() {
+    if (!exec) return false;
+    if (!started) { ahead = exec->next_chunk(); started = true; }
+    if (!ahead) { exec.reset(); return false; }
+    cur = ahead;
+    cur_batch = 0;
+    ahead = exec->next_chunk();  // the next chunk's kernels run while `cur` is still being copied to the host
+    finish_copy(*cur);
+    return true;
+  }
+  // false = end of stream
+  bool next(ArrowArray* out) {
+    for (;;) {
+      if (cur) {
+        const uint64_t nb = cur->n_batches(), bs = cur->batch_size;
+        while (cur_batch < nb) {
+          const uint64_t b = cur_batch++;
+          const uint64_t rows = cur->batch_rows(b);
+          if (rows == bs && pending.empty()) { export_batch(cur, b, out); return true; }
+          // the head batch completes what earlier chunks left over; a short last batch waits for the next chunk
+          pending.push_back(Piece{cur, b});
+          pending_rows += rows;
+          if (pending_rows == bs) { flush(out); return true; }
+        }
+        cur.reset();
+      }
+      if (!fetch()) {
+        if (pending_rows) { flush(out); return true; }
+        return false;
+      }
+    }
+  }
+  void flush(ArrowArray* out) {
+    export_pieces(pending, out);
+    pending.clear();
+    pending_rows = 0;
+  }
+};
 
 // -------------------------------------------------------------------------------------------------
 // schema determination (table_provider.rs:42-140, 447-505)
@@ -1434,6 +1686,7 @@ int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_
   p.device = o.device_id;
   p.zero_based = o.coordinate_system_zero_based != 0;
   p.binary_cigar = o.binary_cigar != 0;
+  p.chunk_members = o.chunk_members > 0 ? (uint32_t)o.chunk_members : 0;
   if (o.tag_fields) {
     p.has_tag_fields = true;
     for (int i = 0; i < o.n_tag_fields; i++) p.tag_fields.push_back(o.tag_fields[i]);
@@ -1763,10 +2016,23 @@ static int execute_impl(const bioscan_plan* plan, int32_t partition, int32_t bat
   if (partition < 0 || partition >= plan->pl.n_partitions()) throw Error("partition index out of range");
   if (batch_size <= 0) throw Error("batch_size must be positive");
   std::unique_ptr<bioscan_stream> bs(new bioscan_stream);
-  bs->s.prov = plan->pl.prov;
-  bs->s.res = plan->pl.prov->kind == 1 ? run_partition_fastq(plan->pl, partition, (uint32_t)batch_size, !device_only)
-                                       : run_partition(plan->pl, partition, (uint32_t)batch_size, device_only, !device_only);
-  if (stats) *stats = bs->s.res->stats;
+  Stream& sm = bs->s;
+  sm.prov = plan->pl.prov;
+  sm.on_host = !device_only;
+  if (plan->pl.prov->kind == 1) {
+    sm.cur = run_partition_fastq(plan->pl, partition, (uint32_t)batch_size, !device_only);
+    sm.stats = sm.cur->stats;
+    if (device_only) { sm.device_results.push_back(sm.cur); sm.cur.reset(); }
+  } else {
+    sm.exec.reset(new BamExecState(plan->pl, partition, (uint32_t)batch_size, !device_only));
+    if (device_only) {
+      // the whole partition now, every chunk's Arrow buffers left in HBM
+      while (auto r = sm.exec->next_chunk()) sm.device_results.push_back(std::move(r));
+      sm.stats = sm.exec->total;
+      sm.exec.reset();
+    }
+  }
+  if (stats) *stats = sm.stats;
   *out = bs.release();
   API_END
 }
@@ -1785,14 +2051,8 @@ int bioscan_next(bioscan_stream* s, struct ArrowArray* out, int32_t* has_batch) 
     return 0;
   }
   Stream& st = s->s;
-  if (!st.res->on_host) throw Error("stream was executed device-only; no host batches to export");
-  if (st.next >= st.res->n_batches()) {
-    *has_batch = 0;
-    return 0;
-  }
-  export_batch(st.res, st.next, out);
-  st.next++;
-  *has_batch = 1;
+  if (!st.on_host) throw Error("stream was executed device-only; no host batches to export");
+  *has_batch = st.next(out) ? 1 : 0;
   API_END
 }
 

@@ -8,6 +8,7 @@ namespace bioscan {
 
 constexpr uint64_t SEG_NONE = ~0ull;       // segment has no record start
 constexpr uint64_t SEG_BAD = ~0ull - 1;    // walk ran into an impossible block_size
+constexpr uint64_t SEG_PARTIAL = 1ull << 62;  // | start of a record that runs past the end of the chunk (see k_seg_walk)
 constexpr uint32_t SEG_BYTES = 65536;      // record-chain segment size (bytes of inflated stream)
 
 // per-block inflate status codes (0 = ok)
@@ -56,7 +57,7 @@ struct ChainBuffers {
 };
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref,
                       ChainBuffers cb, hipStream_t st);
-void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, hipStream_t st);
+void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, int allow_partial, hipStream_t st);
 void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st);
 void launch_last_exit(const uint64_t* exit_, uint64_t nseg, unsigned long long* res, hipStream_t st);
 void launch_first_bad_status(const uint32_t* status, uint32_t n, uint32_t* res, hipStream_t st);
@@ -112,8 +113,8 @@ struct RowOverride {  // indexed-path overrides (physical_exec.rs:1078-1080, 120
 void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, CoreCols c,
                           const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
                           RowOverride ov, uint32_t* err, hipStream_t st);
-void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, int32_t* off32, hipStream_t st);
-void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint64_t* base, hipStream_t st);
+void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, uint32_t phase, int32_t* off32, hipStream_t st);
+void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint32_t phase, uint64_t* base, hipStream_t st);
 void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n,
                           const uint64_t* off_name, uint8_t* d_name,
                           const uint64_t* off_chrom, uint8_t* d_chrom,

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(WAVE) void k_seg_guess(const uint8_t* __restrict__ 
   if (lane == 0) entry[s] = res;
 }
 
-__global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty) {
+__global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, int allow_partial) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nseg) return;
   if (only_dirty && !cb.dirty[s]) return;
@@ -205,9 +205,13 @@ __global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
   if (p != SEG_NONE) {
     ex = p;
     while (ex < E) {
-      if (ex + 4 > ulen) { ex = SEG_BAD; break; }
+      // allow_partial: the buffer is one chunk of a longer stream; a record that runs past its end belongs to the next
+      // chunk (the caller carries its bytes over).  SEG_PARTIAL | start is larger than any segment end, so every later
+      // segment is expected to hold no record start, exactly as behind a record that covers them.
+      if (ex + 4 > ulen) { ex = allow_partial ? (SEG_PARTIAL | ex) : SEG_BAD; break; }
       int32_t bs = ld_i32(u + ex);
-      if (bs < 32 || ex + 4 + (uint64_t)bs > ulen) { ex = SEG_BAD; break; }
+      if (bs < 32) { ex = SEG_BAD; break; }
+      if (ex + 4 + (uint64_t)bs > ulen) { ex = allow_partial ? (SEG_PARTIAL | ex) : SEG_BAD; break; }
       ex += 4 + (uint64_t)bs;
       cnt++;
     }
@@ -258,7 +262,7 @@ __global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
   }
   uint64_t o = base[s];
   bool bad = false;
-  while (p < E) {
+  for (uint32_t c = cb.count[s]; c > 0; c--) {  // the complete records the walk counted (a partial tail record is not one)
     rec_off[o++] = p;
     // Every later kernel trusts l_read_name / n_cigar_op / l_seq: check once, here, that the variable-length fields fit
     // inside block_size (noodles fails such a record with an I/O error; a CRC-valid member can still carry one).
@@ -275,8 +279,8 @@ __global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref, ChainBuffers cb, hipStream_t st) {
   hipLaunchKernelGGL(k_seg_guess, dim3((uint32_t)nseg), dim3(WAVE), 0, st, u, ulen, first_rec, nseg, n_ref, cb.entry);
 }
-void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, hipStream_t st) {
-  hipLaunchKernelGGL(k_seg_walk, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, only_dirty);
+void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, int allow_partial, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_walk, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, only_dirty, allow_partial);
 }
 void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st) {
   hipLaunchKernelGGL(k_seg_verify, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, ulen, first_rec, nseg, cb);
@@ -547,32 +551,35 @@ void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0,
                      n_ref, zero_based, binary_cigar, ov, err);
 }
 
-// per-batch int32 offsets: off32[b*(bs+1) + r] = off64[b*bs + r] - off64[b*bs]
-__global__ void k_batch_offsets(const uint64_t* __restrict__ off64, uint64_t n_rows, uint32_t bs, int32_t* __restrict__ off32) {
+// per-batch int32 offsets of a chunk of rows whose first `phase` batch slots were filled by the previous chunk: batch b
+// covers rows [max(0, b*bs - phase), (b+1)*bs - phase) of the chunk, off32[b*(bs+1) + j] = off64[start_b + j] - off64[start_b]
+__device__ __forceinline__ uint64_t batch_start_row(uint64_t b, uint32_t bs, uint32_t phase) { return b ? b * bs - phase : 0; }
+__global__ void k_batch_offsets(const uint64_t* __restrict__ off64, uint64_t n_rows, uint32_t bs, uint32_t phase, int32_t* __restrict__ off32) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t nb = (n_rows + bs - 1) / bs;
+  const uint64_t nb = (n_rows + phase + bs - 1) / bs;
   const uint64_t per = (uint64_t)bs + 1;
   if (t >= nb * per) return;
   const uint64_t b = t / per, r = t % per;
-  uint64_t row = b * bs + r;
+  const uint64_t start = batch_start_row(b, bs, phase);
+  uint64_t row = start + r;
   if (row > n_rows) row = n_rows;
-  off32[t] = (int32_t)(off64[row] - off64[b * bs]);
+  off32[t] = (int32_t)(off64[row] - off64[start]);
 }
-void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, int32_t* off32, hipStream_t st) {
+void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, uint32_t phase, int32_t* off32, hipStream_t st) {
   if (!n_rows) return;
-  uint64_t nb = (n_rows + batch_size - 1) / batch_size;
+  uint64_t nb = (n_rows + phase + batch_size - 1) / batch_size;
   uint64_t tot = nb * ((uint64_t)batch_size + 1);
-  hipLaunchKernelGGL(k_batch_offsets, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, off64, n_rows, batch_size, off32);
+  hipLaunchKernelGGL(k_batch_offsets, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, st, off64, n_rows, batch_size, phase, off32);
 }
 
-// base[b] = off64[b * bs]: first byte / element of every batch (host export builds zero-copy windows from it)
-__global__ void k_batch_bases(const uint64_t* __restrict__ off64, uint64_t nb, uint32_t bs, uint64_t* __restrict__ base) {
+// base[b] = off64[first row of batch b]: first byte / element of every batch (host export builds zero-copy windows from it)
+__global__ void k_batch_bases(const uint64_t* __restrict__ off64, uint64_t nb, uint32_t bs, uint32_t phase, uint64_t* __restrict__ base) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) base[b] = off64[b * bs];
+  if (b < nb) base[b] = off64[batch_start_row(b, bs, phase)];
 }
-void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint64_t* base, hipStream_t st) {
+void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint32_t phase, uint64_t* base, hipStream_t st) {
   if (!nb) return;
-  hipLaunchKernelGGL(k_batch_bases, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, st, off64, nb, bs, base);
+  hipLaunchKernelGGL(k_batch_bases, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, st, off64, nb, bs, phase, base);
 }
 
 // =================================================================================================

@@ -32,7 +32,8 @@ class _Options(C.Structure):
     _fields_ = [("coordinate_system_zero_based", C.c_int32), ("tag_fields", C.POINTER(C.c_char_p)),
                 ("n_tag_fields", C.c_int32), ("binary_cigar", C.c_int32), ("infer_tag_types", C.c_int32),
                 ("infer_tag_sample_size", C.c_int32), ("tag_type_hints", C.POINTER(C.c_char_p)),
-                ("n_tag_type_hints", C.c_int32), ("index_path", C.c_char_p), ("device_id", C.c_int32)]
+                ("n_tag_type_hints", C.c_int32), ("index_path", C.c_char_p), ("device_id", C.c_int32),
+                ("chunk_members", C.c_int32)]
 
 
 class _Literal(C.Structure):
@@ -223,7 +224,7 @@ class BamTableProvider:
     def __init__(self, file_path: str, object_storage_options=None, coordinate_system_zero_based: bool = True,
                  tag_fields: Optional[Sequence[str]] = None, binary_cigar: bool = False, infer_tag_types: bool = True,
                  infer_tag_sample_size: int = 100, tag_type_hints: Optional[Sequence[str]] = None,
-                 device_id: int = 0, index_path: Optional[str] = None):
+                 device_id: int = 0, index_path: Optional[str] = None, chunk_members: int = 0):
         lib = load_library()
         o = _Options()
         lib.bioscan_bam_options_default(C.byref(o))
@@ -243,6 +244,7 @@ class BamTableProvider:
         if index_path is not None:
             o.index_path = index_path.encode()
         o.device_id = device_id
+        o.chunk_members = chunk_members  # BGZF members per pipeline chunk of a stream (0 = default)
         self._h = C.c_void_p()
         _check(lib.bioscan_bam_open(file_path.encode(), C.byref(o), C.byref(self._h)))
         self.file_path = file_path

@@ -46,6 +46,8 @@ typedef struct bioscan_bam_options {
   int32_t n_tag_type_hints;
   const char* index_path;
   int32_t device_id;                    /* HIP device ordinal this provider's scans run on */
+  int32_t chunk_members;                /* BGZF members per pipeline chunk of a stream (bounds the HBM and host memory of
+                                           one execute); 0 = default (16384, or BIOSCAN_CHUNK_MEMBERS) */
 } bioscan_bam_options;
 
 void bioscan_bam_options_default(bioscan_bam_options* o);
