@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 DEFAULT_BLOCKS = 655360  # config 2: ~10 GiB compressed BGZF-BAM
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
+K1_NAME = "k_bgzf_inflate_v3"
 
 
 COLL_DEVICE = "cuda"  # where the bench's own collectives (barrier, MAX of times, SUM of counts) live
@@ -104,7 +105,7 @@ def bench_fastq(args, pkg, rank, local_rank, world, torch, dist):
             "decoded_GB_s": round(ubytes / per_step / 1e9, 3),
             "stage_ms": {"inflate": round(st["ms_inflate"], 3), "crc32": round(st["ms_crc"], 3),
                          "newline_index": round(st["ms_chain"], 3), "extract": round(st["ms_extract"], 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate_v2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": K1_NAME, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
             "cpu_baseline": cpu,
             "reference_published": {"source": "openspec/changes/refactor-single-thread-partition-reads/design.md:29-36",
@@ -284,6 +285,7 @@ def main():
     ap.add_argument("--projection", default="*", help="'*' (12 core columns), 'chrom,start' or 'count'")
     ap.add_argument("--cpu-sample-blocks", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-stream (D2H-inclusive) leg")
     ap.add_argument("--keep-file", action="store_true")
     ap.add_argument("--lines", type=int, default=0, help="vcf-*: number of VCF lines (default 60 M sites / 200 k multi-sample)")
     ap.add_argument("--samples", type=int, default=1000, help="vcf-samples: number of samples")
@@ -437,43 +439,75 @@ def main():
         tot_rows, tot_u, tot_c, tot_a = (float(stats["n_rows"]), float(stats["inflated_bytes"]),
                                          float(stats["compressed_bytes"]), float(stats["arrow_bytes"]))
 
+    def k1_source_hash():
+        import hashlib
+        with open(os.path.join(ROOT, "datafusion-bio-formats_amd", "csrc", "inflate_v3.hip"), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+
     def pmc_traffic_per_member():
-        """HBM bytes per BGZF member of K1 from the committed rocprofv3 PMC passes (separate
-        FETCH_SIZE / WRITE_SIZE runs of this bench at 65 536 members, values in KiB as reported)."""
+        """HBM bytes per BGZF member of K1 from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs
+        of this bench at 65 536 members, values in KiB as reported; tools/profile_k1.sh).  The passes are offline: they
+        are only used when profiles/rNN/k1_pmc_source.sha256 names the K1 source this library was built from, so the
+        figure can never describe an older kernel."""
         import csv
         import glob
+        stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k1_pmc_source.sha256")))
+        if not stamps or open(stamps[-1]).read().split()[0] != k1_source_hash():
+            return None
+        d = os.path.dirname(stamps[-1])
         tot = 0.0
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"v2_pmc_{c}_65536blocks.csv")))
-            if not fs:
+            f = os.path.join(d, f"k1_pmc_{c}_65536blocks.csv")
+            if not os.path.exists(f):
                 return None
-            rows = [r for r in csv.DictReader(open(fs[-1])) if "k_bgzf_inflate_v2" in r["Kernel_Name"] and int(r["Grid_Size"]) > 6400]
+            rows = [r for r in csv.DictReader(open(f)) if K1_NAME in r["Kernel_Name"] and int(r["Grid_Size"]) > 6400]
             if not rows:
                 return None
             tot += sum(float(r["Counter_Value"]) for r in rows) / len(rows) * 1024.0
         return tot / 65536.0
+
+    # ---- end to end (rank 0 at N = 1): file resident in HBM -> Arrow buffers in host memory, through the chunk pipeline
+    #      (D2H of chunk k overlapped with the kernels of chunk k + 1); never part of `value` ----
+    e2e = None
+    if rank == 0 and world == 1 and args.mode == "sequential" and not args.no_end_to_end:
+        runs = [plan.execute_drain(0, args.batch_size) for _ in range(2)]  # the first run also pins the host blocks
+        r = runs[-1]
+        if int(r["n_rows"]) != int(meta["n_records"]):
+            raise SystemExit(f"end-to-end stream returned {r['n_rows']} rows, the generator wrote {meta['n_records']} records")
+        e2e = {"Mrec_s": round(r["n_rows"] / r["seconds"] / 1e6, 3), "seconds": round(r["seconds"], 3),
+               "link_GB_s": round(float(stats["arrow_bytes"]) / r["seconds"] / 1e9, 3),
+               "ms_to_first_batch": round(r["seconds_to_first_batch"] * 1e3, 2), "n_batches": r["n_batches"],
+               "first_run_seconds": round(runs[0]["seconds"], 3),
+               "what": "bioscan_execute + bioscan_next until end of stream, every batch released at once; compressed file resident in "
+                       "HBM, chunks of %d BGZF members, Arrow buffers copied D2H into recycled pinned blocks "
+                       "(BIOSCAN_HOST_POOL_GB=%s)" % (int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384)), os.environ.get("BIOSCAN_HOST_POOL_GB", "64"))}
 
     if cpu_sample is not None:
         # the C oracle (oracle/bioscan_oracle.c) on a bounded sample of the same file, host cores of this box
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
         data, sample_blocks = cpu_sample
-        cores = min(16, ncpu)
+        try:
+            nproc = len(os.sched_getaffinity(0))  # the cores this process may use (what `nproc` prints)
+        except AttributeError:
+            nproc = ncpu
+        cores = min(16, nproc)  # a one-GPU box's CPU share; the all-cores leg of SURVEY 8(d) is in threads_sweep
         st, _ = c_oracle.scan(data, True, cores, sample_blocks, (), (), build_columns=True, to_arrow=False)
-        # SURVEY 8(d): the same restatement at 1 and 8 threads (one thread per partition, like the reference's
-        # sync_batch_stream), on smaller samples so that the whole baseline stays within ~20 s
+        # the same restatement at 1 and 8 threads (one thread per partition, like the reference's sync_batch_stream),
+        # on smaller samples so that the whole baseline stays within ~20 s
         sweep = {}
-        for thr, blocks in ((1, min(sample_blocks, 8192)), (8, min(sample_blocks, 32768))):
-            if thr < cores:
+        for thr, blocks in ((1, min(sample_blocks, 8192)), (8, min(sample_blocks, 32768)), (nproc, sample_blocks)):
+            if thr != cores:
                 s2, _ = c_oracle.scan(data, True, thr, blocks, (), (), build_columns=True, to_arrow=False)
                 sweep[str(thr)] = {"Mrec_s": round(s2["n_rows"] / s2["seconds_total"] / 1e6, 3), "blocks": int(s2["n_blocks"]),
                                    "seconds": round(s2["seconds_total"], 3)}
         del data, cpu_sample
         cpu = {
             "value": round(st["n_rows"] / st["seconds_total"] / 1e6, 3), "unit": "Mrec/s", "cores": cores, "kind": "port",
+            "nproc": nproc, "os_cpu_count": ncpu,
             "sample": f"first {st['n_blocks']} BGZF blocks of the same file ({st['inflated_bytes'] / 1e9:.2f} GB inflated, "
                       f"{st['n_rows']} records), SELECT * core columns, "
-                      f"{'libdeflate' if st['used_libdeflate'] else 'zlib'} inflate, {cores} threads",
+                      f"{'libdeflate' if st['used_libdeflate'] else 'zlib'} inflate, {cores} threads (nproc of the box: {nproc}; its all-cores run is threads_sweep['{nproc}'])",
             "decoded_GB_s": round(st["inflated_bytes"] / st["seconds_total"] / 1e9, 3),
             "seconds": round(st["seconds_total"], 3),
             "threads_sweep": sweep,
@@ -481,6 +515,16 @@ def main():
 
     if rank == 0:
         per_step = elapsed / args.steps
+        gb = meta["compressed_bytes"] / 1e9
+        if world == 1:
+            workload = "BGZF-BAM full-table scan (config 2), synthetic 150bp paired reads, seed 42"
+        elif args.mode == "indexed":
+            workload = (f"BGZF-BAM scan of ONE {gb:.1f} GB file (config-2 generator, seed 42) by {world} GPUs: the BAI plan of "
+                        f"{8 * world} partitions sharded in order, every rank inflates only its partitions' members")
+        else:
+            workload = (f"config-5 style shards: {world} GPUs x {meta['n_blocks']} BGZF members ({gb:.1f} GB compressed each, "
+                        f"{gb * world:.1f} GB in total; config 5 names ~200 GB), config-2 generator with seed 42 + rank, "
+                        "one independent block-range shard per GPU")
         avg_infl = sum(infl_ms) / len(infl_ms)
         c, u = float(stats["compressed_bytes"]), float(stats["inflated_bytes"])
         achieved = (c + u) / (avg_infl * 1e-3) / 1e9  # GB/s, algorithmic bytes of K1 = C read + U written
@@ -488,7 +532,7 @@ def main():
             "metric": "bgzf_bam_full_scan_records_per_sec", "value": round(tot_rows / per_step / 1e6, 3), "unit": "Mrec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if args.mode == "indexed" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BGZF-BAM full-table scan (config 2), synthetic 150bp paired reads, seed 42",
+            "config": {"workload": workload,
                        "n_blocks_per_gpu": meta["n_blocks"], "compressed_bytes_per_gpu": meta["compressed_bytes"],
                        "inflated_bytes_per_gpu": meta["inflated_bytes"], "records_per_gpu": meta["n_records"],
                        "projection": args.projection, "batch_size": args.batch_size, "mode": args.mode, "deflate_level": meta["level"],
@@ -500,14 +544,17 @@ def main():
                          "extract": round(sum(extract_ms) / len(extract_ms), 3), "crc32": round(stats["ms_crc"], 3),
                          "keys": round(stats["ms_keys"], 3), "select": round(stats["ms_select"], 3),
                          "wall_last_step": round(stats["ms_wall"], 3), "chain_iterations": stats["chain_iterations"]},
-            "roofline": {"bound": "hbm", "kernel": "k_bgzf_inflate_v2", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": K1_NAME, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": (int(pmc_traffic_per_member() * stats["n_blocks"]) if pmc_traffic_per_member() else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01/v2_pmc_*), "
+                         "traffic_source": "offline PMC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/rNN/k1_pmc_*, "
+                                           "stamped with the sha256 of the K1 source they were collected on; null when that is not the source of this build), "
                                            "per-member average x members of this launch; FETCH_SIZE as reported (K1 issues dword / 8-byte / unaligned 16-byte loads, "
                                            "widths the guide calls uncalibrated; K2 in the same profile confirms the x2 rule for 16 B/lane reads)",
+                         "k1_source_sha256_16": k1_source_hash(),
                          "algorithmic_bytes_per_launch": int(c + u), "avg_launch_ms": round(avg_infl, 3)},
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
             "setup_s": {"generate": round(t_gen, 1), "load_and_h2d": round(t_load, 1)},
         }
         print(json.dumps(out))

@@ -1297,11 +1297,16 @@ static void finish_array(ArrowArray* a) {
   a->children = pr->children.empty() ? nullptr : pr->children.data();
 }
 static int64_t count_nulls(const uint8_t* bits, uint64_t bit0, uint64_t nbits) {
+  // set bits of [bit0, bit0 + nbits): ragged head and tail bit by bit, the aligned middle by 64-bit popcounts
   int64_t set = 0;
-  for (uint64_t i = 0; i < nbits; i++) {
-    uint64_t b = bit0 + i;
-    set += (bits[b >> 3] >> (b & 7)) & 1;
+  uint64_t i = bit0, end = bit0 + nbits;
+  for (; i < end && (i & 63); i++) set += (bits[i >> 3] >> (i & 7)) & 1;
+  for (; i + 64 <= end; i += 64) {
+    uint64_t w;
+    memcpy(&w, bits + (i >> 3), 8);
+    set += __builtin_popcountll(w);
   }
+  for (; i < end; i++) set += (bits[i >> 3] >> (i & 7)) & 1;
   return (int64_t)nbits - set;
 }
 

@@ -345,6 +345,33 @@ class BamExec:
         finally:
             lib.bioscan_stream_close(st)
 
+    def execute_drain(self, partition: int, batch_size: int = 8192) -> dict:
+        """Host stream, consumed the cheapest possible way: every exported batch is released at once (no pyarrow import).
+        Measures what a consumer that keeps up sees: file resident in HBM -> Arrow buffers in host memory."""
+        import time
+        lib = load_library()
+        st = C.c_void_p()
+        t0 = time.perf_counter()
+        _check(lib.bioscan_execute(self._h, partition, batch_size, C.byref(st)))
+        rel_t = C.CFUNCTYPE(None, C.c_void_p)
+        rows = batches = 0
+        t_first = None
+        try:
+            while True:
+                arr = _ArrowArray()
+                has = C.c_int32()
+                _check(lib.bioscan_next(st, C.addressof(arr), C.byref(has)))
+                if not has.value:
+                    break
+                if t_first is None:
+                    t_first = time.perf_counter() - t0
+                rows += arr.length
+                batches += 1
+                rel_t(arr.release)(C.addressof(arr))
+        finally:
+            lib.bioscan_stream_close(st)
+        return {"n_rows": rows, "n_batches": batches, "seconds": time.perf_counter() - t0, "seconds_to_first_batch": t_first or 0.0}
+
     def execute_device(self, partition: int, batch_size: int = 8192) -> dict:
         """Runs the whole partition on the GPU, leaves the Arrow buffers in HBM, returns stats."""
         lib = load_library()
