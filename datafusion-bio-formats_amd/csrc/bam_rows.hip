@@ -1,0 +1,422 @@
+// bam_rows.hip -- BAM record -> Arrow columns in two passes over the selected rows (gfx950).
+//
+// Replaces the per-record loop of the reference's BamExec (bio-format-bam/src/physical_exec.rs:408-573 sequential,
+// :1269-1356 indexed) and the Arrow builders it drives (bio-format-core/src/alignment_utils.rs:383-644) for the twelve
+// core columns.  A record's header is read once per pass and every Arrow byte is written exactly once:
+//   pass 1  one row per lane: fixed-width columns + validity words, and the SUM of every variable-length column's row
+//           lengths per tile of 256 rows (one u64 per column and tile -- no per-row length arrays, no offset arrays);
+//   scan    exclusive scan of the tile sums (one workgroup per column) -> tile bases and column totals;
+//   bases   first byte of every RecordBatch of the chunk (tile base + the rows of that tile in front of the batch);
+//   pass 2  one workgroup per tile: lengths are recomputed from the records, scanned inside the tile, the per-batch int32
+//           offsets are written straight from that scan, chrom / cigar / mate_chrom are written one row per lane, and
+//           name / sequence / quality by 16-lane groups from metadata staged in LDS (16-byte chunks, coalesced).
+// All integer / byte work: no MFMA.  Bound: HBM (the inflated records are read twice -- headers only in pass 1 -- and the
+// Arrow buffers written once).
+#include "kernels.h"
+
+namespace bioscan {
+
+#define WAVE 64
+
+struct __attribute__((packed, aligned(1))) br_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) br_u16 { uint16_t v; };
+struct __attribute__((packed, aligned(1))) br_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) br_u32x4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint32_t br_ld32(const uint8_t* p) { return ((const br_u32*)p)->v; }
+__device__ __forceinline__ uint32_t br_ld16(const uint8_t* p) { return (uint32_t)((const br_u16*)p)->v; }
+
+__device__ __forceinline__ uint32_t br_dec_digits(uint32_t v) {
+  uint32_t d = 1;
+  while (v >= 10) { v /= 10; d++; }
+  return d;
+}
+
+// what one record contributes to each variable-length column (k: 0 name, 1 chrom, 2 cigar, 3 mate_chrom, 4 sequence, 5 quality)
+struct RowInfo {
+  uint32_t len[6];
+  int32_t refid, nref, pos, npos, tlen;
+  uint32_t lrn, ncig, lseq, flag, mapq, end1;
+  bool bad_ref, bad_op, bad_rec;
+};
+
+// reads the 36-byte header (and, when the CIGAR string or `end` is wanted, the CIGAR ops) of the record at r
+__device__ __forceinline__ RowInfo row_info(const uint8_t* r, const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
+                                            int32_t binary_cigar, bool want_cigar, bool want_end) {
+  RowInfo ri;
+  ri.refid = (int32_t)br_ld32(r + 4); ri.pos = (int32_t)br_ld32(r + 8);
+  ri.lrn = r[12]; ri.mapq = r[13]; ri.ncig = br_ld16(r + 16); ri.flag = br_ld16(r + 18);
+  ri.lseq = br_ld32(r + 20); ri.nref = (int32_t)br_ld32(r + 24); ri.npos = (int32_t)br_ld32(r + 28); ri.tlen = (int32_t)br_ld32(r + 32);
+  // Every later step trusts l_read_name / n_cigar_op / l_seq: they must fit inside block_size (noodles fails such a record
+  // with an I/O error; a CRC-valid member can still carry one).  A bad record is treated as empty and reported.
+  ri.bad_rec = ri.lrn == 0 || (int32_t)ri.lseq < 0 ||
+               32ull + ri.lrn + 4ull * ri.ncig + (((uint64_t)ri.lseq + 1) >> 1) + (uint64_t)ri.lseq > (uint64_t)br_ld32(r);
+  if (ri.bad_rec) { ri.lrn = 1; ri.ncig = 0; ri.lseq = 0; }
+  ri.bad_ref = ri.refid >= n_ref || ri.nref >= n_ref;
+  if (ri.bad_ref) { ri.refid = -1; ri.nref = -1; }
+  ri.bad_op = false;
+  uint32_t clen = 0, span = 0;
+  if (want_cigar || want_end) {
+    const uint8_t* cg = r + 36 + ri.lrn;
+    for (uint32_t k = 0; k < ri.ncig; k++) {
+      const uint32_t v = br_ld32(cg + 4 * k);
+      const uint32_t op = v & 15u;
+      if (op > 8u) ri.bad_op = true;
+      if ((0x18Du >> op) & 1u) span += v >> 4;  // M(0) D(2) N(3) =(7) X(8) consume the reference
+      clen += br_dec_digits(v >> 4) + 1;
+    }
+  }
+  ri.end1 = ri.pos < 0 ? 0u : (uint32_t)ri.pos + span;  // 1-based inclusive end; 0 = None (noodles: start + span - 1)
+  ri.len[0] = ri.lrn ? ri.lrn - 1 : 0;  // noodles strips the trailing NUL; a missing name ("*\0") is rendered "*"
+  ri.len[1] = ri.refid >= 0 ? ref_name_len[ri.refid] : 0u;
+  ri.len[2] = binary_cigar ? 4 * ri.ncig : clen;
+  ri.len[3] = ri.nref >= 0 ? ref_name_len[ri.nref] : 0u;
+  ri.len[4] = ri.lseq;
+  ri.len[5] = ri.lseq;
+  return ri;
+}
+
+__device__ __forceinline__ uint64_t br_wave_incl_scan(uint64_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d, WAVE);
+    const uint32_t hi = __shfl_up((uint32_t)(v >> 32), d, WAVE);
+    if (lane >= d) v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+// ---- pass 1 -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass1(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                                              RowsCols c, const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
+                                                              int32_t zero_based, int32_t binary_cigar, uint64_t n_tiles,
+                                                              uint64_t* __restrict__ tile_sums, uint32_t* err) {
+  __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
+  const uint64_t i = (uint64_t)blockIdx.x * ROWS_TILE + threadIdx.x;
+  const bool act = i < n;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool want_cigar = (c.want >> 2) & 1u, want_end = c.end != nullptr || c.v_end != nullptr;
+  RowInfo ri{};
+  ri.refid = -1; ri.nref = -1; ri.pos = -1; ri.npos = -1;
+  if (act) {
+    ri = row_info(u + rows[i], ref_name_len, n_ref, binary_cigar, want_cigar, want_end);
+    if (ri.bad_rec) atomicExch(err, 8u);
+    else if (ri.bad_ref) atomicExch(err, 2u);
+    if (ri.bad_op && want_cigar && !binary_cigar) atomicExch(err, 3u);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; k++) ri.len[k] = 0;
+  }
+  const bool v_start = act && ri.pos >= 0;
+  const bool v_end = act && want_end && ri.end1 != 0;
+  const bool v_chrom = act && ri.refid >= 0;
+  const bool v_mchrom = act && ri.nref >= 0;
+  const bool v_mstart = act && ri.npos >= 0;
+  if (act) {
+    if (c.start) c.start[i] = v_start ? (zero_based ? (uint32_t)ri.pos : (uint32_t)ri.pos + 1u) : 0u;
+    if (c.end) c.end[i] = v_end ? ri.end1 : 0u;
+    if (c.flags) c.flags[i] = ri.flag;
+    if (c.mapq) c.mapq[i] = ri.mapq;
+    if (c.mate_start) c.mate_start[i] = v_mstart ? (zero_based ? (uint32_t)ri.npos : (uint32_t)ri.npos + 1u) : 0u;
+    if (c.tlen) c.tlen[i] = ri.tlen;
+  }
+  // validity words: one 64-bit word per wave (rows are wave-aligned)
+  const uint64_t word = i >> 6;
+  unsigned long long m;
+  if (c.v_chrom) { m = __ballot(v_chrom); if (lane == 0 && act) c.v_chrom[word] = m; }
+  if (c.v_start) { m = __ballot(v_start); if (lane == 0 && act) c.v_start[word] = m; }
+  if (c.v_end) { m = __ballot(v_end); if (lane == 0 && act) c.v_end[word] = m; }
+  if (c.v_mate_chrom) { m = __ballot(v_mchrom); if (lane == 0 && act) c.v_mate_chrom[word] = m; }
+  if (c.v_mate_start) { m = __ballot(v_mstart); if (lane == 0 && act) c.v_mate_start[word] = m; }
+  // tile sums of the projected variable-length columns
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (!((c.want >> k) & 1u)) continue;
+    uint64_t v = ri.len[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t lo = __shfl_down((uint32_t)v, d, WAVE);
+      const uint32_t hi = __shfl_down((uint32_t)(v >> 32), d, WAVE);
+      v += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) s_w[k][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && ((c.want >> threadIdx.x) & 1u)) {
+    uint64_t t = 0;
+    for (int q = 0; q < ROWS_TILE / WAVE; q++) t += s_w[threadIdx.x][q];
+    tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + blockIdx.x] = t;
+  }
+}
+
+// exclusive scan of one column's tile sums in place (one workgroup per column); entry n_tiles = the column's total
+__global__ __launch_bounds__(1024) void k_bam_tile_scan(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint32_t want) {
+  if (!((want >> blockIdx.x) & 1u)) return;
+  uint64_t* a = tile_sums + (uint64_t)blockIdx.x * (n_tiles + 1);
+  __shared__ uint64_t s_w[1024 / WAVE];
+  __shared__ uint64_t carry_s;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint64_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+    const uint64_t i = b0 + threadIdx.x;
+    const uint64_t v = i < n_tiles ? a[i] : 0;
+    const uint64_t inc = br_wave_incl_scan(v, lane);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+    for (int q = 0; q < 1024 / WAVE; q++) { if (q < w) base += s_w[q]; tot += s_w[q]; }
+    const uint64_t cy = carry_s;
+    if (i < n_tiles) a[i] = cy + base + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = cy + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a[n_tiles] = carry_s;
+}
+
+__device__ __forceinline__ uint64_t br_batch_start_row(uint64_t b, uint32_t bs, uint32_t phase) { return b ? b * bs - phase : 0; }
+
+// first byte of every batch: base of the tile that holds the batch's first row + the rows of that tile in front of it
+__global__ __launch_bounds__(ROWS_TILE) void k_bam_batch_bases(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                                               RowsCols c, const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
+                                                               int32_t binary_cigar, uint32_t bs, uint32_t phase,
+                                                               uint64_t n_tiles, const uint64_t* __restrict__ tile_sums) {
+  const uint32_t want = c.want;
+  __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
+  const uint64_t b = blockIdx.x;
+  const uint64_t s = br_batch_start_row(b, bs, phase);
+  const uint64_t tile = s / ROWS_TILE, part = s % ROWS_TILE;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t i = tile * ROWS_TILE + threadIdx.x;
+  RowInfo ri;
+#pragma unroll
+  for (int k = 0; k < 6; k++) ri.len[k] = 0;
+  if (threadIdx.x < part && i < n) ri = row_info(u + rows[i], ref_name_len, n_ref, binary_cigar, (want >> 2) & 1u, false);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (!((want >> k) & 1u)) continue;
+    uint64_t v = ri.len[k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t lo = __shfl_down((uint32_t)v, d, WAVE);
+      const uint32_t hi = __shfl_down((uint32_t)(v >> 32), d, WAVE);
+      v += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 0) s_w[k][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && ((want >> threadIdx.x) & 1u)) {
+    uint64_t t = tile < n_tiles ? tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + tile] : tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + n_tiles];
+    for (int q = 0; q < ROWS_TILE / WAVE; q++) t += s_w[threadIdx.x][q];
+    c.base[threadIdx.x][b] = t;
+  }
+}
+
+// ---- pass 2 -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t br_write_dec(uint8_t* d, uint32_t v) {
+  const uint32_t nd = br_dec_digits(v);
+  for (int k = (int)nd - 1; k >= 0; k--) { d[k] = (uint8_t)('0' + v % 10); v /= 10; }
+  return nd;
+}
+__device__ __forceinline__ uint32_t br_qual_swar(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x21212121u) ^ (w & 0x80808080u); }  // (q + 33) mod 256 per byte
+
+__global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
+                                                              RowsCols c, const uint8_t* __restrict__ ref_names,
+                                                              const uint32_t* __restrict__ ref_name_off, const uint32_t* __restrict__ ref_name_len,
+                                                              int32_t n_ref, int32_t binary_cigar, uint32_t bs, uint32_t phase,
+                                                              uint64_t n_tiles, const uint64_t* __restrict__ tile_sums, uint32_t* qual_wide) {
+  __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
+  __shared__ uint64_t s_rec[ROWS_TILE], s_on[ROWS_TILE], s_os[ROWS_TILE], s_oq[ROWS_TILE];
+  __shared__ uint32_t s_meta[ROWS_TILE], s_lseq[ROWS_TILE];
+  __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first), little-endian u16
+  {
+    const char* Lt = "=ACMGRSVTWYHKDBN";
+    s_pair[threadIdx.x] = (uint16_t)((uint8_t)Lt[threadIdx.x >> 4] | ((uint16_t)(uint8_t)Lt[threadIdx.x & 15] << 8));
+  }
+  const uint64_t tile = blockIdx.x;
+  const uint64_t i = tile * ROWS_TILE + threadIdx.x;
+  const bool act = i < n;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool want_cigar = (c.want >> 2) & 1u;
+  RowInfo ri{};
+  uint64_t ro = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) ri.len[k] = 0;
+  if (act) {
+    ro = rows[i];
+    ri = row_info(u + ro, ref_name_len, n_ref, binary_cigar, want_cigar, false);
+  }
+  // exclusive scan of every projected column inside the tile
+  uint64_t off[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    off[k] = 0;
+    if (!((c.want >> k) & 1u)) continue;
+    const uint64_t inc = br_wave_incl_scan((uint64_t)ri.len[k], lane);
+    if (lane == 63) s_w[k][w] = inc;
+    off[k] = inc - ri.len[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (!((c.want >> k) & 1u)) continue;
+    uint64_t base = tile_sums[(uint64_t)k * (n_tiles + 1) + tile];
+    for (int q = 0; q < w; q++) base += s_w[k][q];
+    off[k] += base;
+  }
+  if (act) {
+    // per-batch int32 offsets: entry j of batch b, and the closing entry when this is the batch's (or the chunk's) last row
+    const uint32_t v = (uint32_t)i + phase;
+    const uint32_t b = v / bs;
+    const uint64_t start = br_batch_start_row(b, bs, phase);
+    const uint64_t j = i - start;
+    const bool closes = (v + 1) % bs == 0 || i + 1 == n;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      if (!((c.want >> k) & 1u)) continue;
+      const uint64_t bb = c.base[k][b];
+      int32_t* o32 = c.off32[k] + (uint64_t)b * ((uint64_t)bs + 1);
+      o32[j] = (int32_t)(off[k] - bb);
+      if (closes) o32[j + 1] = (int32_t)(off[k] + ri.len[k] - bb);
+    }
+    // chrom / mate_chrom / cigar: one row per lane
+    if (c.val[1] && ri.refid >= 0) {
+      uint8_t* d = c.val[1] + off[1];
+      const uint32_t a = ref_name_off[ri.refid], e = ref_name_off[ri.refid + 1];
+      for (uint32_t k = a; k < e; k++) d[k - a] = ref_names[k];
+    }
+    if (c.val[3] && ri.nref >= 0) {
+      uint8_t* d = c.val[3] + off[3];
+      const uint32_t a = ref_name_off[ri.nref], e = ref_name_off[ri.nref + 1];
+      for (uint32_t k = a; k < e; k++) d[k - a] = ref_names[k];
+    }
+    if (c.val[2]) {
+      const uint8_t* cg = u + ro + 36 + ri.lrn;
+      uint8_t* d = c.val[2] + off[2];
+      if (binary_cigar) {
+        for (uint32_t k = 0; k < 4 * ri.ncig; k++) d[k] = cg[k];
+      } else {
+        const char ops[] = "MIDNSHP=X???????";
+        for (uint32_t k = 0; k < ri.ncig; k++) {
+          const uint32_t v2 = br_ld32(cg + 4 * k);
+          d += br_write_dec(d, v2 >> 4);
+          *d++ = (uint8_t)ops[v2 & 15u];
+        }
+      }
+    }
+  }
+  s_rec[threadIdx.x] = ro;
+  s_meta[threadIdx.x] = ri.lrn | (ri.ncig << 8);
+  s_lseq[threadIdx.x] = act ? ri.lseq : 0u;
+  s_on[threadIdx.x] = off[0]; s_os[threadIdx.x] = off[4]; s_oq[threadIdx.x] = off[5];
+  __syncthreads();
+  if (!c.val[0] && !c.val[4] && !c.val[5]) return;
+  // name / sequence / quality: four 16-lane groups per wave, each on its own row; 16 rows of the tile in flight
+  const int g = lane >> 4, sl = lane & 15;
+  const uint32_t nrow = (uint32_t)((n - tile * ROWS_TILE) < ROWS_TILE ? (n - tile * ROWS_TILE) : ROWS_TILE);
+  uint8_t* const d_name = c.val[0];
+  uint8_t* const d_seq = c.val[4];
+  uint8_t* const d_qual = c.val[5];
+  bool wide = false;
+  for (uint32_t it = 0; it < ROWS_TILE / 16; it++) {
+    const uint32_t k = it * 16 + (uint32_t)w * 4 + (uint32_t)g;
+    if (k >= nrow) continue;
+    const uint32_t meta = s_meta[k], lseq = s_lseq[k];
+    const uint32_t lrn = meta & 0xFFu, ncig = meta >> 8;
+    const uint64_t ono = s_on[k], oso = s_os[k], oqo = s_oq[k];
+    const uint8_t* np = u + s_rec[k] + 36;  // read_name starts 36 bytes into the record
+    const uint8_t* sp = np + lrn + 4ull * ncig;
+    const uint8_t* qp = sp + ((lseq + 1) >> 1);
+    // First 256 bytes of each segment: one 16-byte chunk per lane, all three loads issued before any store.  A partial
+    // last chunk is served by the (overlapping) 16 bytes that END at the segment's end, so no lane runs a byte loop unless
+    // the whole segment is shorter than 16 bytes.
+    const uint32_t c0 = (uint32_t)sl * 16;
+    const uint32_t ln = lrn ? lrn - 1 : 0;
+    const bool n_on = d_name && c0 < ln, s_on_ = d_seq && c0 < lseq, q_on = d_qual && c0 < lseq;
+    const uint32_t cn = (c0 + 16 <= ln || ln < 16) ? c0 : ln - 16;
+    const uint32_t cq = (c0 + 16 <= lseq || lseq < 16) ? c0 : lseq - 16;
+    const uint32_t cs = (c0 + 16 <= lseq || lseq < 16) ? c0 : ((lseq - 16) & ~1u);  // packed bytes start on even bases
+    const bool n_vec = n_on && ln >= 16, s_vec = s_on_ && lseq >= 16, q_vec = q_on && lseq >= 16;
+    br_u32x4 vn = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
+    uint64_t pk = 0;
+    if (n_vec) vn = *(const br_u32x4*)(np + cn);
+    if (s_vec) pk = ((const br_u64*)(sp + (cs >> 1)))->v;
+    if (q_vec) vq = *(const br_u32x4*)(qp + cq);
+    if (n_vec) *(br_u32x4*)(d_name + ono + cn) = vn;
+    else if (n_on) for (uint32_t j = c0; j < ln; j++) d_name[ono + j] = np[j];
+    if (s_vec) {
+      br_u32x4 v;
+      v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
+      v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
+      v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
+      v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
+      *(br_u32x4*)(d_seq + oso + cs) = v;
+      // odd-length tail: the vector ended one base early
+      if (cs != c0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
+    } else if (s_on_) {
+      for (uint32_t j = c0; j < lseq; j += 2) {
+        const uint16_t pr = s_pair[sp[j >> 1]];
+        d_seq[oso + j] = (uint8_t)pr;
+        if (j + 1 < lseq) d_seq[oso + j + 1] = (uint8_t)(pr >> 8);
+      }
+    }
+    if (q_vec) {
+      vq.x = br_qual_swar(vq.x); vq.y = br_qual_swar(vq.y); vq.z = br_qual_swar(vq.z); vq.w = br_qual_swar(vq.w);
+      wide = wide || ((vq.x | vq.y | vq.z | vq.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
+      *(br_u32x4*)(d_qual + oqo + cq) = vq;
+    } else if (q_on) {
+      for (uint32_t j = c0; j < lseq; j++) {
+        const uint32_t q = ((uint32_t)qp[j] + 33u) & 0xFFu;
+        wide = wide || q >= 128u;
+        d_qual[oqo + j] = (uint8_t)q;
+      }
+    }
+    // rows longer than 256 bytes per segment (long reads): remaining chunks, same scheme
+    if (d_name) for (uint32_t cc0 = c0 + 256; cc0 < ln; cc0 += 256) {
+      const uint32_t cc = cc0 + 16 <= ln ? cc0 : ln - 16;
+      *(br_u32x4*)(d_name + ono + cc) = *(const br_u32x4*)(np + cc);
+    }
+    if (d_seq) for (uint32_t cc0 = c0 + 256; cc0 < lseq; cc0 += 256) {
+      const uint32_t cc = cc0 + 16 <= lseq ? cc0 : ((lseq - 16) & ~1u);
+      const uint64_t p2 = ((const br_u64*)(sp + (cc >> 1)))->v;
+      br_u32x4 v;
+      v.x = (uint32_t)s_pair[p2 & 0xFF] | ((uint32_t)s_pair[(p2 >> 8) & 0xFF] << 16);
+      v.y = (uint32_t)s_pair[(p2 >> 16) & 0xFF] | ((uint32_t)s_pair[(p2 >> 24) & 0xFF] << 16);
+      v.z = (uint32_t)s_pair[(p2 >> 32) & 0xFF] | ((uint32_t)s_pair[(p2 >> 40) & 0xFF] << 16);
+      v.w = (uint32_t)s_pair[(p2 >> 48) & 0xFF] | ((uint32_t)s_pair[(p2 >> 56) & 0xFF] << 16);
+      *(br_u32x4*)(d_seq + oso + cc) = v;
+      if (cc != cc0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
+    }
+    if (d_qual) for (uint32_t cc0 = c0 + 256; cc0 < lseq; cc0 += 256) {
+      const uint32_t cc = cc0 + 16 <= lseq ? cc0 : lseq - 16;
+      br_u32x4 v = *(const br_u32x4*)(qp + cc);
+      v.x = br_qual_swar(v.x); v.y = br_qual_swar(v.y); v.z = br_qual_swar(v.z); v.w = br_qual_swar(v.w);
+      wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);
+      *(br_u32x4*)(d_qual + oqo + cc) = v;
+    }
+  }
+  if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
+}
+
+// ---- host wrappers ----------------------------------------------------------------------------------------------
+void launch_bam_rows_pass1(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint32_t* ref_name_len, int32_t n_ref,
+                           int32_t zero_based, int32_t binary_cigar, uint64_t* tile_sums, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
+  hipLaunchKernelGGL(k_bam_rows_pass1, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_name_len, n_ref, zero_based,
+                     binary_cigar, n_tiles, tile_sums, err);
+  if (c.want) hipLaunchKernelGGL(k_bam_tile_scan, dim3(6), dim3(1024), 0, st, tile_sums, n_tiles, c.want);
+}
+void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint8_t* ref_names,
+                           const uint32_t* ref_name_off, const uint32_t* ref_name_len, int32_t n_ref, int32_t binary_cigar,
+                           uint32_t batch_size, uint32_t phase, const uint64_t* tile_sums, uint32_t* qual_wide, hipStream_t st) {
+  if (!n || !c.want) return;
+  const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
+  const uint64_t nb = (n + phase + batch_size - 1) / batch_size;
+  hipLaunchKernelGGL(k_bam_batch_bases, dim3((uint32_t)nb), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_name_len, n_ref, binary_cigar,
+                     batch_size, phase, n_tiles, tile_sums);
+  hipLaunchKernelGGL(k_bam_rows_pass2, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_names, ref_name_off, ref_name_len,
+                     n_ref, binary_cigar, batch_size, phase, n_tiles, tile_sums, qual_wide);
+}
+
+}  // namespace bioscan

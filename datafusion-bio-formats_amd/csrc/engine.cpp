@@ -343,6 +343,7 @@ static void throw_extract_err(uint32_t e) {
     case 5: throw Error("BAM read error: duplicate optional field tag in one record");
     case 6: throw Error("Arrow error: tag value type mismatch");
     case 7: throw Error("Arrow error: tag value does not fit the column type");
+    case 8: throw Error("BAM read error: invalid record (variable-length fields exceed block_size)");
     default: throw Error("BAM read error: device error " + std::to_string(e));
   }
 }
@@ -517,7 +518,7 @@ static void start_copy_to_host(Result& res, hipStream_t st, hipStream_t copy_st)
   const uint64_t n = res.n_rows, nb = res.n_batches(), nwords = (n + 63) / 64;
   const uint32_t batch_size = res.batch_size;
   for (auto& col : res.cols)
-    if (col.d_off32.p && n) {
+    if (col.d_off32.p && n && !col.d_base.p) {  // (the two-pass extract has written the bases of the core columns already)
       col.d_base.alloc(nb);
       launch_batch_bases(col.d_off64.p, nb, batch_size, res.phase, col.d_base.p, st);
     }
@@ -728,7 +729,6 @@ struct BamExecState {
       uint32_t errf = 0;
       HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
-      if (errf == 2) throw Error("BAM read error: invalid record (variable-length fields exceed block_size)");
       const uint64_t lastv = lx[1];
       if (errf || lastv == SEG_BAD) throw Error("BAM read error: truncated or corrupt record (invalid block_size)");
       if (lastv != SEG_NONE && (lastv & SEG_PARTIAL)) end_of_records = lastv & ~SEG_PARTIAL;
@@ -752,8 +752,11 @@ struct BamExecState {
       RecKeys rk{k_refid.p, k_pos.p, k_end1.p, k_fm.p};
       StageTimer tk(st);
       tk.start();
-      launch_rec_keys(u, rec_off.p, n_rec, rk, st);
+      DevBuf<uint32_t> kerr(1);
+      HIP_CHECK(hipMemsetAsync(kerr.p, 0, 4, st));
+      launch_rec_keys(u, rec_off.p, n_rec, rk, kerr.p, st);
       s.ms_keys = tk.stop();
+      throw_extract_err(read_err(kerr, st));
       RowSelect sel = w.sel;
       bool any = true;
       if (sel.mode == 2) {
@@ -874,7 +877,8 @@ struct BamExecState {
     DevBuf<uint32_t> err(1);
     HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
     uint64_t arrow_bytes = 0;
-    CoreCols cc{};
+    if (n >= 0xFFFF0000ull) throw Error("chunk holds too many rows: lower chunk_members");
+    RowsCols rc{};
     auto fixed = [&](int idx) -> uint32_t* {
       if (core_col[idx] < 0) return nullptr;
       Column& col = res->cols[core_col[idx]];
@@ -889,22 +893,35 @@ struct BamExecState {
       arrow_bytes += nwords * 8;
       return col.d_valid.p;
     };
-    auto lens = [&](int idx) -> uint32_t* {
-      if (core_col[idx] < 0) return nullptr;
-      Column& col = res->cols[core_col[idx]];
-      col.d_len.alloc(n);
-      return col.d_len.p;
-    };
-    cc.start = fixed(2); cc.end = fixed(3); cc.flags = fixed(4); cc.mapq = fixed(6); cc.mate_start = fixed(8);
-    cc.tlen = (int32_t*)fixed(11);
-    cc.v_chrom = valid(1); cc.v_start = valid(2); cc.v_end = valid(3); cc.v_mate_chrom = valid(7); cc.v_mate_start = valid(8);
-    cc.len_name = lens(0); cc.len_chrom = lens(1); cc.len_cigar = lens(5); cc.len_mate_chrom = lens(7);
-    cc.len_seq = lens(9); cc.len_qual = lens(10);
-    RowOverride ov{};
-    launch_extract_fixed(u, rows, 0, n, cc, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
-                         p.binary_cigar ? 1 : 0, ov, err.p, st);
-    throw_extract_err(read_err(err, st));
-
+    rc.start = fixed(2); rc.end = fixed(3); rc.flags = fixed(4); rc.mapq = fixed(6); rc.mate_start = fixed(8);
+    rc.tlen = (int32_t*)fixed(11);
+    rc.v_chrom = valid(1); rc.v_start = valid(2); rc.v_end = valid(3); rc.v_mate_chrom = valid(7); rc.v_mate_start = valid(8);
+    const int var_idx[6] = {0, 1, 5, 7, 9, 10};  // name, chrom, cigar, mate_chrom, sequence, quality_scores
+    for (int k = 0; k < 6; k++) if (core_col[var_idx[k]] >= 0) rc.want |= 1u << k;
+    // pass 1: fixed columns, validity, tile sums of the variable-length columns (+ their scan)
+    const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
+    DevBuf<uint64_t> tile_sums(6 * (n_tiles + 1));
+    launch_bam_rows_pass1(u, rows, n, rc, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
+                          p.binary_cigar ? 1 : 0, tile_sums.p, err.p, st);
+    uint64_t totals[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 6; k++)
+      if ((rc.want >> k) & 1u) HIP_CHECK(hipMemcpyAsync(&totals[k], tile_sums.p + (uint64_t)k * (n_tiles + 1) + n_tiles, 8, hipMemcpyDeviceToHost, st));
+    throw_extract_err(read_err(err, st));  // synchronises: the totals are here as well
+    for (int k = 0; k < 6; k++) {
+      if (!((rc.want >> k) & 1u)) continue;
+      Column& col = res->cols[core_col[var_idx[k]]];
+      col.total_bytes = totals[k];
+      col.d_values.alloc(std::max<uint64_t>(totals[k], 1));
+      col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
+      col.d_base.alloc(nb);
+      rc.val[k] = col.d_values.p; rc.off32[k] = col.d_off32.p; rc.base[k] = col.d_base.p;
+      arrow_bytes += totals[k] + nb * ((uint64_t)batch_size + 1) * 4;
+    }
+    // pass 2: per-batch offsets + every variable-length byte
+    DevBuf<uint32_t> wide(1);
+    HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
+    launch_bam_rows_pass2(u, rows, n, rc, p.d_ref_names.p, p.d_ref_name_off.p, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(),
+                          p.binary_cigar ? 1 : 0, batch_size, phase, tile_sums.p, wide.p, st);
     DevBuf<uint64_t> tmp(scan_tmp_elems(n));
     auto finish_var = [&](Column& col, uint32_t elem_bytes) {
       col.d_off64.alloc(n + 1);
@@ -915,28 +932,18 @@ struct BamExecState {
       col.total_bytes = tot;
       col.d_values.alloc(std::max<uint64_t>(tot * elem_bytes, 1));
       col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
+      col.d_base.reset();  // start_copy_to_host derives the batch bases of such a column from its offsets
       launch_batch_offsets(col.d_off64.p, n, batch_size, phase, col.d_off32.p, st);
       arrow_bytes += tot * elem_bytes + nb * ((uint64_t)batch_size + 1) * 4;
     };
-    const int var_idx[6] = {0, 1, 5, 7, 9, 10};
-    for (int k : var_idx) if (core_col[k] >= 0) finish_var(res->cols[core_col[k]], 1);
-    auto off_of = [&](int idx) -> const uint64_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_off64.p : nullptr; };
-    auto dat_of = [&](int idx) -> uint8_t* { return core_col[idx] >= 0 ? res->cols[core_col[idx]].d_values.p : nullptr; };
-    // name rides with sequence / quality in the row-centric kernel; chrom, cigar, mate_chrom stay one row per lane
-    if (core_col[1] >= 0 || core_col[5] >= 0 || core_col[7] >= 0)
-      launch_scatter_small(u, rows, 0, n, nullptr, nullptr, off_of(1), dat_of(1), off_of(5), dat_of(5), off_of(7), dat_of(7),
-                           p.d_ref_names.p, p.d_ref_name_off.p, (int32_t)p.hdr.ref_names.size(), p.binary_cigar ? 1 : 0, ov, st);
-    DevBuf<uint32_t> wide(1);
-    HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    launch_scatter_seqqual_rows(u, rows, n, off_of(9), dat_of(9), off_of(10), dat_of(10), off_of(0), dat_of(0), wide.p, st);
     if (core_col[10] >= 0) {
       if (read_err(wide, st)) {
-        // exact path for qualities >= 95 (two-byte UTF-8 chars)
+        // exact path for qualities >= 95 (two-byte UTF-8 chars): the column is redone with its own length pass
         Column& col = res->cols[core_col[10]];
-        arrow_bytes -= col.total_bytes;
+        arrow_bytes -= col.total_bytes + nb * ((uint64_t)batch_size + 1) * 4;
+        col.d_len.alloc(n);
         launch_qual_wide_len(u, rows, 0, n, col.d_len.p, st);
         finish_var(col, 1);
-        arrow_bytes -= nb * ((uint64_t)batch_size + 1) * 4;
         launch_qual_wide_scatter(u, rows, n, col.d_off64.p, col.d_values.p, st);
       }
     }

@@ -71,7 +71,7 @@ struct RecKeys {
   int32_t* end1;     // 1-based inclusive end, 0 = None
   uint32_t* flag_mapq;  // flag | mapq << 16
 };
-void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, hipStream_t st);
+void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, uint32_t* err, hipStream_t st);  // err = 8: invalid record
 
 // ---- row selection ----------------------------------------------------------------------------
 // Residual filter program: conjunction of terms on numeric fields / chrom index.
@@ -99,36 +99,31 @@ void launch_find_first(const int32_t* refid, uint64_t n, uint64_t from, int32_t 
                        unsigned long long* result, hipStream_t st);
 void launch_lower_bound_u64(const uint64_t* arr, uint64_t n, uint64_t key, unsigned long long* result, hipStream_t st);
 
-// ---- K4-K7: field extract + Arrow scatter -----------------------------------------------------
-struct CoreCols {   // device pointers; nullptr = not projected
-  uint32_t* start; uint32_t* end; uint32_t* flags; uint32_t* mapq; uint32_t* mate_start; int32_t* tlen;
-  uint64_t* v_chrom; uint64_t* v_start; uint64_t* v_end; uint64_t* v_mate_chrom; uint64_t* v_mate_start;  // validity words
-  uint32_t* len_name; uint32_t* len_chrom; uint32_t* len_cigar; uint32_t* len_mate_chrom; uint32_t* len_seq; uint32_t* len_qual;
-};
-struct RowOverride {  // indexed-path overrides (physical_exec.rs:1078-1080, 1206-1208)
-  int32_t force_null_coords;   // start/end NULL
-  int32_t chrom_mode;          // 0 from record, 1 NULL, 2 fixed ref index
-  int32_t chrom_ref;
-};
-void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, CoreCols c,
-                          const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
-                          RowOverride ov, uint32_t* err, hipStream_t st);
+// ---- per-batch offsets of columns that keep an offset array (tags, wide qualities) ------------
 void launch_batch_offsets(const uint64_t* off64, uint64_t n_rows, uint32_t batch_size, uint32_t phase, int32_t* off32, hipStream_t st);
 void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint32_t phase, uint64_t* base, hipStream_t st);
-void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n,
-                          const uint64_t* off_name, uint8_t* d_name,
-                          const uint64_t* off_chrom, uint8_t* d_chrom,
-                          const uint64_t* off_cigar, uint8_t* d_cigar,
-                          const uint64_t* off_mate, uint8_t* d_mate,
-                          const uint8_t* ref_names, const uint32_t* ref_name_off, int32_t n_ref, int32_t binary_cigar,
-                          RowOverride ov, hipStream_t st);
-// name + sequence (4-bit -> ASCII) + quality (+33) of a row in one pass.  qual_wide: set to 1 when a quality byte maps to a
-// 2-byte UTF-8 char (q+33 >= 128): the caller re-runs the exact wide path.
-void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
-                                 const uint64_t* off_qual, uint8_t* d_qual, const uint64_t* off_name, uint8_t* d_name,
-                                 uint32_t* qual_wide, hipStream_t st);
+// exact path for quality bytes >= 95 (`char::from(q + 33)` is a two-byte UTF-8 char): own length pass + scatter
 void launch_qual_wide_len(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, uint32_t* len_qual, hipStream_t st);
 void launch_qual_wide_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off64, uint8_t* dst, hipStream_t st);
+
+// ---- bam_rows.hip: the twelve core columns in two passes (fixed columns + tile sums; offsets + scatter) ----------
+constexpr int ROWS_TILE = 256;
+struct RowsCols {   // device pointers; nullptr = not projected
+  uint32_t* start; uint32_t* end; uint32_t* flags; uint32_t* mapq; uint32_t* mate_start; int32_t* tlen;
+  uint64_t* v_chrom; uint64_t* v_start; uint64_t* v_end; uint64_t* v_mate_chrom; uint64_t* v_mate_start;  // validity words
+  // variable-length columns k: 0 name, 1 chrom, 2 cigar, 3 mate_chrom, 4 sequence, 5 quality_scores
+  uint8_t* val[6];     // values (pass 2)
+  int32_t* off32[6];   // per-batch int32 offsets [n_batches][batch_size + 1] (pass 2)
+  uint64_t* base[6];   // first byte of every batch [n_batches] (pass 2)
+  uint32_t want;       // bit k: column k is projected
+};
+// pass 1 + the scan of its tile sums: tile_sums holds 6 x (n_tiles + 1) u64; afterwards entry [k][t] is the first byte of
+// tile t in column k and entry [k][n_tiles] the column's total
+void launch_bam_rows_pass1(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint32_t* ref_name_len, int32_t n_ref,
+                           int32_t zero_based, int32_t binary_cigar, uint64_t* tile_sums, uint32_t* err, hipStream_t st);
+void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint8_t* ref_names,
+                           const uint32_t* ref_name_off, const uint32_t* ref_name_len, int32_t n_ref, int32_t binary_cigar,
+                           uint32_t batch_size, uint32_t phase, const uint64_t* tile_sums, uint32_t* qual_wide, hipStream_t st);
 
 // ---- tags ---------------------------------------------------------------------------------------
 // loc[t*n + i] = byte offset (from record start) of the aux VALUE of requested tag t in row i,

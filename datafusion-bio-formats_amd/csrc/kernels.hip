@@ -261,19 +261,10 @@ __global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
     return;
   }
   uint64_t o = base[s];
-  bool bad = false;
   for (uint32_t c = cb.count[s]; c > 0; c--) {  // the complete records the walk counted (a partial tail record is not one)
     rec_off[o++] = p;
-    // Every later kernel trusts l_read_name / n_cigar_op / l_seq: check once, here, that the variable-length fields fit
-    // inside block_size (noodles fails such a record with an I/O error; a CRC-valid member can still carry one).
-    const uint8_t* r = u + p;
-    const uint32_t bs = ld_u32(r);
-    const uint32_t lrn = r[12], ncig = ld_u16(r + 16);
-    const int32_t lseq = ld_i32(r + 20);
-    if (lrn == 0 || lseq < 0 || 32ull + lrn + 4ull * ncig + (((uint64_t)(uint32_t)lseq + 1) >> 1) + (uint64_t)(uint32_t)lseq > (uint64_t)bs) bad = true;
-    p += 4 + (uint64_t)bs;
+    p += 4 + (uint64_t)ld_u32(u + p);
   }
-  if (bad) atomicExch(cb.err, 2u);
 }
 
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref, ChainBuffers cb, hipStream_t st) {
@@ -337,18 +328,29 @@ __device__ __forceinline__ uint32_t rec_end1(const uint8_t* r) {
   return (uint32_t)pos + span;  // (pos+1) + span - 1
 }
 
-__global__ void k_rec_keys(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n, RecKeys k) {
+__global__ void k_rec_keys(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n, RecKeys k, uint32_t* err) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* r = u + rec_off[i];
+  {
+    // the first kernel of an indexed scan that interprets a record: its variable-length fields must fit in block_size
+    // (bam_rows.hip makes the same check for scans that build no key table)
+    const uint32_t bs = ld_u32(r), lrn = r[12], ncig = ld_u16(r + 16);
+    const int32_t lseq = ld_i32(r + 20);
+    if (lrn == 0 || lseq < 0 || 32ull + lrn + 4ull * ncig + (((uint64_t)(uint32_t)lseq + 1) >> 1) + (uint64_t)(uint32_t)lseq > (uint64_t)bs) {
+      atomicExch(err, 8u);
+      k.refid[i] = -1; k.pos[i] = -1; k.end1[i] = 0; k.flag_mapq[i] = 0;
+      return;
+    }
+  }
   k.refid[i] = ld_i32(r + 4);
   k.pos[i] = ld_i32(r + 8);
   k.end1[i] = (int32_t)rec_end1(r);
   k.flag_mapq[i] = ld_u16(r + 18) | ((uint32_t)r[13] << 16);
 }
-void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, hipStream_t st) {
+void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecKeys k, uint32_t* err, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_rec_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, k);
+  hipLaunchKernelGGL(k_rec_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, k, err);
 }
 
 // residual filter evaluation (bio-format-core/src/record_filter.rs:57-283 with BamRecordFields,
@@ -467,90 +469,9 @@ void launch_lower_bound_u64(const uint64_t* arr, uint64_t n, uint64_t key, unsig
 }
 
 // =================================================================================================
-// K4/K6: fixed-width columns, validity words, var-len lengths
+// per-batch offsets of columns that keep an offset array (tags, the wide-quality path); the twelve core columns are
+// written by bam_rows.hip
 // =================================================================================================
-__device__ __forceinline__ uint32_t dec_digits(uint32_t v) {
-  uint32_t d = 1;
-  while (v >= 10) { v /= 10; d++; }
-  return d;
-}
-
-__global__ __launch_bounds__(256) void k_extract_fixed(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
-                                                        uint64_t row0, uint64_t n, CoreCols c,
-                                                        const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
-                                                        int32_t zero_based, int32_t binary_cigar, RowOverride ov,
-                                                        uint32_t* err) {
-  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // local row
-  const bool act = li < n;
-  const uint64_t i = row0 + li;  // global row index (row0 is a multiple of 64)
-  int32_t refid = -1, pos = -1, nref = -1, npos = -1, tlen = 0, lseq = 0;
-  uint32_t lrn = 1, mapq = 0, ncig = 0, flag = 0, end1 = 0;
-  const uint8_t* r = nullptr;
-  if (act) {
-    r = u + rows[li];
-    refid = ld_i32(r + 4); pos = ld_i32(r + 8);
-    lrn = r[12]; mapq = r[13]; ncig = ld_u16(r + 16); flag = ld_u16(r + 18);
-    lseq = ld_i32(r + 20); nref = ld_i32(r + 24); npos = ld_i32(r + 28); tlen = ld_i32(r + 32);
-    if (refid >= n_ref || nref >= n_ref) { atomicExch(err, 2u); refid = -1; nref = -1; }
-  }
-  bool v_start = act && pos >= 0 && !ov.force_null_coords;
-  bool v_end = false;
-  if (act && (c.end || c.v_end) && !ov.force_null_coords) {
-    end1 = rec_end1(r);
-    v_end = end1 != 0;
-  }
-  int32_t chrom_ref = ov.chrom_mode == 0 ? refid : (ov.chrom_mode == 2 ? ov.chrom_ref : -1);
-  bool v_chrom = act && chrom_ref >= 0;
-  bool v_mchrom = act && nref >= 0;
-  bool v_mstart = act && npos >= 0;
-  if (act) {
-    if (c.start) c.start[i] = v_start ? (zero_based ? (uint32_t)pos : (uint32_t)pos + 1u) : 0u;
-    if (c.end) c.end[i] = v_end ? end1 : 0u;
-    if (c.flags) c.flags[i] = flag;
-    if (c.mapq) c.mapq[i] = mapq;
-    if (c.mate_start) c.mate_start[i] = v_mstart ? (zero_based ? (uint32_t)npos : (uint32_t)npos + 1u) : 0u;
-    if (c.tlen) c.tlen[i] = tlen;
-    if (c.len_name) {
-      // noodles strips the trailing NUL; a missing name ("*\0") is rendered "*" by the reference
-      uint32_t l = lrn ? lrn - 1 : 0;
-      c.len_name[i] = l;
-    }
-    if (c.len_chrom) c.len_chrom[i] = v_chrom ? ref_name_len[chrom_ref] : 0u;
-    if (c.len_mate_chrom) c.len_mate_chrom[i] = v_mchrom ? ref_name_len[nref] : 0u;
-    if (c.len_seq) c.len_seq[i] = (uint32_t)lseq;
-    if (c.len_qual) c.len_qual[i] = (uint32_t)lseq;
-    if (c.len_cigar) {
-      uint32_t l = 0;
-      if (binary_cigar) l = 4 * ncig;
-      else {
-        const uint8_t* cg = r + 36 + lrn;
-        for (uint32_t k = 0; k < ncig; k++) {
-          uint32_t v = ld_u32(cg + 4 * k);
-          if ((v & 15u) > 8u) atomicExch(err, 3u);
-          l += dec_digits(v >> 4) + 1;
-        }
-      }
-      c.len_cigar[i] = l;
-    }
-  }
-  // validity words: one 64-bit word per wave (rows are wave-aligned)
-  const int lane = threadIdx.x & 63;
-  const uint64_t word = i >> 6;
-  unsigned long long m;
-  if (c.v_chrom) { m = __ballot(v_chrom); if (lane == 0 && act) c.v_chrom[word] = m; }
-  if (c.v_start) { m = __ballot(v_start); if (lane == 0 && act) c.v_start[word] = m; }
-  if (c.v_end) { m = __ballot(v_end); if (lane == 0 && act) c.v_end[word] = m; }
-  if (c.v_mate_chrom) { m = __ballot(v_mchrom); if (lane == 0 && act) c.v_mate_chrom[word] = m; }
-  if (c.v_mate_start) { m = __ballot(v_mstart); if (lane == 0 && act) c.v_mate_start[word] = m; }
-}
-void launch_extract_fixed(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, CoreCols c,
-                          const uint32_t* ref_name_len, int32_t n_ref, int32_t zero_based, int32_t binary_cigar,
-                          RowOverride ov, uint32_t* err, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_extract_fixed, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, c, ref_name_len,
-                     n_ref, zero_based, binary_cigar, ov, err);
-}
-
 // per-batch int32 offsets of a chunk of rows whose first `phase` batch slots were filled by the previous chunk: batch b
 // covers rows [max(0, b*bs - phase), (b+1)*bs - phase) of the chunk, off32[b*(bs+1) + j] = off64[start_b + j] - off64[start_b]
 __device__ __forceinline__ uint64_t batch_start_row(uint64_t b, uint32_t bs, uint32_t phase) { return b ? b * bs - phase : 0; }
@@ -580,211 +501,6 @@ __global__ void k_batch_bases(const uint64_t* __restrict__ off64, uint64_t nb, u
 void launch_batch_bases(const uint64_t* off64, uint64_t nb, uint32_t bs, uint32_t phase, uint64_t* base, hipStream_t st) {
   if (!nb) return;
   hipLaunchKernelGGL(k_batch_bases, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, st, off64, nb, bs, phase, base);
-}
-
-// =================================================================================================
-// K7a: short var-len columns, one record per lane (name, chrom, cigar, mate_chrom)
-// =================================================================================================
-__device__ __forceinline__ uint32_t write_dec(uint8_t* d, uint32_t v) {
-  uint32_t nd = dec_digits(v);
-  for (int k = (int)nd - 1; k >= 0; k--) { d[k] = (uint8_t)('0' + v % 10); v /= 10; }
-  return nd;
-}
-
-__global__ __launch_bounds__(256) void k_scatter_small(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
-                                                        uint64_t row0, uint64_t n,
-                                                        const uint64_t* __restrict__ off_name, uint8_t* __restrict__ d_name,
-                                                        const uint64_t* __restrict__ off_chrom, uint8_t* __restrict__ d_chrom,
-                                                        const uint64_t* __restrict__ off_cigar, uint8_t* __restrict__ d_cigar,
-                                                        const uint64_t* __restrict__ off_mate, uint8_t* __restrict__ d_mate,
-                                                        const uint8_t* __restrict__ ref_names, const uint32_t* __restrict__ ref_name_off,
-                                                        int32_t n_ref, int32_t binary_cigar, RowOverride ov) {
-  const uint64_t li = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (li >= n) return;
-  const uint64_t i = row0 + li;
-  const uint8_t* r = u + rows[li];
-  const uint32_t lrn = r[12];
-  if (d_name) {
-    uint8_t* d = d_name + off_name[i];
-    const uint32_t l = lrn ? lrn - 1 : 0;
-    for (uint32_t k = 0; k < l; k++) d[k] = r[36 + k];
-  }
-  if (d_chrom) {
-    int32_t refid = ld_i32(r + 4);
-    int32_t cr = ov.chrom_mode == 0 ? refid : (ov.chrom_mode == 2 ? ov.chrom_ref : -1);
-    if (cr >= 0 && cr < n_ref) {
-      uint8_t* d = d_chrom + off_chrom[i];
-      const uint32_t a = ref_name_off[cr], b = ref_name_off[cr + 1];
-      for (uint32_t k = a; k < b; k++) d[k - a] = ref_names[k];
-    }
-  }
-  if (d_mate) {
-    int32_t nref = ld_i32(r + 24);
-    if (nref >= 0 && nref < n_ref) {
-      uint8_t* d = d_mate + off_mate[i];
-      const uint32_t a = ref_name_off[nref], b = ref_name_off[nref + 1];
-      for (uint32_t k = a; k < b; k++) d[k - a] = ref_names[k];
-    }
-  }
-  if (d_cigar) {
-    const uint32_t ncig = ld_u16(r + 16);
-    const uint8_t* cg = r + 36 + lrn;
-    uint8_t* d = d_cigar + off_cigar[i];
-    if (binary_cigar) {
-      for (uint32_t k = 0; k < 4 * ncig; k++) d[k] = cg[k];
-    } else {
-      const char ops[] = "MIDNSHP=X???????";
-      for (uint32_t k = 0; k < ncig; k++) {
-        uint32_t v = ld_u32(cg + 4 * k);
-        d += write_dec(d, v >> 4);
-        *d++ = (uint8_t)ops[v & 15u];
-      }
-    }
-  }
-}
-void launch_scatter_small(const uint8_t* u, const uint64_t* rows, uint64_t row0, uint64_t n, const uint64_t* off_name,
-                          uint8_t* d_name, const uint64_t* off_chrom, uint8_t* d_chrom, const uint64_t* off_cigar,
-                          uint8_t* d_cigar, const uint64_t* off_mate, uint8_t* d_mate, const uint8_t* ref_names,
-                          const uint32_t* ref_name_off, int32_t n_ref, int32_t binary_cigar, RowOverride ov, hipStream_t st) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_scatter_small, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rows, row0, n, off_name, d_name,
-                     off_chrom, d_chrom, off_cigar, d_cigar, off_mate, d_mate, ref_names, ref_name_off, n_ref, binary_cigar, ov);
-}
-
-// =================================================================================================
-struct __attribute__((packed, aligned(1))) u32x4u { uint32_t x, y, z, w; };
-struct __attribute__((packed, aligned(1))) u64u { uint64_t v; };
-
-// K7b: name + sequence + quality in ONE pass, one wave per row (8 rows per wave, grid-stride free): the packed
-// bases and the qualities of a record are adjacent (225 contiguous bytes for a 150 bp read), so the wave
-// reads them once with 2- and 4-byte lane accesses and writes both Arrow value buffers with 4-byte stores
-// to consecutive addresses.  Replaces two output-centric k_scatter_seqqual launches (which re-read most of
-// d_u twice and paid a binary search per 16 output bytes).
-constexpr int SQR_ROWS_PER_WAVE = 16;
-struct __attribute__((packed, aligned(1))) u16u { uint16_t v; };
-struct __attribute__((packed, aligned(1))) u32u { uint32_t v; };
-__device__ __forceinline__ uint32_t qual_swar(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x21212121u) ^ (w & 0x80808080u); }  // (q + 33) mod 256 per byte
-__global__ __launch_bounds__(256) void k_scatter_seqqual_rows(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows,
-                                                               uint64_t n, const uint64_t* __restrict__ off_seq,
-                                                               uint8_t* __restrict__ d_seq, const uint64_t* __restrict__ off_qual,
-                                                               uint8_t* __restrict__ d_qual, const uint64_t* __restrict__ off_name,
-                                                               uint8_t* __restrict__ d_name, uint32_t* qual_wide) {
-  __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first), little-endian u16
-  {
-    const char* L = "=ACMGRSVTWYHKDBN";
-    s_pair[threadIdx.x] = (uint16_t)((uint8_t)L[threadIdx.x >> 4] | ((uint16_t)(uint8_t)L[threadIdx.x & 15] << 8));
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, sl = lane & 15;  // four 16-lane groups, each works on its own row: 4 rows in flight per wave
-  const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const uint64_t r_lo = wave * SQR_ROWS_PER_WAVE;
-  if (r_lo >= n) return;
-  // lanes 0..15 fetch the metadata of the wave's 16 rows in parallel (one dependent-load chain for all of
-  // them); the row loop broadcasts it with shuffles
-  uint64_t m_sp = 0, m_os = 0, m_oq = 0, m_on = 0;
-  uint32_t m_lseq = 0, m_lrn = 0, m_ncig = 0;
-  if (lane < SQR_ROWS_PER_WAVE && r_lo + lane < n) {
-    const uint64_t ro = rows[r_lo + lane];
-    const uint8_t* rec = u + ro;
-    m_lrn = rec[12];
-    m_ncig = ld_u16(rec + 16);
-    m_lseq = (uint32_t)ld_i32(rec + 20);
-    m_sp = ro + 36 + m_lrn + 4ull * m_ncig;
-    if (d_seq) m_os = off_seq[r_lo + lane];
-    if (d_qual) m_oq = off_qual[r_lo + lane];
-    if (d_name) m_on = off_name[r_lo + lane];
-  }
-  bool wide = false;
-  const int nrow = (int)((n - r_lo) < SQR_ROWS_PER_WAVE ? (n - r_lo) : SQR_ROWS_PER_WAVE);
-#pragma unroll
-  for (int it = 0; it < SQR_ROWS_PER_WAVE / 4; it++) {
-    const int k = it * 4 + g;
-    const uint32_t lseq = __shfl(m_lseq, k, 64);
-    const uint64_t spo = __shfl(m_sp, k, 64), oso = __shfl(m_os, k, 64), oqo = __shfl(m_oq, k, 64);
-    const uint32_t lrn = __shfl(m_lrn, k, 64), ncig = __shfl(m_ncig, k, 64);
-    const uint64_t ono = __shfl(m_on, k, 64);
-    if (k >= nrow) continue;
-    const uint8_t* sp = u + spo;
-    const uint8_t* qp = sp + ((lseq + 1) >> 1);
-    // First 256 bytes of each segment: one 16-byte chunk per lane, all three loads issued before any store.  A
-    // partial last chunk is served by the (overlapping) 16 bytes that END at the segment's end, so no lane runs a
-    // byte loop unless the whole segment is shorter than 16 bytes.
-    const uint32_t c0 = (uint32_t)sl * 16;
-    const uint32_t ln = lrn ? lrn - 1 : 0;
-    const uint8_t* np = sp - 4ull * ncig - lrn;  // read_name starts 36 bytes into the record
-    const bool n_on = d_name && c0 < ln, s_on = d_seq && c0 < lseq, q_on = d_qual && c0 < lseq;
-    const uint32_t cn = (c0 + 16 <= ln || ln < 16) ? c0 : ln - 16;
-    const uint32_t cq = (c0 + 16 <= lseq || lseq < 16) ? c0 : lseq - 16;
-    const uint32_t cs = (c0 + 16 <= lseq || lseq < 16) ? c0 : ((lseq - 16) & ~1u);  // packed bytes start on even bases
-    const bool n_vec = n_on && ln >= 16, s_vec = s_on && lseq >= 16, q_vec = q_on && lseq >= 16;
-    u32x4u vn = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
-    uint64_t pk = 0;
-    if (n_vec) vn = *(const u32x4u*)(np + cn);
-    if (s_vec) pk = ((const u64u*)(sp + (cs >> 1)))->v;
-    if (q_vec) vq = *(const u32x4u*)(qp + cq);
-    if (n_vec) *(u32x4u*)(d_name + ono + cn) = vn;
-    else if (n_on) for (uint32_t j = c0; j < ln; j++) d_name[ono + j] = np[j];
-    if (s_vec) {
-      u32x4u v;
-      v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
-      v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
-      v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
-      v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
-      *(u32x4u*)(d_seq + oso + cs) = v;
-      // odd-length tail: the vector ended one base early
-      if (cs != c0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
-    } else if (s_on) {
-      for (uint32_t j = c0; j < lseq; j += 2) {
-        const uint16_t pr = s_pair[sp[j >> 1]];
-        d_seq[oso + j] = (uint8_t)pr;
-        if (j + 1 < lseq) d_seq[oso + j + 1] = (uint8_t)(pr >> 8);
-      }
-    }
-    if (q_vec) {
-      vq.x = qual_swar(vq.x); vq.y = qual_swar(vq.y); vq.z = qual_swar(vq.z); vq.w = qual_swar(vq.w);
-      wide = wide || ((vq.x | vq.y | vq.z | vq.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
-      *(u32x4u*)(d_qual + oqo + cq) = vq;
-    } else if (q_on) {
-      for (uint32_t j = c0; j < lseq; j++) {
-        const uint32_t q = ((uint32_t)qp[j] + 33u) & 0xFFu;
-        wide = wide || q >= 128u;
-        d_qual[oqo + j] = (uint8_t)q;
-      }
-    }
-    // rows longer than 256 bytes per segment (long reads): remaining chunks, same scheme
-    if (d_name) for (uint32_t c = c0 + 256; c < ln; c += 256) {
-      const uint32_t cc = c + 16 <= ln ? c : ln - 16;
-      *(u32x4u*)(d_name + ono + cc) = *(const u32x4u*)(np + cc);
-    }
-    if (d_seq) for (uint32_t c = c0 + 256; c < lseq; c += 256) {
-      const uint32_t cc = c + 16 <= lseq ? c : ((lseq - 16) & ~1u);
-      const uint64_t p2 = ((const u64u*)(sp + (cc >> 1)))->v;
-      u32x4u v;
-      v.x = (uint32_t)s_pair[p2 & 0xFF] | ((uint32_t)s_pair[(p2 >> 8) & 0xFF] << 16);
-      v.y = (uint32_t)s_pair[(p2 >> 16) & 0xFF] | ((uint32_t)s_pair[(p2 >> 24) & 0xFF] << 16);
-      v.z = (uint32_t)s_pair[(p2 >> 32) & 0xFF] | ((uint32_t)s_pair[(p2 >> 40) & 0xFF] << 16);
-      v.w = (uint32_t)s_pair[(p2 >> 48) & 0xFF] | ((uint32_t)s_pair[(p2 >> 56) & 0xFF] << 16);
-      *(u32x4u*)(d_seq + oso + cc) = v;
-      if (cc != c && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
-    }
-    if (d_qual) for (uint32_t c = c0 + 256; c < lseq; c += 256) {
-      const uint32_t cc = c + 16 <= lseq ? c : lseq - 16;
-      u32x4u v = *(const u32x4u*)(qp + cc);
-      v.x = qual_swar(v.x); v.y = qual_swar(v.y); v.z = qual_swar(v.z); v.w = qual_swar(v.w);
-      wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);
-      *(u32x4u*)(d_qual + oqo + cc) = v;
-    }
-  }
-  if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
-}
-void launch_scatter_seqqual_rows(const uint8_t* u, const uint64_t* rows, uint64_t n, const uint64_t* off_seq, uint8_t* d_seq,
-                                 const uint64_t* off_qual, uint8_t* d_qual, const uint64_t* off_name, uint8_t* d_name,
-                                 uint32_t* qual_wide, hipStream_t st) {
-  if (!n || (!d_seq && !d_qual && !d_name)) return;
-  const uint64_t waves = (n + SQR_ROWS_PER_WAVE - 1) / SQR_ROWS_PER_WAVE;
-  hipLaunchKernelGGL(k_scatter_seqqual_rows, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, u, rows, n, off_seq, d_seq, off_qual,
-                     d_qual, off_name, d_name, qual_wide);
 }
 
 // exact wide-quality path: `char::from(q + 33)` pushed into a String -> chars >= U+0080 take two UTF-8 bytes
