@@ -369,7 +369,8 @@ def main():
     t0 = time.time()
     prov = pkg.BamTableProvider(path, None, True, None, index_path=None if args.mode == "indexed" else "",
                                 device_id=local_rank)
-    prov.make_resident()
+    if args.mode != "indexed":
+        prov.make_resident()  # (indexed mode: each rank uploads only what its partitions inflate, below)
     t_load = time.time() - t0
     if not args.keep_file:
         for p in (path, path + ".bai"):
@@ -388,6 +389,10 @@ def main():
         plan = prov.scan(projection=projection, target_partitions=8 * world)
         weights = [plan.partition_estimated_bytes(p) for p in range(plan.num_partitions())]
         my_parts = pkg.shard_partitions_in_order(weights, world)[rank]
+        t0 = time.time()
+        plan.make_resident(my_parts)   # only the compressed byte range this rank's partitions cover
+        t_load += time.time() - t0
+        res_lo, res_hi = prov.resident_range(local_rank)
     else:
         plan = prov.scan(projection=projection, target_partitions=1)
         assert plan.num_partitions() == 1

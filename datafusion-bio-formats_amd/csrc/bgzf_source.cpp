@@ -86,6 +86,21 @@ void BgzfSource::frame() {
   ulen = uo;
 }
 
+static void k1_launch_params(int device, uint32_t* grid, size_t* stride) {
+  hipDeviceProp_t pr;
+  HIP_CHECK(hipGetDeviceProperties(&pr, device));
+#ifdef BIOSCAN_K1_V2
+  const int occ = v2_resident_wg_per_cu();
+  *stride = V2_SCRATCH_STRIDE;
+#else
+  const int occ = v3_resident_wg_per_cu();
+  *stride = V3_SCRATCH_STRIDE;
+#endif
+  const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
+  *grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
+  if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
+}
+
 void BgzfSource::make_resident() {
   if (resident) return;
   set_device();
@@ -99,26 +114,15 @@ void BgzfSource::make_resident() {
   HIP_CHECK(hipMemcpyAsync(d_uoff.p, blk_uoff.data(), blk_uoff.size() * 8, hipMemcpyHostToDevice, stream));
   d_status.alloc(std::max<size_t>(n_blocks(), 1));
   {
-    hipDeviceProp_t pr;
-    HIP_CHECK(hipGetDeviceProperties(&pr, device));
-#ifdef BIOSCAN_K1_V2
-    const int occ = v2_resident_wg_per_cu();
-    const size_t stride = V2_SCRATCH_STRIDE;
-#else
-    const int occ = v3_resident_wg_per_cu();
-    const size_t stride = V3_SCRATCH_STRIDE;
-#endif
-    const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
-    v2_grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
-    v2_grid_max = v2_grid;
-    k1_scratch_stride = stride;
-    if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
+    size_t stride = 0;
+    k1_launch_params(device, &v2_grid, &stride);
     v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
     d_v2_ctr.alloc(32);
     d_v2_scratch.alloc(((size_t)v2_grid + 8) * stride);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   file.reset();  // the compressed bytes now live in HBM; the host image is not read again
+  images.clear();  // (the header image of the open call)
   resident = true;
 }
 
@@ -145,32 +149,81 @@ K1Ctx::~K1Ctx() {
   }
 }
 
-void BgzfSource::init_ctx(K1Ctx& c, uint32_t max_members) {
-  make_resident();
-  set_device();
-  c.device = device;
+std::shared_ptr<DeviceImage> BgzfSource::image_of(int dev) {
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = images.find(dev);
+  return it == images.end() ? nullptr : it->second;
+}
+
+std::shared_ptr<DeviceImage> BgzfSource::image_for(int dev, uint32_t m_lo, uint32_t m_hi) {
+  std::lock_guard<std::mutex> lk(mu);
+  m_hi = std::min(m_hi, n_blocks());
+  if (m_lo > m_hi) m_lo = m_hi;
+  auto it = images.find(dev);
+  if (it != images.end()) {
+    const DeviceImage& cur = *it->second;
+    if (m_lo == m_hi || (cur.m_lo <= m_lo && m_hi <= cur.m_hi)) return it->second;  // (an empty request needs no bytes)
+    if (cur.m_lo == cur.m_hi) { images.erase(it); it = images.end(); }
+  }
+  if (it != images.end()) {
+    m_lo = std::min(m_lo, it->second->m_lo);  // widen: one contiguous span per device
+    m_hi = std::max(m_hi, it->second->m_hi);
+  }
+  auto img = build_image(dev, m_lo, m_hi);
+  images[dev] = img;
+  return img;
+}
+
+// uploads members [m_lo, m_hi) to `dev` (caller holds mu or owns the source exclusively)
+std::shared_ptr<DeviceImage> BgzfSource::build_image(int dev, uint32_t m_lo, uint32_t m_hi) {
+  if (!file.p && file_len) throw Error("the host image of " + path + " has been released (make_resident): cannot upload another range");
+  HIP_CHECK(hipSetDevice(dev));
+  auto img = std::make_shared<DeviceImage>();
+  img->device = dev;
+  img->m_lo = m_lo; img->m_hi = m_hi;
+  const uint64_t c0 = blk_coff[m_lo], c1 = blk_coff[m_hi];
+  hipStream_t up;
+  HIP_CHECK(hipStreamCreate(&up));
+  img->d_comp.alloc(c1 - c0 + 4096);
+  if (c1 > c0) HIP_CHECK(hipMemcpyAsync(img->d_comp.p, file.p + c0, c1 - c0, hipMemcpyHostToDevice, up));
+  HIP_CHECK(hipMemsetAsync(img->d_comp.p + (c1 - c0), 0, 4096, up));  // the kernels over-read a little past the last member
+  img->comp_base = img->d_comp.p - c0;
+  img->d_coff.alloc(blk_coff.size());
+  img->d_uoff.alloc(blk_uoff.size());
+  HIP_CHECK(hipMemcpyAsync(img->d_coff.p, blk_coff.data(), blk_coff.size() * 8, hipMemcpyHostToDevice, up));
+  HIP_CHECK(hipMemcpyAsync(img->d_uoff.p, blk_uoff.data(), blk_uoff.size() * 8, hipMemcpyHostToDevice, up));
+  k1_launch_params(dev, &img->grid_max, &img->scratch_stride);
+  HIP_CHECK(hipStreamSynchronize(up));
+  (void)hipStreamDestroy(up);
+  return img;
+}
+
+void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members) {
+  HIP_CHECK(hipSetDevice(img.device));
+  c.device = img.device;
   if (!c.stream) HIP_CHECK(hipStreamCreate(&c.stream));
-  c.grid = std::min<uint32_t>(v2_grid_max, std::max<uint32_t>(max_members, 1));
+  c.grid = std::min<uint32_t>(img.grid_max, std::max<uint32_t>(max_members, 1));
   if (!c.ctr.p) c.ctr.alloc(32);
-  const size_t need = ((size_t)c.grid + 8) * k1_scratch_stride;
+  const size_t need = ((size_t)c.grid + 8) * img.scratch_stride;
   if (c.scratch.n < need) c.scratch.alloc(need);
   if (c.status.n < max_members) c.status.alloc(std::max<uint32_t>(max_members, 1));
 }
 
-void BgzfSource::launch_inflate(K1Ctx& c, uint8_t* dst, uint32_t nb, uint32_t b0) {
+void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0) {
+  if (b0 < img.m_lo || b0 + nb > img.m_hi) throw Error("internal: members outside the resident range of the device image");
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
 #ifdef BIOSCAN_K1_V2
-  launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, V2_SCRATCH_STRIDE, c.grid,
+  launch_bgzf_inflate_v2(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, V2_SCRATCH_STRIDE, c.grid,
                          env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
 #else
-  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, c.grid,
+  launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, c.grid,
                          env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
 #endif
 }
 
-void BgzfSource::launch_crc(K1Ctx& c, const uint8_t* dst, uint32_t nb, uint32_t b0) {
-  launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, c.status.p, c.stream);
+void BgzfSource::launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0) {
+  launch_bgzf_crc32(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, dst - blk_uoff[b0], nb, c.status.p, c.stream);
 }
 
 void BgzfSource::check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb) {
@@ -229,14 +282,18 @@ void BgzfSource::check_inflate_status(uint32_t b0, uint32_t nb) {
 }
 
 std::vector<uint8_t> BgzfSource::inflate_prefix_to_host(uint32_t b1) {
-  make_resident();
+  // header / sampling: only the leading members are uploaded (a provider that will execute a far range of the file, or on
+  // another device, never sends the whole file to this one)
   b1 = std::min(b1, n_blocks());
+  auto img = build_image(device, 0, b1);  // private to this call: it is not what an execute will want resident
+  K1Ctx c;
+  init_ctx(c, *img, std::max<uint32_t>(b1, 1));
   uint64_t bytes = blk_uoff[b1];
   DevBuf<uint8_t> tmp(bytes + 64);
-  launch_inflate(tmp.p, b1);
-  launch_crc(tmp.p, b1);
-  HIP_CHECK(hipStreamSynchronize(stream));
-  check_inflate_status(0, b1);
+  launch_inflate(c, *img, tmp.p, b1, 0);
+  launch_crc(c, *img, tmp.p, b1, 0);
+  HIP_CHECK(hipStreamSynchronize(c.stream));
+  check_inflate_status(c, 0, b1);
   std::vector<uint8_t> out(bytes);
   if (bytes) HIP_CHECK(hipMemcpy(out.data(), tmp.p, bytes, hipMemcpyDeviceToHost));
   return out;

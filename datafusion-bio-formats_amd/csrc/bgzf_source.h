@@ -3,6 +3,8 @@
 // Replaces noodles-bgzf's `io::Reader` (call sites bam/src/storage.rs:161-169, fastq/src/physical_exec.rs:482-491,
 // vcf/src/storage.rs:117-122, 766-776) at block granularity.
 #pragma once
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -31,6 +33,21 @@ struct K1Ctx {
   ~K1Ctx();
 };
 
+// The part of a file one device holds: the compressed bytes of members [m_lo, m_hi) and the member tables, resident in
+// that device's HBM (each GPU receives only the compressed byte ranges its partitions cover).  Immutable once
+// built: a wider span is a new image, executions in flight keep the one they started with.
+struct DeviceImage {
+  int device = 0;
+  uint32_t m_lo = 0, m_hi = 0;
+  DevBuf<uint8_t> d_comp;              // bytes [blk_coff[m_lo], blk_coff[m_hi]) + 4 KiB of zero padding
+  const uint8_t* comp_base = nullptr;  // d_comp.p - blk_coff[m_lo]: comp_base + blk_coff[b] is member b
+  DevBuf<uint64_t> d_coff, d_uoff;     // the whole tables (8 B per member each)
+  uint32_t grid_max = 0;               // persistent grid of K1 on this device (waves)
+  size_t scratch_stride = 0;
+  DevBuf<uint8_t> d_ref_names;         // BAM: reference-name table for chrom / mate_chrom
+  DevBuf<uint32_t> d_ref_name_off, d_ref_name_len;
+};
+
 struct BgzfSource {
   std::string path;
   const char* what = "BAM";  // format name used in error messages
@@ -49,8 +66,7 @@ struct BgzfSource {
   DevBuf<uint32_t> d_status;
   DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..] debug counters
   DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
-  uint32_t v2_grid = 0, v2_grid_max = 0;  // persistent grid of K1 (waves): for this file / for any launch
-  size_t k1_scratch_stride = 0;
+  uint32_t v2_grid = 0;  // persistent grid of K1 (waves) of the whole-file image below
   DevBuf<uint8_t> d_u;  // inflated bytes of the range decoded last
 
   ~BgzfSource();
@@ -64,10 +80,16 @@ struct BgzfSource {
   void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
   void report_v2_debug(uint32_t nb);
   void check_inflate_status(uint32_t b0, uint32_t nb);
-  // the same three steps on a caller-owned context (its stream, its scratch, status relative to b0)
-  void init_ctx(K1Ctx& c, uint32_t max_members);
-  void launch_inflate(K1Ctx& c, uint8_t* dst, uint32_t nb, uint32_t b0);
-  void launch_crc(K1Ctx& c, const uint8_t* dst, uint32_t nb, uint32_t b0);
+  // Per-device, per-range residency (BAM): the image of `device` that covers members [m_lo, m_hi), built or widened on
+  // demand from the mapped file.  The three K1 / K2 steps on a caller-owned context (its stream, its scratch, status
+  // relative to b0) against an image.
+  std::map<int, std::shared_ptr<DeviceImage>> images;  // guarded by mu
+  std::shared_ptr<DeviceImage> image_for(int dev, uint32_t m_lo, uint32_t m_hi);
+  std::shared_ptr<DeviceImage> image_of(int dev);      // the current image of a device, or null
+  std::shared_ptr<DeviceImage> build_image(int dev, uint32_t m_lo, uint32_t m_hi);
+  void init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members);
+  void launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0);
+  void launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0);
   void check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb);
   // Inflate blocks [0, b1) into a temporary device buffer and copy to the host (header / sampling).
   std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1);

@@ -208,9 +208,6 @@ struct Provider : BgzfSource {
   std::string index_path;
   Bai bai;
 
-  DevBuf<uint8_t> d_ref_names;
-  DevBuf<uint32_t> d_ref_name_off, d_ref_name_len;
-
   DecodeRange whole_file() const {
     DecodeRange r;
     r.b_lo = 0; r.b_hi = n_blocks();
@@ -218,12 +215,13 @@ struct Provider : BgzfSource {
     return r;
   }
 
-  // file + reference-name table in HBM (idempotent; the only provider state an execute waits for)
-  void prepare_device() {
-    std::lock_guard<std::mutex> lk(mu);
-    make_resident();
-    if (d_ref_name_off.p) return;
-    set_device();
+  // The image of `dev` covering members [m_lo, m_hi), with the reference-name table beside it.  This is the only
+  // provider state an execute waits for; everything else it touches is its own.
+  std::shared_ptr<DeviceImage> device_image(int dev, uint32_t m_lo, uint32_t m_hi) {
+    auto img = image_for(dev, m_lo, m_hi);
+    std::lock_guard<std::mutex> lk(ref_mu);
+    if (img->d_ref_name_off.p) return img;
+    HIP_CHECK(hipSetDevice(dev));
     std::vector<uint32_t> off{0}, len;
     std::string blob;
     for (auto& n : hdr.ref_names) {
@@ -231,14 +229,16 @@ struct Provider : BgzfSource {
       off.push_back((uint32_t)blob.size());
       len.push_back((uint32_t)n.size());
     }
-    d_ref_names.alloc(std::max<size_t>(blob.size(), 1));
-    d_ref_name_len.alloc(std::max<size_t>(len.size(), 1));
+    img->d_ref_names.alloc(std::max<size_t>(blob.size(), 1));
+    img->d_ref_name_len.alloc(std::max<size_t>(len.size(), 1));
     DevBuf<uint32_t> o(off.size());
-    if (!blob.empty()) HIP_CHECK(hipMemcpy(d_ref_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    if (!blob.empty()) HIP_CHECK(hipMemcpy(img->d_ref_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(o.p, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-    if (!len.empty()) HIP_CHECK(hipMemcpy(d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
-    d_ref_name_off = std::move(o);  // published last: its pointer is the "ready" flag read above
+    if (!len.empty()) HIP_CHECK(hipMemcpy(img->d_ref_name_len.p, len.data(), len.size() * 4, hipMemcpyHostToDevice));
+    img->d_ref_name_off = std::move(o);  // published last: its pointer is the "ready" flag read above
+    return img;
   }
+  std::mutex ref_mu;
 };
 
 // One step of a partition: the records of `range` that pass `sel` (reference: one region query, one unmapped-tail scan,
@@ -267,6 +267,8 @@ struct Plan {
   // execute cost 1-3 ms of host time per partition
   mutable std::mutex work_mu;
   mutable std::vector<std::pair<bool, std::vector<WorkItem>>> work_cache;
+  std::vector<int32_t> part_device;  // HIP device of each partition (bioscan_scan_devices); empty = the provider's device
+  int device_of(int partition) const { return part_device.empty() ? prov->device : part_device[(size_t)partition]; }
   int n_partitions() const {
     if (prov && prov->kind == 1) return fq_strategy == 0 ? 1 : (int)fq_parts.size();
     return empty ? 0 : (indexed ? (int)assignments.size() : 1);
@@ -510,6 +512,14 @@ static std::vector<WorkItem> build_work(const Plan& plan, int partition, size_t 
   return slot.second;
 }
 
+// members spanned by a work list (what has to be resident on the device that executes it)
+static void work_span(const std::vector<WorkItem>& items, uint32_t* m_lo, uint32_t* m_hi) {
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (auto& w : items) { lo = std::min(lo, w.range.b_lo); hi = std::max(hi, w.range.b_hi); }
+  if (lo > hi) { lo = 0; hi = 0; }
+  *m_lo = lo; *m_hi = hi;
+}
+
 // -------------------------------------------------------------------------------------------------
 // D2H of a chunk's Arrow buffers.  The copies run on `copy_st` behind an event of the compute stream, into pinned
 // blocks, so they overlap with the next chunk's kernels; finish_copy() waits for them and drops the device buffers.
@@ -578,6 +588,7 @@ struct BamExecState {
   const uint32_t batch_size;
   const bool to_host;
   const uint32_t chunk_members;
+  std::shared_ptr<DeviceImage> img;  // this partition's device: resident members + tables + reference names
   K1Ctx k1;
   hipStream_t st = nullptr, copy_st = nullptr;
   std::vector<WorkItem> items;
@@ -602,12 +613,14 @@ struct BamExecState {
   BamExecState(const Plan& pl, int partition, uint32_t bs, bool host)
       : plan(pl), p(*pl.prov), batch_size(bs), to_host(host),
         chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device) {
-    p.prepare_device();
-    p.set_device();
     satisfiable = build_terms(plan, &terms);
     items = build_work(plan, partition, terms.size());
     if (!satisfiable) items.clear();
-    p.init_ctx(k1, std::min<uint32_t>(chunk_members, std::max<uint32_t>(p.n_blocks(), 1)));
+    uint32_t m_lo = 0, m_hi = 0;
+    work_span(items, &m_lo, &m_hi);
+    img = p.device_image(plan.device_of(partition), m_lo, m_hi);
+    HIP_CHECK(hipSetDevice(img->device));
+    p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(m_hi - m_lo, 1)));
     st = k1.stream;
     if (to_host) HIP_CHECK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
     d_terms.alloc(std::max<size_t>(terms.size(), 1));
@@ -625,7 +638,7 @@ struct BamExecState {
     if (copy_st) {
       int prev = 0;
       (void)hipGetDevice(&prev);
-      (void)hipSetDevice(p.device);
+      (void)hipSetDevice(img->device);
       (void)hipStreamSynchronize(copy_st);
       (void)hipStreamDestroy(copy_st);
       (void)hipSetDevice(prev);
@@ -634,7 +647,7 @@ struct BamExecState {
 
   // Next chunk of rows of the partition (never an empty one), or nullptr when the partition is exhausted.
   std::shared_ptr<Result> next_chunk() {
-    p.set_device();
+    HIP_CHECK(hipSetDevice(img->device));
     for (;;) {
       if (!item_open) {
         if (item >= items.size()) return nullptr;
@@ -675,11 +688,11 @@ struct BamExecState {
     s.compressed_bytes = p.blk_coff[m1] - p.blk_coff[m0];
     s.inflated_bytes = chunk_bytes;
     t.start();
-    p.launch_inflate(k1, u + carry_len, m1 - m0, m0);
+    p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
     s.ms_inflate = t.stop();
     // CRC32 validation (noodles-bgzf checks every block)
     t.start();
-    p.launch_crc(k1, u + carry_len, m1 - m0, m0);
+    p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
     s.ms_crc = t.stop();
     p.check_inflate_status(k1, m0, m1 - m0);
     (void)range_u0;
@@ -856,7 +869,7 @@ struct BamExecState {
     auto res = std::make_shared<Result>();
     res->batch_size = batch_size;
     res->phase = phase;
-    res->device = p.device;
+    res->device = img->device;
     res->n_rows = n;
     const uint64_t nwords = (n + 63) / 64;
     const uint64_t nb = res->n_batches();
@@ -901,7 +914,7 @@ struct BamExecState {
     // pass 1: fixed columns, validity, tile sums of the variable-length columns (+ their scan)
     const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
     DevBuf<uint64_t> tile_sums(6 * (n_tiles + 1));
-    launch_bam_rows_pass1(u, rows, n, rc, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
+    launch_bam_rows_pass1(u, rows, n, rc, img->d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
                           p.binary_cigar ? 1 : 0, tile_sums.p, err.p, st);
     uint64_t totals[6] = {0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 6; k++)
@@ -920,7 +933,7 @@ struct BamExecState {
     // pass 2: per-batch offsets + every variable-length byte
     DevBuf<uint32_t> wide(1);
     HIP_CHECK(hipMemsetAsync(wide.p, 0, 4, st));
-    launch_bam_rows_pass2(u, rows, n, rc, p.d_ref_names.p, p.d_ref_name_off.p, p.d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(),
+    launch_bam_rows_pass2(u, rows, n, rc, img->d_ref_names.p, img->d_ref_name_off.p, img->d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(),
                           p.binary_cigar ? 1 : 0, batch_size, phase, tile_sums.p, wide.p, st);
     DevBuf<uint64_t> tmp(scan_tmp_elems(n));
     auto finish_var = [&](Column& col, uint32_t elem_bytes) {
@@ -1645,6 +1658,29 @@ static bool file_exists(const std::string& s) {
 
 }  // namespace
 
+// Partitions -> devices: contiguous runs in plan order, byte balanced -- partition_byte_ranges_in_order
+// (bio-format-core/src/range_planning.rs:147-195) applied to the plan's per-partition estimates.  run_of[i] = run index.
+static std::vector<int32_t> shard_in_order(const std::vector<uint64_t>& weights, size_t world) {
+  const size_t n = weights.size();
+  std::vector<int32_t> run_of(n, 0);
+  if (n == 0) return run_of;
+  const size_t count = std::min(std::max<size_t>(world, 1), n);
+  unsigned __int128 total = 0;
+  for (auto w : weights) total += w;
+  size_t runs = 0, cur = 0;
+  unsigned __int128 assigned = 0;
+  for (size_t idx = 0; idx < n; idx++) {
+    const size_t remaining_ranges = n - idx, remaining_parts = count - runs;
+    const bool share_complete = count > 1 && cur > 0 && assigned * count >= total * (runs + 1);
+    const bool must_close = remaining_ranges < remaining_parts;
+    if (remaining_parts > 1 && (share_complete || must_close)) { runs++; cur = 0; }
+    run_of[idx] = (int32_t)runs;
+    cur++;
+    assigned += weights[idx];
+  }
+  return run_of;
+}
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
@@ -2078,8 +2114,86 @@ void bioscan_provider_close(bioscan_provider* p) {
 
 int bioscan_provider_make_resident(bioscan_provider* p) {
   API_BEGIN
-  if (p->vcf) p->vcf->make_resident(); else p->p.make_resident();
+  if (p->vcf) p->vcf->make_resident();
+  else if (p->p.kind == 1) p->p.make_resident();
+  else p->p.device_image(p->p.device, 0, p->p.n_blocks());
   API_END
+}
+
+int bioscan_scan_devices(const bioscan_provider* cp, const int32_t* projection, int32_t n_projection, const bioscan_filter* filters,
+                         int32_t n_filters, int64_t limit, int32_t target_partitions, const int32_t* device_ids, int32_t n_devices,
+                         bioscan_plan** out) {
+  API_BEGIN
+  if (n_devices < 1 || !device_ids) throw Error("bioscan_scan_devices needs at least one device");
+  if (cp->vcf || cp->p.kind != 0) {
+    if (n_devices != 1) throw Error("multi-device plans are implemented for BAM providers");
+    return bioscan_scan(cp, projection, n_projection, filters, n_filters, limit, target_partitions, out);
+  }
+  for (int32_t d = 0; d < n_devices; d++) {
+    char nm[8];
+    if (bioscan_device_check(device_ids[d], nm, sizeof nm)) throw Error(g_err);
+  }
+  bioscan_plan* pl = nullptr;
+  if (bioscan_scan(cp, projection, n_projection, filters, n_filters, limit, target_partitions, &pl)) throw Error(g_err);
+  std::unique_ptr<bioscan_plan> hold(pl);
+  const int np = pl->pl.n_partitions();
+  std::vector<uint64_t> w((size_t)np, 1);
+  if (pl->pl.indexed)
+    for (int i = 0; i < np; i++) w[(size_t)i] = pl->pl.assignments[(size_t)i].total_estimated_bytes;
+  const auto run_of = shard_in_order(w, (size_t)n_devices);
+  pl->pl.part_device.resize((size_t)np);
+  for (int i = 0; i < np; i++) pl->pl.part_device[(size_t)i] = device_ids[run_of[(size_t)i]];
+  *out = hold.release();
+  API_END
+}
+
+int32_t bioscan_plan_partition_device(const bioscan_plan* plan, int32_t partition) {
+  if (plan->vcf) return 0;
+  if (partition < 0 || partition >= plan->pl.n_partitions()) return -1;
+  return plan->pl.device_of(partition);
+}
+
+int bioscan_plan_make_resident(const bioscan_plan* plan, const int32_t* partitions, int32_t n) {
+  API_BEGIN
+  if (plan->vcf) throw Error("bioscan_plan_make_resident: use bioscan_provider_make_resident for VCF providers");
+  const Plan& pl = plan->pl;
+  Provider& p = *pl.prov;
+  if (p.kind == 1) { p.make_resident(); return 0; }
+  std::vector<FilterTerm> terms;
+  (void)build_terms(pl, &terms);
+  std::map<int, std::pair<uint32_t, uint32_t>> span;  // device -> members
+  const int np = pl.n_partitions();
+  for (int k = 0; k < (partitions ? n : np); k++) {
+    const int part = partitions ? partitions[k] : k;
+    if (part < 0 || part >= np) throw Error("partition index out of range");
+    uint32_t lo = 0, hi = 0;
+    work_span(build_work(pl, part, terms.size()), &lo, &hi);
+    if (hi <= lo) continue;
+    auto it = span.find(pl.device_of(part));
+    if (it == span.end()) span[pl.device_of(part)] = {lo, hi};
+    else { it->second.first = std::min(it->second.first, lo); it->second.second = std::max(it->second.second, hi); }
+  }
+  for (auto& kv : span) p.device_image(kv.first, kv.second.first, kv.second.second);
+  API_END
+}
+
+int bioscan_provider_resident_range(const bioscan_provider* cp, int32_t device_id, uint64_t* lo, uint64_t* hi) {
+  API_BEGIN
+  *lo = 0; *hi = 0;
+  if (cp->vcf) throw Error("bioscan_provider_resident_range: BAM / FASTQ providers");
+  Provider& p = const_cast<Provider&>(cp->p);
+  if (p.resident && device_id == p.device) { *hi = p.file_len; return 0; }
+  auto img = p.image_of(device_id);
+  if (img) { *lo = p.blk_coff[img->m_lo]; *hi = p.blk_coff[img->m_hi]; }
+  API_END
+}
+
+int32_t bioscan_debug_shard_partitions(const uint64_t* weights, int32_t n, int32_t world, int32_t* run_of) {
+  std::vector<uint64_t> w(weights, weights + std::max(n, 0));
+  const auto r = shard_in_order(w, (size_t)std::max(world, 1));
+  int32_t runs = 0;
+  for (int32_t i = 0; i < n; i++) { run_of[i] = r[(size_t)i]; runs = std::max(runs, r[(size_t)i] + 1); }
+  return runs;
 }
 
 void bioscan_free(void* p) { free(p); }

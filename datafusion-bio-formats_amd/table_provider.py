@@ -80,7 +80,18 @@ EXPORTED_SYMBOLS = [
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
     "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
+    "bioscan_scan_devices", "bioscan_plan_partition_device", "bioscan_plan_make_resident", "bioscan_provider_resident_range",
+    "bioscan_debug_shard_partitions",
 ]
+
+
+def debug_shard_partitions(weights, world: int):
+    """The C++ planner's partition -> device runs (bioscan_debug_shard_partitions; host only)."""
+    n = len(weights)
+    w = (C.c_uint64 * max(n, 1))(*weights)
+    out = (C.c_int32 * max(n, 1))()
+    runs = load_library().bioscan_debug_shard_partitions(w, n, world, out)
+    return runs, [out[i] for i in range(n)]
 
 
 def load_library():
@@ -119,6 +130,12 @@ def load_library():
     lib.bioscan_udf_list_and.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_udf_vcf_set_gts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_stream_list_udf.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_double, C.POINTER(UdfStats)]
+    lib.bioscan_scan_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_Filter), C.c_int32, C.c_int64,
+                                         C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_plan_partition_device.argtypes = [C.c_void_p, C.c_int32]
+    lib.bioscan_plan_make_resident.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
+    lib.bioscan_provider_resident_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bioscan_debug_shard_partitions.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     _lib = lib
     return lib
 
@@ -269,8 +286,16 @@ class BamTableProvider:
     def make_resident(self):
         _check(load_library().bioscan_provider_make_resident(self._h))
 
+    def resident_range(self, device_id: int = 0):
+        """Compressed byte range [lo, hi) of the file resident on `device_id` ((0, 0): nothing)."""
+        lo, hi = C.c_uint64(), C.c_uint64()
+        _check(load_library().bioscan_provider_resident_range(self._h, device_id, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
     def scan(self, projection: Optional[Sequence[int]] = None, filters=(), limit: Optional[int] = None,
-             target_partitions: int = 1) -> "BamExec":
+             target_partitions: int = 1, device_ids: Optional[Sequence[int]] = None) -> "BamExec":
+        """TableProvider::scan.  device_ids: the GPUs of this node the plan's partitions are dealt to (contiguous runs in
+        plan order, bioscan_scan_devices); None = the provider's device."""
         filters = list(filters)
         arr, keep = _make_filters(filters)
         if projection is None:
@@ -279,8 +304,13 @@ class BamTableProvider:
             proj = (C.c_int32 * max(len(projection), 1))(*projection)
             nproj = len(projection)
         plan = C.c_void_p()
-        _check(load_library().bioscan_scan(self._h, proj, nproj, arr, len(filters), -1 if limit is None else limit,
-                                           target_partitions, C.byref(plan)))
+        lim = -1 if limit is None else limit
+        if device_ids is None:
+            _check(load_library().bioscan_scan(self._h, proj, nproj, arr, len(filters), lim, target_partitions, C.byref(plan)))
+        else:
+            dv = (C.c_int32 * max(len(device_ids), 1))(*device_ids)
+            _check(load_library().bioscan_scan_devices(self._h, proj, nproj, arr, len(filters), lim, target_partitions, dv,
+                                                       len(device_ids), C.byref(plan)))
         return BamExec(self, plan)
 
 
@@ -317,6 +347,17 @@ class BamExec:
         buf = C.create_string_buffer(1 << 16)
         load_library().bioscan_plan_partition_desc(self._h, partition, buf, 1 << 16)
         return buf.value.decode()
+
+    def partition_device(self, partition: int) -> int:
+        return load_library().bioscan_plan_partition_device(self._h, partition)
+
+    def make_resident(self, partitions: Optional[Sequence[int]] = None):
+        """Uploads now what the given partitions (None = all) will inflate, each to the device that executes it."""
+        if partitions is None:
+            _check(load_library().bioscan_plan_make_resident(self._h, None, 0))
+        else:
+            a = (C.c_int32 * max(len(partitions), 1))(*partitions)
+            _check(load_library().bioscan_plan_make_resident(self._h, a, len(partitions)))
 
     def partition_estimated_bytes(self, partition: int) -> int:
         """PartitionAssignment.total_estimated_bytes (0 for the sequential single-partition plan)."""

@@ -213,6 +213,23 @@ typedef struct bioscan_scan_stats {
 
 /* Make the file's compressed bytes resident in HBM (idempotent); later executes reuse them. */
 int bioscan_provider_make_resident(bioscan_provider* p);
+
+/* ---- several GPUs of one node behind ONE plan (DataFusion calls execute(partition) for every partition
+ * of one ExecutionPlan object).  Like bioscan_scan, and the plan's partitions are dealt to `device_ids` in contiguous runs
+ * in plan order, balanced by PartitionAssignment.total_estimated_bytes -- the rule of partition_byte_ranges_in_order
+ * (bio-format-core/src/range_planning.rs:147-195) -- so the devices' outputs concatenated in order reproduce the
+ * single-device partition order.  No collective: partitions never exchange data.  Each device receives only the
+ * compressed byte range its partitions inflate (uploaded on first use, or ahead of time by bioscan_plan_make_resident).
+ * BAM providers; a VCF / FASTQ provider accepts exactly one device. */
+int bioscan_scan_devices(const bioscan_provider* p, const int32_t* projection, int32_t n_projection,
+                         const bioscan_filter* filters, int32_t n_filters, int64_t limit, int32_t target_partitions,
+                         const int32_t* device_ids, int32_t n_devices, bioscan_plan** out);
+/* HIP device that executes `partition` (-1: no such partition). */
+int32_t bioscan_plan_partition_device(const bioscan_plan* plan, int32_t partition);
+/* Upload now what the given partitions (NULL = every partition of the plan) will inflate, each to its own device. */
+int bioscan_plan_make_resident(const bioscan_plan* plan, const int32_t* partitions, int32_t n_partitions);
+/* Compressed byte range [*lo, *hi) of the file that is resident on `device_id` (both 0: nothing). */
+int bioscan_provider_resident_range(const bioscan_provider* p, int32_t device_id, uint64_t* lo, uint64_t* hi);
 /* Execute a partition entirely on the device; columns stay in HBM until the stream is closed
  * or drained with bioscan_next. */
 int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t batch_size,
@@ -240,6 +257,10 @@ int32_t bioscan_debug_balance_partitions(int32_t n, const char* const* chroms, c
  * partition.  Same output format. */
 int32_t bioscan_debug_plan_full_scan(const char* bai_path, int32_t n_ref, const char* const* ref_names,
                                      const int64_t* ref_lengths, int32_t target_partitions, char* buf, int32_t cap);
+
+/* partition_byte_ranges_in_order (bio-format-core/src/range_planning.rs:147-195) on per-partition byte estimates:
+ * run_of[i] = index of the contiguous run (device / rank) partition i belongs to; returns the number of runs. */
+int32_t bioscan_debug_shard_partitions(const uint64_t* weights, int32_t n, int32_t world, int32_t* run_of);
 
 /* Library / device probe: returns 0 when a gfx950-capable HIP device is usable. */
 int bioscan_device_check(int32_t device_id, char* name_buf, int32_t cap);

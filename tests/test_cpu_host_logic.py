@@ -194,3 +194,46 @@ def test_f32_display_header_matches_oracle_and_numpy(oracle, tmp_path):
                 ties += 1
                 assert len(w) == len(g) and int(g.replace(".", "").replace("-", "")) - int(w.replace(".", "").replace("-", "")) == 1, (g, w)
     assert ties < 100
+
+
+# ---- partitions -> devices: partition_byte_ranges_in_order (bio-format-core/src/range_planning.rs:147-195) -----------
+# The reference's own tests (range_planning.rs:328-374), transcribed as data, run against the Python restatement
+# (sharding.py, used by bench.py) AND the C++ planner behind bioscan_scan_devices.
+def _runs_from_c(pkg, weights, world):
+    runs, run_of = pkg.debug_shard_partitions(weights, world)
+    out = [[] for _ in range(runs)]
+    for i, r in enumerate(run_of):
+        out[r].append(i)
+    return out
+
+
+def test_in_order_partitions_are_contiguous_and_cover_every_range(pkg):
+    # range_planning.rs:328-357: 17 ranges of lengths 10 + 5 i, targets 1..20
+    weights = [10 + 5 * i for i in range(17)]
+    for target in range(1, 21):
+        for runs in (pkg.shard_partitions_in_order(weights, target)[:min(target, 17)], _runs_from_c(pkg, weights, target)):
+            assert runs and len(runs) <= min(max(target, 1), len(weights))
+            assert all(r for r in runs), (target, runs)                       # no empty partition
+            assert [i for r in runs for i in r] == list(range(17)), target    # source order kept, every range once
+
+
+def test_in_order_partitions_split_even_work_evenly(pkg):
+    # range_planning.rs:359-370: 8 equal ranges over 4 partitions -> 2 each
+    for runs in (pkg.shard_partitions_in_order([10] * 8, 4), _runs_from_c(pkg, [10] * 8, 4)):
+        assert len(runs) == 4 and all(len(r) == 2 for r in runs)
+
+
+def test_in_order_partitions_handle_an_empty_input(pkg):
+    # range_planning.rs:372-374
+    assert pkg.shard_partitions_in_order([], 4) == [[], [], [], []]
+    assert pkg.debug_shard_partitions([], 4)[0] == 0
+
+
+def test_cpp_sharding_equals_python_restatement(pkg):
+    rng = random.Random(11)
+    for _ in range(300):
+        n = rng.randrange(1, 40)
+        weights = [rng.choice([0, 1, 7, 1000, rng.randrange(1, 1 << 40)]) for _ in range(n)]
+        world = rng.randrange(1, 12)
+        want = [r for r in pkg.shard_partitions_in_order(weights, world) if r]
+        assert _runs_from_c(pkg, weights, world) == want, (weights, world)
