@@ -393,9 +393,10 @@ static bool build_terms(const Plan& plan, std::vector<FilterTerm>* terms) {
       if (!num(f.values[0], &t.vals[0]) || !num(f.values[1], &t.vals[1])) continue;
       t.n_vals = 2;
     } else {
-      if (f.values.size() > 8) throw Error("IN list longer than 8 literals is not supported by the device filter");
+      // eight literals per term; a longer list continues in the following terms (`more`)
       int n = 0;
       for (auto& l : f.values) {
+        if (n == 8) { t.n_vals = 8; t.more = 1; terms->push_back(t); t.has_null = 0; t.more = 0; n = 0; }
         if (field == 0) {
           if (l.kind == BIOSCAN_LIT_NULL) t.has_null = 1;
           else if (l.kind == BIOSCAN_LIT_STR) t.vals[n++] = chrom_idx(l.s);
@@ -2186,6 +2187,27 @@ int bioscan_provider_resident_range(const bioscan_provider* cp, int32_t device_i
   auto img = p.image_of(device_id);
   if (img) { *lo = p.blk_coff[img->m_lo]; *hi = p.blk_coff[img->m_hi]; }
   API_END
+}
+
+int32_t bioscan_debug_extract_regions(const bioscan_filter* filters, int32_t n_filters, int32_t zero_based, char* buf, int32_t cap) {
+  std::string o;
+  try {
+    auto fs = copy_filters(filters, n_filters);
+    std::vector<GenomicRegion> regions;
+    bool unsat = false;
+    extract_genomic_regions(fs, zero_based != 0, &regions, &unsat);
+    for (auto& r : regions) {
+      if (!o.empty() && o.back() != '|') o += ";";
+      o += r.chrom + ":" + (r.has_start ? std::to_string(r.start) : "") + "-" + (r.has_end ? std::to_string(r.end) : "");
+    }
+    int residual = 0, genomic = 0;
+    for (auto& f : fs) { if (is_genomic_coordinate_filter(f)) genomic++; else residual++; }
+    o += "|unsat=" + std::to_string(unsat ? 1 : 0) + "|genomic=" + std::to_string(genomic) + "|residual=" + std::to_string(residual);
+  } catch (const std::exception& e) {
+    o = std::string("error: ") + e.what();
+  }
+  if (buf && cap > 0) snprintf(buf, cap, "%s", o.c_str());
+  return (int32_t)o.size();
 }
 
 int32_t bioscan_debug_shard_partitions(const uint64_t* weights, int32_t n, int32_t world, int32_t* run_of) {

@@ -78,8 +78,10 @@ void launch_rec_keys(const uint8_t* u, const uint64_t* rec_off, uint64_t n, RecK
 struct FilterTerm {
   int32_t field;     // 0 chrom(refid), 1 start, 2 end, 3 mapping_quality, 4 flags
   int32_t op;        // bioscan_filter_op
-  int32_t n_vals;    // number of literal values (<= 8)
+  int32_t n_vals;    // number of literal values in this term (<= 8)
   int32_t has_null;  // in-list contained NULL / non-numeric literal
+  int32_t more;      // [NOT] IN only: the next term holds further literals of the same list (lists of any length)
+  int32_t pad_;
   double vals[8];    // numeric literals, or ref index for chrom (-1 = name not in header)
 };
 struct RowSelect {

@@ -368,7 +368,10 @@ __device__ bool eval_terms(const FilterTerm* t, int n, bool has_chrom, int32_t c
       case 3: have = true; v = (double)mapq; break;
       default: have = true; v = (double)flags; break;
     }
-    if (!have) continue;  // field not found on record -> pass through
+    if (!have) {          // field not found on record -> pass through (all terms of a long list)
+      while (t[k].more && k + 1 < n) k++;
+      continue;
+    }
     bool ok = true;
     switch (f.op) {
       case BIOSCAN_OP_EQ: ok = v == f.vals[0]; break;
@@ -381,10 +384,17 @@ __device__ bool eval_terms(const FilterTerm* t, int n, bool has_chrom, int32_t c
       case BIOSCAN_OP_NOT_BETWEEN: ok = !(v >= f.vals[0] && v <= f.vals[1]); break;
       case BIOSCAN_OP_IN:
       case BIOSCAN_OP_NOT_IN: {
-        bool hit = false;
-        for (int j = 0; j < f.n_vals; j++) hit = hit || (v == f.vals[j]);
+        // a list longer than eight literals spans consecutive terms (`more`): the verdict is taken over the whole list
+        bool hit = false, has_null = false;
+        for (;;) {
+          const FilterTerm& g = t[k];
+          for (int j = 0; j < g.n_vals; j++) hit = hit || (v == g.vals[j]);
+          has_null = has_null || g.has_null;
+          if (!g.more || k + 1 >= n) break;
+          k++;
+        }
         const bool neg = f.op == BIOSCAN_OP_NOT_IN;
-        ok = hit ? !neg : (!f.has_null && neg);
+        ok = hit ? !neg : (!has_null && neg);
       } break;
     }
     if (!ok) return false;

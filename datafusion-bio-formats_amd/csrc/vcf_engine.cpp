@@ -52,12 +52,12 @@ static void throw_vcf_err(uint32_t e) {
     case VERR_MISSING_START: throw Error("Missing variant start");
     case VERR_BAD_END: throw Error("VCF read error: invalid INFO END value");
     case VERR_BAD_QUAL: throw Error("VCF qual error: invalid float literal");
-    case VERR_FLOAT_PRECISION: throw Error("VCF read error: float literal needs arbitrary-precision parsing (not supported on device)");
+    case VERR_FLOAT_PRECISION: throw Error("VCF read error: float literal with more than 19 significant digits lies on a rounding boundary of f32 (needs arbitrary-precision parsing: not supported on device)");
     case VERR_DUP_INFO_KEY: throw Error("VCF read error: duplicate INFO key in one record");
     case VERR_BAD_INT: throw Error("Error reading INFO / FORMAT field: invalid integer");
     case VERR_BAD_FLOAT: throw Error("Error reading INFO / FORMAT field: invalid float literal");
     case VERR_INVALID_FLAG: throw Error("Error reading INFO field: invalid flag");
-    case VERR_PERCENT: throw Error("VCF read error: percent-encoded byte >= 0x80 in a string value (not supported on device)");
+    case VERR_PERCENT: throw Error("VCF read error: invalid UTF-8 after percent-decoding a string value");
     case VERR_BAD_GT: throw Error("Error reading FORMAT field 'GT': invalid genotype");
     default: throw Error("VCF read error: device error " + std::to_string(e));
   }
@@ -773,9 +773,10 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
           if (!num(f.values[0], &tm.vals[0]) || !num(f.values[1], &tm.vals[1])) continue;
           tm.n_vals = 2;
         } else {
-          if (f.values.size() > 8) throw Error("IN list longer than 8 literals is not supported by the device filter");
+          // eight literals per term; a longer list continues in the following terms (`more`)
           int k = 0;
           for (auto& l : f.values) {
+            if (k == 8) { tm.n_vals = 8; tm.more = 1; terms.push_back(tm); tm.has_null = 0; tm.more = 0; k = 0; }
             if (is_str) {
               if (l.kind == BIOSCAN_LIT_NULL) tm.has_null = 1;
               else if (l.kind == BIOSCAN_LIT_STR) put_str(k++, l.s);

@@ -35,6 +35,8 @@ struct VcfFilterTerm {
   int32_t op;        // bioscan_filter_op
   int32_t n_vals;
   int32_t has_null;
+  int32_t more;      // [NOT] IN only: the next term holds further literals of the same list
+  int32_t pad_;
   double vals[8];
   uint32_t str_off[8], str_len[8];  // into the string blob (string fields)
 };

@@ -214,8 +214,24 @@ __device__ __forceinline__ bool ci_eq(const uint8_t* p, uint32_t len, const char
   }
   return i == len;
 }
+// f64 -> f32, round to nearest even, on the bit patterns: results below 2^-126 come out as the exact subnormal whatever
+// the denormal mode of the float pipeline is (INFO fields carry p-values like 3.1e-42).
+__device__ __forceinline__ float f64_to_f32_rne(double d) {
+  const uint64_t b = (uint64_t)__double_as_longlong(d);
+  const uint32_t sign = (uint32_t)(b >> 63) << 31;
+  const int e = (int)((b >> 52) & 0x7FF) - 1023;
+  if (e >= -126) return (float)d;                       // normal range (or inf / nan / zero handled by the conversion)
+  if (((b >> 52) & 0x7FF) == 0) return __uint_as_float(sign);  // zero / f64 subnormal: far below 2^-149
+  const uint64_t mant = (b & ((1ull << 52) - 1)) | (1ull << 52);
+  const int s = -(e + 97);                              // value = mant * 2^(e - 52) = q * 2^-149 with q = mant >> s
+  if (s > 54) return __uint_as_float(sign);             // below half the smallest subnormal
+  const uint64_t q = mant >> s, rest = mant & ((1ull << s) - 1), half = 1ull << (s - 1);
+  const uint64_t r = q + ((rest > half || (rest == half && (q & 1))) ? 1 : 0);
+  return __uint_as_float(sign | (uint32_t)r);           // r == 2^23 is the smallest normal: the same encoding
+}
 // Correctly rounded decimal -> f32 (what Rust's `str::parse::<f32>` returns).  0 ok; 1 malformed;
-// 2 needs arbitrary precision (reported as an error, never guessed).
+// 2 needs arbitrary precision: more than 19 significant digits AND within one part in 2^52 of a rounding boundary
+// (reported as an error, never guessed).
 __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
   uint32_t i = 0;
   bool neg = false;
@@ -283,8 +299,7 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
     }
     if (sticky && (q & 0x7F) == 0x7F) return 2;  // dropped digits could carry into the rounding position
     if (rem || sticky) q |= 1ull;
-    r = ldexpf((float)q, dz - lz - 32);
-    if (r != 0.0f && fabsf(r) < 1.1754944e-38f) return 2;  // subnormal result: not handled
+    r = ldexpf((float)q, dz - lz - 32);  // m >= 1 and 10^k <= 10^19: never below 1e-19, far from the subnormal range
   } else {
     double d = (double)m;
     int64_t e = e10;
@@ -294,9 +309,8 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
     if (e >= 0) d *= P10D[e]; else d /= P10D[-e];
     kerr += 0.5;
     const double eps = (kerr + 0.5) * 2.220446049250313e-16;
-    const float flo = (float)(d * (1.0 - eps)), fhi = (float)(d * (1.0 + eps));
-    if (flo != fhi) return 2;
-    if (fhi != 0.0f && fabsf(fhi) < 1.1754944e-38f) return 2;  // subnormal result: not handled
+    const float flo = f64_to_f32_rne(d * (1.0 - eps)), fhi = f64_to_f32_rne(d * (1.0 + eps));
+    if (__float_as_uint(flo) != __float_as_uint(fhi)) return 2;
     r = fhi;
   }
   *out = neg ? -r : r;
@@ -311,18 +325,45 @@ __device__ __forceinline__ int hexval(uint32_t c) {
   return -1;
 }
 // length of [p, p+l) after percent-decoding (noodles decodes INFO / FORMAT strings; malformed escapes stay as they are).
-// Sets *pct when an escape was decoded; decoded bytes >= 0x80 would need UTF-8 validation and are refused.
+// Sets *pct when an escape was decoded.  An escape may produce a byte >= 0x80: the decoded value then has to be valid
+// UTF-8 as a whole (percent_decode(..).decode_utf8() in noodles), otherwise the record is an error.
 __device__ uint32_t pct_decoded_len(const uint8_t* p, uint32_t l, bool* pct, uint32_t* err) {
   uint32_t out = 0;
+  bool high = false;
   for (uint32_t k = 0; k < l; k++, out++) {
     if (p[k] == '%' && k + 2 < l) {
       const int h = hexval(p[k + 1]), lo = hexval(p[k + 2]);
       if (h >= 0 && lo >= 0) {
-        if (h >= 8) set_err(err, VERR_PERCENT);
+        if (h >= 8) high = true;
         *pct = true;
         k += 2;
       }
     }
+  }
+  if (high) {
+    // second walk: UTF-8 validation of the decoded bytes (Unicode 15 table 3-7: no overlongs, no surrogates, <= U+10FFFF)
+    uint32_t need = 0, lo_b = 0x80, hi_b = 0xBF;
+    bool ok = true;
+    for (uint32_t k = 0; k < l && ok; k++) {
+      uint32_t c = p[k];
+      if (c == '%' && k + 2 < l) {
+        const int h = hexval(p[k + 1]), lo = hexval(p[k + 2]);
+        if (h >= 0 && lo >= 0) { c = (uint32_t)(h * 16 + lo); k += 2; }
+      }
+      if (need) {
+        ok = c >= lo_b && c <= hi_b;
+        need--; lo_b = 0x80; hi_b = 0xBF;
+      } else if (c < 0x80) {
+      } else if (c >= 0xC2 && c <= 0xDF) { need = 1; }
+      else if (c == 0xE0) { need = 2; lo_b = 0xA0; }
+      else if ((c >= 0xE1 && c <= 0xEC) || c == 0xEE || c == 0xEF) { need = 2; }
+      else if (c == 0xED) { need = 2; hi_b = 0x9F; }
+      else if (c == 0xF0) { need = 3; lo_b = 0x90; }
+      else if (c >= 0xF1 && c <= 0xF3) { need = 3; }
+      else if (c == 0xF4) { need = 3; hi_b = 0x8F; }
+      else ok = false;
+    }
+    if (!ok || need) set_err(err, VERR_PERCENT);
   }
   return out;
 }
@@ -428,11 +469,18 @@ __device__ bool eval_terms(const VcfFilterTerm* __restrict__ terms, int n_terms,
       const bool bt = nv >= T.vals[0] && nv <= T.vals[1];
       ok = T.op == BIOSCAN_OP_BETWEEN ? bt : !bt;
     } else {
+      // a list longer than eight literals spans consecutive terms (`more`): the verdict is taken over the whole list
       const bool neg = T.op == BIOSCAN_OP_NOT_IN;
-      bool hit = false;
-      for (int k = 0; k < T.n_vals && !hit; k++)
-        hit = is_str ? bytes_eq(sv, sl, strs + T.str_off[k], T.str_len[k]) : nv == T.vals[k];
-      ok = hit ? !neg : (!T.has_null && neg);
+      bool hit = false, has_null = false;
+      for (;;) {
+        const VcfFilterTerm& Gt = terms[t];
+        for (int k = 0; k < Gt.n_vals && !hit; k++)
+          hit = is_str ? bytes_eq(sv, sl, strs + Gt.str_off[k], Gt.str_len[k]) : nv == Gt.vals[k];
+        has_null = has_null || Gt.has_null;
+        if (!Gt.more || t + 1 >= n_terms) break;
+        t++;
+      }
+      ok = hit ? !neg : (!has_null && neg);
     }
     if (!ok) return false;
   }

@@ -81,8 +81,17 @@ EXPORTED_SYMBOLS = [
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
     "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
     "bioscan_scan_devices", "bioscan_plan_partition_device", "bioscan_plan_make_resident", "bioscan_provider_resident_range",
-    "bioscan_debug_shard_partitions",
+    "bioscan_debug_shard_partitions", "bioscan_debug_extract_regions",
 ]
+
+
+def debug_extract_regions(filters, zero_based: bool = True) -> str:
+    """The C++ planner's extract_genomic_regions on (column, op, value) filters (host only)."""
+    filters = list(filters)
+    arr, keep = _make_filters(filters)
+    buf = C.create_string_buffer(1 << 14)
+    load_library().bioscan_debug_extract_regions(arr, len(filters), 1 if zero_based else 0, buf, 1 << 14)
+    return buf.value.decode()
 
 
 def debug_shard_partitions(weights, world: int):
@@ -135,6 +144,7 @@ def load_library():
     lib.bioscan_plan_partition_device.argtypes = [C.c_void_p, C.c_int32]
     lib.bioscan_plan_make_resident.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     lib.bioscan_provider_resident_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bioscan_debug_extract_regions.argtypes = [C.POINTER(_Filter), C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
     lib.bioscan_debug_shard_partitions.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     _lib = lib
     return lib

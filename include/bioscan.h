@@ -258,6 +258,9 @@ int32_t bioscan_debug_balance_partitions(int32_t n, const char* const* chroms, c
 int32_t bioscan_debug_plan_full_scan(const char* bai_path, int32_t n_ref, const char* const* ref_names,
                                      const int64_t* ref_lengths, int32_t target_partitions, char* buf, int32_t cap);
 
+/* extract_genomic_regions + is_genomic_coordinate_filter (bio-format-core/src/genomic_filter.rs:51-147) on caller-supplied
+ * filters: "chrom:start-end;...|unsat=0|genomic=N|residual=M" (regions 1-based inclusive, empty bound = None). */
+int32_t bioscan_debug_extract_regions(const bioscan_filter* filters, int32_t n_filters, int32_t zero_based, char* buf, int32_t cap);
 /* partition_byte_ranges_in_order (bio-format-core/src/range_planning.rs:147-195) on per-partition byte estimates:
  * run_of[i] = index of the contiguous run (device / rank) partition i belongs to; returns the number of runs. */
 int32_t bioscan_debug_shard_partitions(const uint64_t* weights, int32_t n, int32_t world, int32_t* run_of);

@@ -880,10 +880,15 @@ def _num(v):
 
 
 def evaluate_record_filters(fields: dict, filters, string_fields=("chrom",),
-                            num_fields=("start", "end", "mapping_quality", "flags")) -> bool:
+                            num_fields=("start", "end", "mapping_quality", "flags"), null_fields=()) -> bool:
     """record_filter.rs:57-283 with BamRecordFields (storage.rs:456-494): `chrom` is the only
-    string field; start/end/mapping_quality/flags are u32 fields; anything else passes."""
+    string field; start/end/mapping_quality/flags are u32 fields; anything else passes.
+    null_fields: the accessor's `is_null_field` (record_filter.rs:87, 120, 153) -- a column the record reports as NULL
+    fails every comparison, BETWEEN and [NOT] IN.  BamRecordFields never reports one (a missing value simply has no
+    accessor and passes); VCF records do."""
     for col, op, val in filters:
+        if col in null_fields and op in ("=", "!=", "<", "<=", ">", ">=", "between", "not between", "in", "not in"):
+            return False
         if op in ("=", "!=", "<", "<=", ">", ">="):
             if val is None:
                 return False

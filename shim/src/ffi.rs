@@ -170,6 +170,7 @@ unsafe extern "C" {
                                             target_partitions: i32, buf: *mut c_char, cap: i32) -> i32;
     pub fn bioscan_debug_plan_full_scan(bai_path: *const c_char, n_ref: i32, ref_names: *const *const c_char,
                                         ref_lengths: *const i64, target_partitions: i32, buf: *mut c_char, cap: i32) -> i32;
+    pub fn bioscan_debug_extract_regions(filters: *const bioscan_filter, n_filters: i32, zero_based: i32, buf: *mut c_char, cap: i32) -> i32;
     pub fn bioscan_debug_shard_partitions(weights: *const u64, n: i32, world: i32, run_of: *mut i32) -> i32;
     pub fn bioscan_device_check(device_id: i32, name_buf: *mut c_char, cap: i32) -> c_int;
 }

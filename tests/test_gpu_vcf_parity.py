@@ -294,7 +294,8 @@ def test_float_parse_fuzz(pkg, tmp_path):
     """decimal -> f32 on the device must equal the correctly rounded value (Rust `str::parse::<f32>`)."""
     rnd = random.Random(12)
     vals = ["0", "0.0", "1", "-1", "0.1", "0.3", "1e-5", "1E5", "3.4028235e38", "1.17549435e-38", "16777217", "0.998595",
-            "1e39", "1e-60", "123456789012345678901234567890", "0.000000000000000000001", "+5.5", "5.", ".5", "nan", "inf", "-Infinity"]
+            "1e39", "1e-60", "123456789012345678901234567890",
+            "1e-40", "3.1e-42", "1.4e-45", "1e-46", "7e-46", "7.1e-46", "1.1754942e-38", "-2.5e-44", "0.00000000000000000000000000000000000000000314", "0.000000000000000000001", "+5.5", "5.", ".5", "nan", "inf", "-Infinity"]
     for _ in range(6000):
         kind = rnd.random()
         if kind < 0.4:
@@ -336,7 +337,8 @@ def test_vcf_errors_are_loud(pkg, tmp_path):
     assert run("c\t5\t.\tA\tT\t.\t.\tDP=3\n")["DP"] == [3]
     for body, msg in (("c\t5\t.\tA\tT\t.\t.\tDP=x\n", "invalid integer"),
                       ("c\t5\t.\tA\tT\t.\t.\tDP=1;DP=2\n", "duplicate INFO key"),
-                      ("c\t5\t.\tA\tT\t.\t.\tS=a%C3%A9\n", "percent-encoded byte"),
+                      ("c\t5\t.\tA\tT\t.\t.\tS=a%C3%28\n", "invalid UTF-8"),      # an escape that does not decode to UTF-8
+                      ("c\t5\t.\tA\tT\t.\t.\tS=a%ED%A0%80\n", "invalid UTF-8"),   # a surrogate
                       ("c\t5\t.\tA\tT\tbad\t.\tDP=1\n", "qual"),
                       ("c\t0\t.\tA\tT\t.\t.\tDP=1\n", "Missing variant start"),
                       ("c\tx\t.\tA\tT\t.\t.\tDP=1\n", "position"),
@@ -368,13 +370,16 @@ def test_percent_decoding(pkg, vo, tmp_path):
             "##FORMAT=<ID=FT,Number=1,Type=String,Description=\"f\">\n"
             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tA\tB\n"
             "c\t5\t.\tA\tT\t.\t.\tS=a%3Bb%3Dc;L=x%2Cy,.,%25z\tGT:FT\t0/1:p%3Aq\t1/1:.\n"
-            "c\t6\t.\tA\tT\t.\t.\tS=plain;L=%zz,100%\tGT:FT\t0/0:ok\t./.:%41\n")
+            "c\t6\t.\tA\tT\t.\t.\tS=plain;L=%zz,100%\tGT:FT\t0/0:ok\t./.:%41\n"
+            "c\t7\t.\tA\tT\t.\t.\tS=caf%C3%A9;L=%E2%82%AC,%F0%9F%A7%AC\tGT:FT\t0/0:%C3%9F\t./.:x\n")
     p = tmp_path / "pct.vcf"
     p.write_text(text)
-    assert _parity(pkg, vo, str(p), {}, exact_batches=False) == 2
+    assert _parity(pkg, vo, str(p), {}, exact_batches=False) == 3
     t = GpuTable(pkg, str(p))
     r = t.read(["S", "L", "genotypes"])
-    assert r["S"] == ["a;b=c", "plain"] and r["L"] == [["x,y", None, "%z"], ["%zz", "100%"]]
+    # escapes >= 0x80 are fine as long as the decoded value is UTF-8 (noodles: percent_decode(..).decode_utf8())
+    assert r["S"] == ["a;b=c", "plain", "caf\u00e9"] and r["L"] == [["x,y", None, "%z"], ["%zz", "100%"], ["\u20ac", "\U0001f9ec"]]
+    assert r["genotypes"][2]["FT"] == ["\u00df", "x"]
     assert r["genotypes"][0]["FT"] == ["p:q", None] and r["genotypes"][1]["FT"] == ["ok", "A"]
 
 
