@@ -17,7 +17,7 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
                                                        const uint64_t* __restrict__ blk_coff,
                                                        const uint64_t* __restrict__ blk_uoff,
                                                        const uint8_t* __restrict__ out_all, uint32_t n_blocks,
-                                                       uint32_t* status) {
+                                                       uint32_t* status, uint32_t* __restrict__ store) {
   __shared__ uint32_t T[16][256];
   {
     uint32_t c = threadIdx.x;
@@ -36,8 +36,11 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
   if (b >= n_blocks) return;
   const uint8_t* p = out_all + blk_uoff[b];
   uint32_t n = (uint32_t)(blk_uoff[b + 1] - blk_uoff[b]);
-  const uint8_t* tr = comp + blk_coff[b + 1] - 8;
-  const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+  uint32_t want = 0;
+  if (!store) {  // validation mode: the CRC32 field of the member's trailer
+    const uint8_t* tr = comp + blk_coff[b + 1] - 8;
+    want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+  }
   uint32_t c = 0xFFFFFFFFu;
   while (n && ((uintptr_t)p & 15)) { c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF]; n--; }
   // slice-by-16: one 16-byte load per step, 16 table lookups of which only 4 depend on the running CRC
@@ -63,12 +66,20 @@ __global__ __launch_bounds__(CRC_T) void k_bgzf_crc32(const uint8_t* __restrict_
   n &= 15;
   while (n--) c = (c >> 8) ^ T[0][(c ^ *p++) & 0xFF];
   c ^= 0xFFFFFFFFu;
-  if (c != want && status[b] == INF_OK) status[b] = INF_CRC_MISMATCH;
+  if (store) store[b] = c;  // write path: the value that goes into the trailer of member b
+  else if (c != want && status[b] == INF_OK) status[b] = INF_CRC_MISMATCH;
 }
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, const uint8_t* out,
                        uint32_t n_blocks, uint32_t* status, hipStream_t st) {
   if (!n_blocks) return;
-  hipLaunchKernelGGL(k_bgzf_crc32, dim3((n_blocks + CRC_T - 1) / CRC_T), dim3(CRC_T), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status);
+  hipLaunchKernelGGL(k_bgzf_crc32, dim3((n_blocks + CRC_T - 1) / CRC_T), dim3(CRC_T), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status,
+                     (uint32_t*)nullptr);
+}
+// write path: crc[b] = CRC32 of payload[off[b] .. off[b + 1])
+void launch_crc32_store(const uint8_t* payload, const uint64_t* off, uint32_t n_members, uint32_t* crc, hipStream_t st) {
+  if (!n_members) return;
+  hipLaunchKernelGGL(k_bgzf_crc32, dim3((n_members + CRC_T - 1) / CRC_T), dim3(CRC_T), 0, st, (const uint8_t*)nullptr, (const uint64_t*)nullptr,
+                     off, payload, n_members, (uint32_t*)nullptr, crc);
 }
 
 }  // namespace bioscan

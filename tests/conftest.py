@@ -45,6 +45,26 @@ def scratch_dir(need_bytes):
     pytest.skip("no scratch space for %d MB" % (need_bytes >> 20))
 
 
+def full_size_blocks(full: int, fallback: int, bytes_per_block: int = 27000) -> int:
+    """Member count of a large-input property test: BIOSCAN_TEST_LARGE_BLOCKS when set, else the BASELINE.json size
+    (`full`) when /dev/shm or /tmp can hold the file with room to spare and the box has the cores to generate it in well
+    under a minute, else `fallback`."""
+    env = os.environ.get("BIOSCAN_TEST_LARGE_BLOCKS")
+    if env:
+        return int(env)
+    if (os.cpu_count() or 1) < 16:
+        return fallback
+    for cand in ("/dev/shm", "/tmp"):
+        try:
+            if os.path.isdir(cand) and os.access(cand, os.W_OK):
+                v = os.statvfs(cand)
+                if v.f_bavail * v.f_frsize > full * bytes_per_block * 2:
+                    return full
+        except OSError:
+            pass
+    return fallback
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -91,11 +91,12 @@ def test_multi_gpu_sharding_reproduces_single_gpu_order(pkg, synth):
 
 
 def test_large_file_properties(pkg):
-    """Size-independent properties on a file too large for a value-by-value comparison (65 536 members by default;
+    """Size-independent properties on a file too large for a value-by-value comparison (650 000 members = BASELINE config 2 when the scratch space allows, else 65 536;
     BIOSCAN_TEST_LARGE_BLOCKS=650000 is BASELINE.json's config 2): every member's CRC32 and ISIZE hold (K2 / K1 gates,
     a failure raises), the record chain ends exactly at the end of the inflated stream, every record the generator wrote
     comes back, a second run gives the same totals, and the BAI plan returns the same number of rows in total."""
-    blocks = int(os.environ.get("BIOSCAN_TEST_LARGE_BLOCKS", "65536"))
+    from conftest import full_size_blocks
+    blocks = full_size_blocks(650000, 65536)
     exe = os.path.join(ROOT, "tools", "_build", "synth_bam")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
@@ -116,6 +117,11 @@ def test_large_file_properties(pkg):
             assert again[k] == first[k], k
         count = prov.scan(projection=[], target_partitions=1).execute_device(0, 8192)
         assert count["n_rows"] == meta["n_records"]
+        # the host stream (chunk pipeline, D2H overlapped, batches stitched across chunks): every row, batches of exactly
+        # 8192 rows except the last
+        drained = plan.execute_drain(0, 8192)
+        assert drained["n_rows"] == meta["n_records"]
+        assert drained["n_batches"] == (meta["n_records"] + 8191) // 8192
         del prov, plan
         indexed = pkg.BamTableProvider(path)
         iplan = indexed.scan(projection=[0, 2], target_partitions=8)

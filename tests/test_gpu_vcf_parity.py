@@ -213,6 +213,29 @@ def test_synth_samples_parity(pkg, vo, tmp_path):
     _parity(pkg, vo, path, {}, names=["chrom", "AF"], target=2)   # FORMAT not projected: plain batch size
 
 
+def test_thousand_sample_parity(pkg, vo, tmp_path):
+    """BASELINE.json config 4's shape -- 1000 samples, FORMAT GT:GQ:DP -- value by value against the oracle (the
+    reference's adaptive batch sizing makes batch boundaries irreproducible there, so rows are compared per partition),
+    plus the list UDFs on the GQ / DP lists of those rows."""
+    path = str(tmp_path / "s1000.vcf.gz")
+    _synth(tmp_path, "samples", path, 90, 1000, 23)
+    assert _parity(pkg, vo, path, {}, target=1, exact_batches=False) == 90
+    assert _parity(pkg, vo, path, {}, target=4, exact_batches=False) == 90
+    _parity(pkg, vo, path, {"format_fields": ["DP", "GT"]}, names=["chrom", "start", "genotypes"], target=3, exact_batches=False)
+    g = pkg.VcfTableProvider(path)
+    o = vo.VcfOracle(path)
+    gi = g.schema().get_field_index("genotypes")
+    rows = pa.Table.from_batches(list(g.scan(projection=[gi]).execute(0, 8192)))
+    st = rows.column("genotypes").combine_chunks()
+    gq, dp = st.field("GQ"), st.field("DP")
+    assert len(gq) == 90 and all(len(x) == 1000 for x in gq.to_pylist())
+    want_avg = [None if not [v for v in r if v is not None] else sum(float(v) for v in r if v is not None) / len([v for v in r if v is not None])
+                for r in gq.to_pylist()]
+    assert pkg.list_avg(gq).to_pylist() == want_avg                        # udfs.rs:67-110, sequential f64 accumulation
+    assert pkg.list_gte(dp, 10).to_pylist() == [[None if v is None else v >= 10 for v in r] for r in dp.to_pylist()]
+    assert pkg.list_lte(dp, 200).to_pylist() == [[None if v is None else v <= 200 for v in r] for r in dp.to_pylist()]
+
+
 def test_list_udfs_host(pkg, vo):
     rnd = random.Random(3)
     L = pa.list_(pa.field("item", pa.int32(), True))
