@@ -1,0 +1,391 @@
+// bam_write.hip -- the write side of the BAM path on gfx950: Arrow columns -> BAM records -> BGZF members.
+//
+// Replaces, for local BAM output, the reference's batch_to_alignment_records
+// (bio-format-core/src/sam_record_serializer.rs:15-258) + noodles-bam's record encoder + noodles-bgzf's Writer
+// (bio-format-bam/src/writer.rs, serializer.rs, write_exec.rs).  Three stages, all integer / byte work (no MFMA):
+//   serialize  one row per lane: record sizes (pass 1), exclusive scan, record bytes (pass 2) -- header fields, read name,
+//              CIGAR parsed from its string (or copied when binary), 4-bit packed bases, qualities minus 33;
+//   crc32      one member per lane (k_bgzf_crc32 in store mode);
+//   deflate    one BGZF member (<= 65280 payload bytes) per wavefront: 64 positions per step, a 4096-entry hash table of
+//              3-byte prefixes in LDS proposes one candidate per lane (+ the distance-1 candidate for runs), lanes measure
+//              their matches, a scalar walk picks the greedy parse of the 64 positions, the chosen tokens are coded with
+//              the FIXED Huffman code (RFC 1951 3.2.6), their bit offsets come from a wave prefix sum and the bits are
+//              OR-ed into an LDS staging window that is flushed as whole dwords.  A member whose fixed-Huffman form would
+//              be larger than the payload is written as a stored block, so a member never exceeds 64 KiB.
+// Every member is valid BGZF (gzip header with the BC subfield, CRC32, ISIZE): zlib, libdeflate and K1 read it back.
+#include "kernels.h"
+
+namespace bioscan {
+
+#define WAVE 64
+
+struct __attribute__((packed, aligned(1))) bw_u32 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) bw_u64 { uint64_t v; };
+struct __attribute__((packed, aligned(1))) bw_u16 { uint16_t v; };
+__device__ __forceinline__ void bw_st32(uint8_t* p, uint32_t v) { ((bw_u32*)p)->v = v; }
+__device__ __forceinline__ void bw_st16(uint8_t* p, uint32_t v) { ((bw_u16*)p)->v = (uint16_t)v; }
+
+__device__ __forceinline__ bool bit_valid(const uint8_t* bits, int64_t i) { return !bits || ((bits[i >> 3] >> (i & 7)) & 1); }
+
+// =================================================================================================================
+// serializer
+// =================================================================================================================
+__device__ __forceinline__ int cigar_op_code(uint8_t c) {
+  switch (c) {
+    case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4;
+    case 'H': return 5; case 'P': return 6; case '=': return 7; case 'X': return 8;
+    default: return -1;
+  }
+}
+// number of ops of a CIGAR string (-1: malformed); "*" and "" are the empty CIGAR (sam_record_serializer.rs:225-237)
+__device__ int cigar_count_ops(const uint8_t* s, int32_t l) {
+  if (l == 0 || (l == 1 && s[0] == '*')) return 0;
+  int n = 0;
+  bool digits = false;
+  for (int32_t k = 0; k < l; k++) {
+    const uint8_t c = s[k];
+    if (c >= '0' && c <= '9') { digits = true; continue; }
+    if (!digits || cigar_op_code(c) < 0) return -1;
+    digits = false;
+    n++;
+  }
+  return digits ? -1 : n;
+}
+
+// samtools / SAM spec 5.3 reg2bin on a 0-based half-open interval
+__device__ __forceinline__ uint32_t reg2bin(int64_t beg, int64_t end) {
+  --end;
+  if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+
+struct SerRow {
+  uint32_t lrn, ncig, lseq, lqual;
+  bool star_name;
+  const uint8_t *name, *cigar, *seq, *qual;
+  int32_t lname, lcigar;
+};
+__device__ __forceinline__ SerRow ser_row(const SerCols& c, uint64_t i, uint32_t* err) {
+  SerRow r;
+  const int64_t j = (int64_t)i + c.offset;
+  const int32_t n0 = c.name_off[j], n1 = c.name_off[j + 1];
+  r.name = c.name + n0; r.lname = n1 - n0;
+  // a NULL name and "*" are the missing name (sam_record_serializer.rs:131-135): "*\0" on disk
+  r.star_name = !bit_valid(c.name_valid, j) || (r.lname == 1 && r.name[0] == '*') || r.lname == 0;
+  r.lrn = r.star_name ? 2u : (uint32_t)r.lname + 1u;
+  if (r.lrn > 255u) atomicExch(err, 4u);
+  const int32_t c0 = c.cigar_off[j], c1 = c.cigar_off[j + 1];
+  r.cigar = c.cigar + c0; r.lcigar = c1 - c0;
+  if (c.cigar_binary) {
+    if (r.lcigar & 3) atomicExch(err, 2u);
+    r.ncig = (uint32_t)r.lcigar >> 2;
+  } else {
+    const int n = cigar_count_ops(r.cigar, r.lcigar);
+    if (n < 0) atomicExch(err, 2u);
+    r.ncig = n < 0 ? 0u : (uint32_t)n;
+  }
+  if (r.ncig > 65535u) atomicExch(err, 5u);
+  const int32_t s0 = c.seq_off[j], s1 = c.seq_off[j + 1];
+  r.seq = c.seq + s0;
+  r.lseq = (uint32_t)(s1 - s0);
+  if (r.lseq == 1 && r.seq[0] == '*') r.lseq = 0;
+  const int32_t q0 = c.qual_off[j], q1 = c.qual_off[j + 1];
+  r.qual = c.qual + q0;
+  r.lqual = (uint32_t)(q1 - q0);
+  if (r.lqual == 1 && r.qual[0] == '*') r.lqual = 0;
+  // noodles' encoder: qualities are either absent (0xFF fill) or exactly one per base
+  if (r.lqual != 0 && r.lqual != r.lseq) atomicExch(err, 3u);
+  if (c.flags[j] > 65535u) atomicExch(err, 1u);  // "does not fit into 16-bit SAM flags" (serializer.rs:117-122)
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_ser_sizes(SerCols c, uint64_t n, uint32_t* __restrict__ rec_bytes, uint32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const SerRow r = ser_row(c, i, err);
+  rec_bytes[i] = 4u + 32u + r.lrn + 4u * r.ncig + ((r.lseq + 1u) >> 1) + r.lseq;
+}
+
+__global__ __launch_bounds__(256) void k_ser_write(SerCols c, uint64_t n, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out,
+                                                   uint32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t dummy = 0;
+  (void)dummy;
+  const SerRow r = ser_row(c, i, err);
+  const int64_t j = (int64_t)i + c.offset;
+  uint8_t* o = out + rec_off[i];
+  const uint32_t block_size = 32u + r.lrn + 4u * r.ncig + ((r.lseq + 1u) >> 1) + r.lseq;
+  const int32_t refid = c.refid[i], nref = c.mate_refid[i];
+  int32_t pos = -1, npos = -1;
+  if (bit_valid(c.start_valid, j)) {
+    const uint32_t v = c.start[j];
+    const int64_t p1 = c.zero_based ? (int64_t)v + 1 : (int64_t)v;   // 1-based; 0 is not a position (None)
+    pos = p1 >= 1 ? (int32_t)(p1 - 1) : -1;
+  }
+  if (bit_valid(c.mate_start_valid, j)) {
+    const uint32_t v = c.mate_start[j];
+    const int64_t p1 = c.zero_based ? (int64_t)v + 1 : (int64_t)v;
+    npos = p1 >= 1 ? (int32_t)(p1 - 1) : -1;
+  }
+  // CIGAR ops (and the reference span for the bin)
+  uint8_t* cg = o + 36 + r.lrn;
+  uint64_t span = 0;
+  if (c.cigar_binary) {
+    for (uint32_t k = 0; k < r.ncig; k++) {
+      const uint32_t v = ((const bw_u32*)(r.cigar + 4 * k))->v;
+      // decode_binary_cigar_to_ops (alignment_utils.rs:985-1017): op codes 0..8, a zero length is invalid
+      if ((v & 15u) > 8u || (v >> 4) == 0u) atomicExch(err, 2u);
+      if ((0x18Du >> (v & 15u)) & 1u) span += v >> 4;
+      bw_st32(cg + 4 * k, v);
+    }
+  } else {
+    uint32_t k = 0, num = 0;
+    for (int32_t q = 0; q < r.lcigar && k < r.ncig; q++) {
+      const uint8_t ch = r.cigar[q];
+      if (ch >= '0' && ch <= '9') { num = num * 10u + (uint32_t)(ch - '0'); continue; }
+      const uint32_t op = (uint32_t)cigar_op_code(ch);
+      if (num > 0x0FFFFFFFu) atomicExch(err, 2u);
+      if ((0x18Du >> op) & 1u) span += num;
+      bw_st32(cg + 4 * k, (num << 4) | op);
+      k++;
+      num = 0;
+    }
+  }
+  const uint32_t bin = pos >= 0 ? reg2bin(pos, (int64_t)pos + (int64_t)(span ? span : 1)) : 4680u;
+  bw_st32(o, block_size);
+  bw_st32(o + 4, (uint32_t)refid);
+  bw_st32(o + 8, (uint32_t)pos);
+  o[12] = (uint8_t)r.lrn;
+  o[13] = (uint8_t)c.mapq[j];          // MappingQuality::new(v as u8): 255 = missing, written as 255
+  bw_st16(o + 14, bin);
+  bw_st16(o + 16, r.ncig);
+  bw_st16(o + 18, c.flags[j]);
+  bw_st32(o + 20, r.lseq);
+  bw_st32(o + 24, (uint32_t)nref);
+  bw_st32(o + 28, (uint32_t)npos);
+  bw_st32(o + 32, (uint32_t)c.tlen[j]);
+  uint8_t* nm = o + 36;
+  if (r.star_name) { nm[0] = '*'; nm[1] = 0; }
+  else { for (int32_t k = 0; k < r.lname; k++) nm[k] = r.name[k]; nm[r.lname] = 0; }
+  // bases: "=ACMGRSVTWYHKDBN", case-insensitive, anything else is N (noodles' sequence encoder)
+  uint8_t* sq = cg + 4 * r.ncig;
+  auto code = [](uint8_t b) -> uint32_t {
+    switch (b & 0xDF) {  // upper-case
+      case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6;
+      case 'V': return 7; case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12;
+      case 'D': return 13; case 'B': return 14; case 'N': return 15;
+      default: return b == '=' ? 0u : 15u;
+    }
+  };
+  for (uint32_t k = 0; k < r.lseq; k += 2) {
+    const uint32_t hi = code(r.seq[k]);
+    const uint32_t lo = k + 1 < r.lseq ? code(r.seq[k + 1]) : 0u;
+    sq[k >> 1] = (uint8_t)((hi << 4) | lo);
+  }
+  uint8_t* ql = sq + ((r.lseq + 1u) >> 1);
+  if (r.lqual == 0) { for (uint32_t k = 0; k < r.lseq; k++) ql[k] = 0xFF; }
+  else { for (uint32_t k = 0; k < r.lseq; k++) { const uint8_t b = r.qual[k]; ql[k] = b >= 33 ? (uint8_t)(b - 33) : 0; } }  // saturating_sub(33)
+}
+
+void launch_ser_sizes(SerCols c, uint64_t n, uint32_t* rec_bytes, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_ser_sizes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, n, rec_bytes, err);
+}
+void launch_ser_write(SerCols c, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_ser_write, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, n, rec_off, out, err);
+}
+
+// =================================================================================================================
+// BGZF deflate: one member per wavefront
+// =================================================================================================================
+constexpr int DF_HASH_BITS = 12;
+constexpr uint32_t DF_NONE = 0xFFFFu;
+constexpr int DF_WORDS = 64;  // staging window: a carried partial dword + 64 tokens of <= 31 bits = at most 63 dwords
+
+__device__ __forceinline__ uint32_t df_excl_scan(uint32_t v, int lane, uint32_t* total) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d, WAVE);
+    if (lane >= d) inc += o;
+  }
+  *total = __builtin_amdgcn_readlane(inc, 63);
+  return inc - v;
+}
+
+// common prefix length of a[0..) and b[0..), at most `cap` (reads up to 7 bytes past cap: buffers are padded)
+__device__ __forceinline__ uint32_t df_match_len(const uint8_t* a, const uint8_t* b, uint32_t cap) {
+  uint32_t k = 0;
+  while (k < cap) {
+    const uint64_t x = ((const bw_u64*)(a + k))->v ^ ((const bw_u64*)(b + k))->v;
+    if (x) { k += (uint32_t)__builtin_ctzll(x) >> 3; break; }
+    k += 8;
+  }
+  return k < cap ? k : cap;
+}
+
+__global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict__ payload, const uint64_t* __restrict__ m_off, uint32_t n_members,
+                                                        const uint32_t* __restrict__ crc, uint8_t* __restrict__ slots, uint32_t slot_stride,
+                                                        uint32_t* __restrict__ sizes) {
+  __shared__ uint16_t table[1 << DF_HASH_BITS];
+  __shared__ uint32_t W[DF_WORDS];
+  const uint32_t m = blockIdx.x;
+  if (m >= n_members) return;
+  const int lane = threadIdx.x;
+  const uint8_t* in = payload + m_off[m];
+  const uint32_t n = (uint32_t)(m_off[m + 1] - m_off[m]);
+  uint8_t* slot = slots + (uint64_t)m * slot_stride;
+  uint8_t* data = slot + 18;  // DEFLATE stream (dwords are stored unaligned: gfx950 global stores need no alignment)
+  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) table[k] = (uint16_t)DF_NONE;
+  W[lane] = lane == 0 ? 3u : 0u;   // block header: BFINAL = 1, BTYPE = 01 (fixed Huffman) -> bits 1, 1, 0
+  uint32_t carry_bits = 3;         // bits of the partial dword W[0]
+  uint32_t word_base = 0;          // dwords flushed so far
+  uint64_t total_bits = 3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t pos = 0;
+  while (pos < n) {
+    const uint32_t p = pos + (uint32_t)lane;
+    const bool inb = p < n;
+    const bool can = p + 3 <= n;
+    uint32_t v = 0;
+    if (inb) v = ((const bw_u32*)(in + p))->v;  // (the payload buffer is padded)
+    const uint32_t h = ((v & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - DF_HASH_BITS);
+    const uint32_t cand = can ? (uint32_t)table[h] : DF_NONE;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (can) table[h] = (uint16_t)p;   // lanes with equal hashes: any of them is a valid candidate for later positions
+    uint32_t best_len = 0, best_dist = 0;
+    if (can) {
+      const uint32_t cap = n - p < 258u ? n - p : 258u;
+      if (cand != DF_NONE && cand < p && p - cand <= 32768u) {
+        const uint32_t l = df_match_len(in + cand, in + p, cap);
+        if (l >= 3) { best_len = l; best_dist = p - cand; }
+      }
+      if (p >= 1) {  // runs: the previous byte (positions of this very step are not in the table yet)
+        const uint32_t l = df_match_len(in + p - 1, in + p, cap);
+        if (l >= 3 && l > best_len) { best_len = l; best_dist = 1; }
+      }
+    }
+    const uint32_t tok_len = best_len >= 3 ? best_len : 1u;
+    // greedy parse of the 64 positions: a scalar walk over the lanes' token lengths
+    unsigned long long sel = 0;
+    uint32_t k = 0;
+    while (k < WAVE && pos + k < n) {
+      sel |= 1ull << k;
+      k += (uint32_t)__builtin_amdgcn_readlane((int)tok_len, (int)k);
+    }
+    const bool chosen = (sel >> lane) & 1ull;
+    // fixed Huffman code of the token, LSB-first (RFC 1951 3.2.5 / 3.2.6)
+    uint64_t bits = 0;
+    uint32_t nbits = 0;
+    if (chosen) {
+      if (best_len >= 3) {
+        const uint32_t lc = best_len - 3;
+        uint32_t sym, leb, lex;
+        if (lc == 255) { sym = 285; leb = 0; lex = 0; }
+        else if (lc < 8) { sym = 257 + lc; leb = 0; lex = 0; }
+        else { leb = (31u - (uint32_t)__builtin_clz(lc)) - 2u; sym = 261 + 4 * leb + ((lc >> leb) & 3u); lex = lc & ((1u << leb) - 1u); }
+        uint32_t lcode, llen;
+        if (sym < 280) { lcode = sym - 256; llen = 7; } else { lcode = 0xC0 + (sym - 280); llen = 8; }
+        const uint32_t dc = best_dist - 1;
+        uint32_t dsym, deb, dex;
+        if (dc < 4) { dsym = dc; deb = 0; dex = 0; }
+        else { deb = (31u - (uint32_t)__builtin_clz(dc)) - 1u; dsym = 2 * deb + 2 + ((dc >> deb) & 1u); dex = dc & ((1u << deb) - 1u); }
+        bits = (uint64_t)(__brev(lcode) >> (32 - llen));
+        nbits = llen;
+        bits |= (uint64_t)lex << nbits; nbits += leb;
+        bits |= (uint64_t)(__brev(dsym) >> 27) << nbits; nbits += 5;
+        bits |= (uint64_t)dex << nbits; nbits += deb;
+      } else {
+        const uint32_t b = v & 0xFFu;
+        if (b < 144) { bits = __brev(0x30u + b) >> 24; nbits = 8; }
+        else { bits = __brev(0x190u + (b - 144)) >> 23; nbits = 9; }
+      }
+    }
+    // bit offsets by a wave prefix sum; the bits are OR-ed into the staging window (<= 31 + 64 x 31 bits: 63 dwords)
+    uint32_t tot;
+    const uint32_t off = carry_bits + df_excl_scan(nbits, lane, &tot);
+    if (nbits) {
+      const uint32_t wi = off >> 5, lo = off & 31u;
+      atomicOr(&W[wi], (uint32_t)(bits << lo));
+      if (lo + nbits > 32) atomicOr(&W[wi + 1], (uint32_t)(bits >> (32 - lo)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t T = carry_bits + tot;
+    const uint32_t full = T >> 5;   // whole dwords: flushed; the partial one is carried into the next step
+    const uint32_t wv = W[lane];
+    if ((uint32_t)lane < full) bw_st32(data + 4ull * (word_base + (uint32_t)lane), wv);
+    const uint32_t carry_word = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)full);
+    __builtin_amdgcn_wave_barrier();
+    W[lane] = lane == 0 ? carry_word : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    word_base += full;
+    carry_bits = T & 31u;
+    total_bits += tot;
+    pos += k;
+  }
+  // END-OF-BLOCK: seven zero bits (already zero in the window); flush the tail, partial dword included
+  {
+    const uint32_t T = carry_bits + 7;
+    total_bits += 7;
+    const uint32_t full = (T + 31) >> 5;
+    if ((uint32_t)lane < full) bw_st32(data + 4ull * (word_base + (uint32_t)lane), W[lane]);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t data_bytes = (uint32_t)((total_bits + 7) >> 3);
+  if (data_bytes > n + 5u) {
+    // the fixed-Huffman form is larger than the payload: a stored block instead (BFINAL = 1, BTYPE = 00, LEN, NLEN, bytes),
+    // so that no member exceeds 64 KiB (65280 + 5 + 26 bytes)
+    if (lane == 0) { data[0] = 1; data[1] = (uint8_t)n; data[2] = (uint8_t)(n >> 8); data[3] = (uint8_t)~n; data[4] = (uint8_t)(~n >> 8); }
+    for (uint32_t q = lane; q < n; q += WAVE) data[5 + q] = in[q];
+    data_bytes = n + 5u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // gzip member header with the BGZF extra subfield, and the trailer (SAM spec 4.1)
+  const uint32_t bsize = 18u + data_bytes + 8u;
+  if (lane == 0) {
+    const uint8_t hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    for (int q = 0; q < 16; q++) slot[q] = hdr[q];
+    slot[16] = (uint8_t)(bsize - 1); slot[17] = (uint8_t)((bsize - 1) >> 8);
+    uint8_t* t = data + data_bytes;
+    const uint32_t cr = crc[m];
+    t[0] = (uint8_t)cr; t[1] = (uint8_t)(cr >> 8); t[2] = (uint8_t)(cr >> 16); t[3] = (uint8_t)(cr >> 24);
+    t[4] = (uint8_t)n; t[5] = (uint8_t)(n >> 8); t[6] = (uint8_t)(n >> 16); t[7] = (uint8_t)(n >> 24);
+    sizes[m] = bsize;
+  }
+}
+
+// members back to back: out[off[m] ..] = slot m
+__global__ __launch_bounds__(256) void k_compact_members(const uint8_t* __restrict__ slots, uint32_t slot_stride, const uint32_t* __restrict__ sizes,
+                                                          const uint64_t* __restrict__ off, uint8_t* __restrict__ out) {
+  const uint32_t m = blockIdx.x;
+  const uint8_t* s = slots + (uint64_t)m * slot_stride;
+  uint8_t* d = out + off[m];
+  const uint32_t n = sizes[m];
+  for (uint32_t k = threadIdx.x * 4; k + 4 <= n; k += 256 * 4) bw_st32(d + k, ((const bw_u32*)(s + k))->v);
+  if (threadIdx.x < (n & 3u)) d[(n & ~3u) + threadIdx.x] = s[(n & ~3u) + threadIdx.x];
+}
+
+void launch_bgzf_deflate(const uint8_t* payload, const uint64_t* m_off, uint32_t n_members, const uint32_t* crc, uint8_t* slots,
+                         uint32_t slot_stride, uint32_t* sizes, hipStream_t st) {
+  if (!n_members) return;
+  hipLaunchKernelGGL(k_bgzf_deflate, dim3(n_members), dim3(WAVE), 0, st, payload, m_off, n_members, crc, slots, slot_stride, sizes);
+}
+void launch_compact_members(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes, const uint64_t* off, uint32_t n_members,
+                            uint8_t* out, hipStream_t st) {
+  if (!n_members) return;
+  hipLaunchKernelGGL(k_compact_members, dim3(n_members), dim3(256), 0, st, slots, slot_stride, sizes, off, out);
+}
+
+}  // namespace bioscan

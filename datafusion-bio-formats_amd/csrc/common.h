@@ -54,6 +54,9 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
 }
 #define HIP_CHECK(x) ::bioscan::hip_check((x), #x, __FILE__, __LINE__)
 
+// what bioscan_last_error() returns on this thread (set by every entry point that fails)
+void set_last_error(const std::string& msg);
+
 // Environment knobs, read ONCE per process (first use).  None of them changes what a scan computes:
 //   BIOSCAN_DEBUG=1            diagnostics on stderr (K1 pass counters, record-chain rounds)
 //   BIOSCAN_LAPS=1             host wall-clock laps of execute() on stderr

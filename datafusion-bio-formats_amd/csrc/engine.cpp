@@ -30,6 +30,7 @@ static thread_local std::string g_err;
 
 // ---- device allocation cache (see common.h) -------------------------------------------------------
 namespace bioscan {
+void set_last_error(const std::string& msg) { g_err = msg; }
 const EnvKnobs& env_knobs() {
   static const EnvKnobs k = [] {
     EnvKnobs v;

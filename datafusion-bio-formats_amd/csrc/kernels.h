@@ -127,6 +127,34 @@ void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, R
                            const uint32_t* ref_name_off, const uint32_t* ref_name_len, int32_t n_ref, int32_t binary_cigar,
                            uint32_t batch_size, uint32_t phase, const uint64_t* tile_sums, uint32_t* qual_wide, hipStream_t st);
 
+// ---- bam_write.hip: Arrow columns -> BAM records -> BGZF members (the write side of the path) -----------------
+struct SerCols {   // one RecordBatch on the device, Arrow layouts as uploaded; `offset` = the arrays' logical offset
+  int64_t offset;
+  const int32_t* name_off; const uint8_t* name; const uint8_t* name_valid;
+  const int32_t* cigar_off; const uint8_t* cigar; int32_t cigar_binary;
+  const int32_t* seq_off; const uint8_t* seq;
+  const int32_t* qual_off; const uint8_t* qual;
+  const uint32_t* start; const uint8_t* start_valid;
+  const uint32_t* flags; const uint32_t* mapq;
+  const uint32_t* mate_start; const uint8_t* mate_start_valid;
+  const int32_t* tlen;
+  const int32_t* refid; const int32_t* mate_refid;  // per row (index 0 = row 0 of the batch), from chrom / mate_chrom; -1 = none
+  int32_t zero_based;
+};
+// err: 1 flag > 65535, 2 malformed CIGAR, 3 quality / sequence length mismatch, 4 read name too long, 5 more than 65535 CIGAR ops
+void launch_ser_sizes(SerCols c, uint64_t n, uint32_t* rec_bytes, uint32_t* err, hipStream_t st);
+void launch_ser_write(SerCols c, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st);
+// crc[b] = CRC32 of payload[off[b] .. off[b + 1]) (k_bgzf_crc32 in store mode)
+void launch_crc32_store(const uint8_t* payload, const uint64_t* off, uint32_t n_members, uint32_t* crc, hipStream_t st);
+// one BGZF member per payload range: complete members (header, DEFLATE data, CRC32, ISIZE) in slots of `slot_stride` bytes
+// (>= BGZF_SLOT_BYTES), their sizes in sizes[]; launch_compact_members lays them back to back at out + off[m]
+constexpr uint32_t BGZF_MAX_PAYLOAD = 65280;   // what noodles-bgzf / htslib put into one member
+constexpr uint32_t BGZF_SLOT_BYTES = 81920;    // fixed-Huffman worst case (9 bits per byte) + header, trailer, slack
+void launch_bgzf_deflate(const uint8_t* payload, const uint64_t* m_off, uint32_t n_members, const uint32_t* crc, uint8_t* slots,
+                         uint32_t slot_stride, uint32_t* sizes, hipStream_t st);
+void launch_compact_members(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes, const uint64_t* off, uint32_t n_members,
+                            uint8_t* out, hipStream_t st);
+
 // ---- tags ---------------------------------------------------------------------------------------
 // loc[t*n + i] = byte offset (from record start) of the aux VALUE of requested tag t in row i,
 // typ[t*n + i] = its BAM type char (0 = absent).  tags[t] = two tag bytes little-endian.

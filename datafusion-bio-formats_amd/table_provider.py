@@ -82,6 +82,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
     "bioscan_scan_devices", "bioscan_plan_partition_device", "bioscan_plan_make_resident", "bioscan_provider_resident_range",
     "bioscan_debug_shard_partitions", "bioscan_debug_extract_regions",
+    "bioscan_bam_writer_open", "bioscan_bam_writer_write", "bioscan_bam_writer_finish", "bioscan_bam_writer_close", "bioscan_bgzf_deflate",
 ]
 
 
@@ -144,6 +145,13 @@ def load_library():
     lib.bioscan_plan_partition_device.argtypes = [C.c_void_p, C.c_int32]
     lib.bioscan_plan_make_resident.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]
     lib.bioscan_provider_resident_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bioscan_bam_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
+                                            C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_bam_writer_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bioscan_bam_writer_finish.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.bioscan_bam_writer_close.argtypes = [C.c_void_p]
+    lib.bioscan_bgzf_deflate.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_double)]
     lib.bioscan_debug_extract_regions.argtypes = [C.POINTER(_Filter), C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
     lib.bioscan_debug_shard_partitions.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     _lib = lib
@@ -662,3 +670,51 @@ def vcf_set_gts(gt: pa.Array, mask: pa.Array, replacement: str = "./.", device_i
         pa.Array._import_from_c(C.addressof(ga), C.addressof(gsch))
         pa.Array._import_from_c(C.addressof(ma), C.addressof(msch))
     return pa.Array._import_from_c(C.addressof(oa), C.addressof(os_))
+
+
+def bgzf_deflate(data: bytes, add_eof: bool = True, device_id: int = 0):
+    """K-level write path: `data` as BGZF members (<= 65280 payload bytes each) compressed on the GPU -> (bytes, kernel ms)."""
+    lib = load_library()
+    out, n, ms = C.c_void_p(), C.c_size_t(), C.c_double()
+    _check(lib.bioscan_bgzf_deflate(data, len(data), device_id, 1 if add_eof else 0, C.byref(out), C.byref(n), C.byref(ms)))
+    try:
+        return C.string_at(out, n.value), ms.value
+    finally:
+        lib.bioscan_free(out)
+
+
+class BamWriter:
+    """Mirror of BamLocalWriter (bio-format-bam/src/writer.rs:57-283): write_header at construction, write_records per
+    RecordBatch, finish.  Serialisation, CRC32 and DEFLATE run on the GPU."""
+
+    def __init__(self, path: str, header_text: str, ref_names: Sequence[str], ref_lengths: Sequence[int],
+                 coordinate_system_zero_based: bool = True, device_id: int = 0):
+        lib = load_library()
+        names = (C.c_char_p * max(len(ref_names), 1))(*[n.encode() for n in ref_names])
+        lens = (C.c_int64 * max(len(ref_lengths), 1))(*ref_lengths)
+        self._h = C.c_void_p()
+        _check(lib.bioscan_bam_writer_open(path.encode(), header_text.encode(), names, lens, len(ref_names),
+                                           1 if coordinate_system_zero_based else 0, device_id, C.byref(self._h)))
+
+    def write_records(self, batch: pa.RecordBatch):
+        arr, sch = _ArrowArray(), _ArrowSchema()
+        pa.StructArray.from_arrays(batch.columns, fields=list(batch.schema))._export_to_c(C.addressof(arr), C.addressof(sch))
+        try:
+            _check(load_library().bioscan_bam_writer_write(self._h, C.addressof(arr), C.addressof(sch)))
+        finally:
+            rel_a = C.CFUNCTYPE(None, C.c_void_p)
+            if arr.release:
+                rel_a(arr.release)(C.addressof(arr))
+            if sch.release:
+                rel_a(sch.release)(C.addressof(sch))
+
+    def finish(self) -> dict:
+        r, m, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(load_library().bioscan_bam_writer_finish(self._h, C.byref(r), C.byref(m), C.byref(b)))
+        return {"n_records": r.value, "n_members": m.value, "n_bytes": b.value}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            load_library().bioscan_bam_writer_close(h)
+            self._h = None

@@ -235,6 +235,26 @@ int bioscan_provider_resident_range(const bioscan_provider* p, int32_t device_id
 int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t batch_size,
                            bioscan_scan_stats* stats, bioscan_stream** out);
 
+/* ---- write path: BamLocalWriter (bio-format-bam/src/writer.rs:57-283) + batch_to_alignment_records
+ * (bio-format-core/src/sam_record_serializer.rs:15-258) + noodles-bgzf Writer, on the GPU ---------------------------
+ * open = new + write_header: `header_text` is the SAM header text, ref_names / ref_lengths the @SQ dictionary in order.
+ * write = write_records of one RecordBatch (a struct array holding at least name, chrom, start, flags, cigar [Utf8 or
+ * Binary], mapping_quality, mate_chrom, mate_start, sequence, quality_scores, template_length -- the reader's own
+ * schema): records are serialised, CRC32-summed and DEFLATE-compressed on the device into BGZF members of at most 65280
+ * payload bytes (fixed-Huffman blocks, stored blocks where that is smaller).  finish = the last short member, the BGZF
+ * EOF marker, close.  Errors of the reference are kept ("does not fit into 16-bit SAM flags", CIGAR parse errors).
+ * Tag columns are not written yet. */
+typedef struct bioscan_bam_writer bioscan_bam_writer;
+int bioscan_bam_writer_open(const char* path, const char* header_text, const char* const* ref_names, const int64_t* ref_lengths,
+                            int32_t n_ref, int32_t coordinate_system_zero_based, int32_t device_id, bioscan_bam_writer** out);
+int bioscan_bam_writer_write(bioscan_bam_writer* w, const struct ArrowArray* batch, const struct ArrowSchema* schema);
+int bioscan_bam_writer_finish(bioscan_bam_writer* w, uint64_t* n_records, uint64_t* n_members, uint64_t* n_bytes);
+void bioscan_bam_writer_close(bioscan_bam_writer* w);
+/* Kernel-level: compresses a host buffer into BGZF members (<= 65280 payload bytes each; + the EOF marker when add_eof)
+ * on the GPU; the result is a malloc'd host buffer (bioscan_free).  Replaces noodles-bgzf Writer + libdeflate's compress. */
+int bioscan_bgzf_deflate(const uint8_t* data, size_t len, int32_t device_id, int32_t add_eof, uint8_t** out, size_t* out_len,
+                         double* kernel_ms);
+
 /* ---- Kernel-level entry point: K1 alone (parity tests against libdeflate/zlib) ----------
  * Inflates every BGZF member of a host buffer on the GPU and returns the concatenated
  * payload in a malloc'd host buffer (caller frees with bioscan_free).

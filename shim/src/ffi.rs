@@ -19,6 +19,11 @@ pub struct bioscan_stream {
 }
 
 #[repr(C)]
+pub struct bioscan_bam_writer {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
 pub struct bioscan_bam_options {
     pub coordinate_system_zero_based: i32,
     pub tag_fields: *const *const c_char,
@@ -159,6 +164,15 @@ unsafe extern "C" {
     pub fn bioscan_provider_resident_range(p: *const bioscan_provider, device_id: i32, lo: *mut u64, hi: *mut u64) -> c_int;
     pub fn bioscan_execute_device(plan: *const bioscan_plan, partition: i32, batch_size: i32, stats: *mut bioscan_scan_stats,
                                   out: *mut *mut bioscan_stream) -> c_int;
+
+    pub fn bioscan_bam_writer_open(path: *const c_char, header_text: *const c_char, ref_names: *const *const c_char,
+                                   ref_lengths: *const i64, n_ref: i32, coordinate_system_zero_based: i32, device_id: i32,
+                                   out: *mut *mut bioscan_bam_writer) -> c_int;
+    pub fn bioscan_bam_writer_write(w: *mut bioscan_bam_writer, batch: *const FFI_ArrowArray, schema: *const FFI_ArrowSchema) -> c_int;
+    pub fn bioscan_bam_writer_finish(w: *mut bioscan_bam_writer, n_records: *mut u64, n_members: *mut u64, n_bytes: *mut u64) -> c_int;
+    pub fn bioscan_bam_writer_close(w: *mut bioscan_bam_writer);
+    pub fn bioscan_bgzf_deflate(data: *const u8, len: usize, device_id: i32, add_eof: i32, out: *mut *mut u8, out_len: *mut usize,
+                                kernel_ms: *mut f64) -> c_int;
 
     pub fn bioscan_bgzf_inflate(data: *const u8, len: usize, device_id: i32, check_crc: i32, out: *mut *mut u8,
                                 out_len: *mut usize, kernel_ms: *mut f64) -> c_int;
