@@ -363,23 +363,72 @@ constexpr uint32_t V3_DIST_BASE = 2u * ((1u << V3_LIT_BITS) + V3_LIT_SUB);
 constexpr uint32_t V3_CK_ROW = 3u * 64u;  // dwords per checkpoint index: pos[64], acc[64], state[64]
 static_assert((uint32_t)V3_CK_MAX * V3_CK_ROW == V3_CK_DWORDS, "kernels.h sizes the checkpoint scratch for V3_CK_MAX rows");
 
-// COUNT pass of this lane's sub-stream [start, limit): bytes produced [0:19] and matches [20:31] in one accumulator.
-// SPEC: the lane starts before `count_from` only to synchronise; the first symbol start at / after count_from is
-// reported (`first_out`, ~0 = never reached) and counting restarts there.
-// Every V3_CK_STEPS steps (wave-uniform counter) a lane that is on the counted part of its chain and still running
-// stores (pos, acc, tb | mb << 12 | pending match length << 16) to checkpoint row c of the wave's scratch; ck_lo / ck_n
-// give the lane's valid rows [ck_lo, ck_lo + ck_n).  Returns true (uniform) when a pass needs more than V3_CK_MAX rows:
-// the caller restarts the round with short sub-streams.
-template <bool SPEC>
-__device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, uint32_t limit, uint32_t count_from,
+// SYNC pass: a speculative lane decodes from `start` (an arbitrary bit, `ov` bits in front of its boundary) only to find the
+// symbol chain: it parks at the first symbol start at or after `count_from` and reports it.  Nothing is counted, so the
+// step needs neither the base / extra-bit values nor the accumulators of the count pass (36 instead of 40 vector
+// instructions), and because every lane then starts its count pass at its own first symbol, the checkpoint rows of all
+// lanes are aligned to the same steps.  Garbage contains END-OF-BLOCK and unassigned codes: such a stop says nothing about
+// the block, the lane carries on from the literal/length root.
+__device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t count_from, uint32_t limit, const uint32_t* __restrict__ gsrc) {
+  uint32_t pos = start;
+  const bool run0 = pos < count_from;  // a lane that starts exactly on its boundary (lane 0: the round's first bit) is there already
+  uint32_t wp = pos >> 5;
+  const uint32_t wp0 = run0 ? wp : 0u;
+  uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC(wp0 + 1), nxt = V3_SRC(wp0 + 2);
+  const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;
+  uint32_t tb = run0 ? 0u : STOP_END, mb = run0 ? (uint32_t)V3_LIT_BITS : 0u;
+  while (__ballot(tb < V3_NULL_BASE) != 0ull) {
+#ifdef V3_ASM_MARKERS
+    asm volatile("; V3LOOP_BEGIN %0" ::"n"(3));
+#endif
+    const bool in_lit = tb < V3_DIST_BASE;
+    const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
+    uint32_t e;
+    {
+      const uint32_t ea = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)T + tb + (__builtin_amdgcn_ubfe(w, 0u, mb) << 1);
+      asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(e) : "v"(ea));
+    }
+    __builtin_assume(e < 65536u);
+    const uint32_t l = e & 15u;
+    const bool ptr = e >= E_SUB;
+    const bool is_lit = e < 0x1000u;
+    const bool lenlike = __builtin_amdgcn_inverse_ballot_w64(~(__ballot(is_lit) | __ballot(ptr)));
+    const bool is_len = lenlike && in_lit;
+    const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
+    pos += ptr ? mb : l + ebv;
+    if ((pos >> 5) != wp) {
+      asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));
+      wp++;
+      nxt = V3_SRC(wp + 2);
+    }
+    // next lookup: a completed symbol at / after count_from is what the lane was looking for
+    const bool arrived = pos >= count_from;
+    uint32_t ntb = is_len ? V3_DIST_BASE : (arrived ? STOP_END : 0u);
+    uint32_t nmb = is_len ? (uint32_t)V3_DIST_BITS : (arrived ? 0u : (uint32_t)V3_LIT_BITS);
+    if (ptr) { ntb = (e >> 3) & 0xFFEu; nmb = l; }
+    if (ntb > STOP_END) { ntb = arrived ? STOP_END : 0u; nmb = arrived ? 0u : (uint32_t)V3_LIT_BITS; }  // bogus END-OF-BLOCK / bad code
+    tb = ntb; mb = nmb;
+#ifdef V3_ASM_MARKERS
+    asm volatile("; V3LOOP_END %0" ::"n"(3));
+#endif
+  }
+  (void)limit;
+  return pos;
+}
+
+// COUNT pass of this lane's sub-stream [start, limit), `start` being a symbol start: bytes produced [0:19] and matches
+// [20:31] in one accumulator.  Every V3_CK_STEPS steps (wave-uniform counter) a lane that is still running stores
+// (pos, acc, tb | mb << 12 | pending match length << 16) to checkpoint row c of the wave's scratch; ck_n = number of the
+// lane's valid rows (rows 1 .. ck_n).  Returns true (uniform) when a pass needs more than V3_CK_MAX rows: the caller
+// restarts the round with short sub-streams.
+__device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, uint32_t limit,
                                          const uint32_t* __restrict__ gsrc, uint32_t* __restrict__ ck, int lane,
-                                         uint32_t& end_out, uint32_t& acc_out, uint32_t& flags, uint32_t& first_out,
-                                         uint32_t& ck_lo, uint32_t& ck_n) {
+                                         uint32_t& end_out, uint32_t& acc_out, uint32_t& flags, uint32_t& ck_n) {
   static_assert(offsetof(V3Lds, null_slot) - offsetof(V3Lds, lit_fast) == V3_NULL_BASE, "null slots must sit at V3_NULL_BASE");
   uint32_t pos = start;
   uint32_t acc = 0;
   const bool run0 = active && pos < limit;
-  uint32_t first = (!SPEC || pos >= count_from) ? pos : 0xFFFFFFFFu;
   // (a lane that does not run keeps pos, so it never crosses a dword and never loads again: its three reads are parked at 0)
   uint32_t wp = pos >> 5;
   const uint32_t wp0 = run0 ? wp : 0u;
@@ -387,23 +436,22 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
   const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;  // dist_fast follows lit_fast in LDS
   uint32_t tb = run0 ? 0u : STOP_END, mb = run0 ? (uint32_t)V3_LIT_BITS : 0u, mlen = 0;
   uint32_t cd = V3_CK_STEPS, c = 0;  // wave-uniform: steps to the next checkpoint, checkpoint row
-  uint32_t clo = 0, cn = 0;
+  uint32_t cn = 0;
   bool overflow = false;
   while (__ballot(tb < V3_NULL_BASE) != 0ull) {
     if (cd == 0) {
       cd = V3_CK_STEPS;
       c++;
       if (c >= (uint32_t)V3_CK_MAX) { overflow = true; break; }
-      if (active && tb < V3_NULL_BASE && first != 0xFFFFFFFFu) {
+      if (active && tb < V3_NULL_BASE) {
         uint32_t* q = ck + c * V3_CK_ROW + (uint32_t)lane;
         q[0] = pos; q[64] = acc; q[128] = tb | (mb << 12) | ((mlen & 0x1FFu) << 16);
-        if (cn == 0) clo = c;
-        cn++;
+        cn = c;
       }
     }
     cd--;
 #ifdef V3_ASM_MARKERS
-    asm volatile("; V3LOOP_BEGIN %0" ::"n"(SPEC ? 3 : 0));
+    asm volatile("; V3LOOP_BEGIN %0" ::"n"(0));
 #endif
     const bool in_lit = tb < V3_DIST_BASE;
     const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
@@ -443,30 +491,14 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
     uint32_t ntb = is_len ? V3_DIST_BASE : (at_end ? STOP_END : 0u);
     uint32_t nmb = is_len ? (uint32_t)V3_DIST_BITS : (at_end ? 0u : (uint32_t)V3_LIT_BITS);
     if (ptr) { ntb = (e >> 3) & 0xFFEu; nmb = l; }
-    if (SPEC) {
-      // A lane that is still synchronising decodes garbage, and garbage contains END-OF-BLOCK and unassigned codes: such
-      // a stop says nothing about the block, so the lane carries on from the literal/length root instead of parking
-      // (a parked lane would have no result and, worse, hide every lane behind it from the fix-point for one pass).
-      const bool bogus = first == 0xFFFFFFFFu && ntb > STOP_END;
-      if (bogus) { ntb = 0u; nmb = (uint32_t)V3_LIT_BITS; }
-    }
     tb = ntb; mb = nmb;
-    if (SPEC) {
-      // the next step starts a symbol at / after count_from: counting restarts there
-      const bool cross = tb == 0u && first == 0xFFFFFFFFu && pos >= count_from;
-      if (cross) { first = pos; acc = 0; }
-    }
 #ifdef V3_ASM_MARKERS
-    asm volatile("; V3LOOP_END %0" ::"n"(SPEC ? 3 : 0));
+    asm volatile("; V3LOOP_END %0" ::"n"(0));
 #endif
   }
   if (active) {
-    // a lane that stopped before reaching count_from (bogus EOB / bad code while synchronising) has no valid result,
-    // even if it stopped exactly on a true symbol boundary: first stays ~0, which never equals a predecessor's end
-    // and so forces a re-decode
-    if (first == 0xFFFFFFFFu) { acc = 0; cn = 0; }
     end_out = tb == STOP_EOB ? pos - (uint32_t)L.eob_fix : pos;
-    acc_out = acc; first_out = first; ck_lo = clo; ck_n = cn;
+    acc_out = acc; ck_n = cn;
     flags = tb == STOP_EOB ? F_EOB : (tb == STOP_BAD ? F_BAD : 0u);
   }
   return overflow;
@@ -986,15 +1018,15 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
         const uint32_t rel0 = (uint32_t)(P & 31);
         const uint32_t bnd = rel0 + (uint32_t)lane * subb;
         const uint32_t limit = rel0 + (uint32_t)(lane + 1) * subb;
-        uint32_t start = bnd, end = bnd, acc = 0, flags = 0, clo = 0, cn = 0;
+        uint32_t start = bnd, end = bnd, acc = 0, flags = 0, cn = 0;
         bool ovf;
         {
           // lanes too close to the round's start for a full pre-roll begin at the round's exact first bit instead
           const uint32_t room = (uint32_t)lane * subb;
           const uint32_t ov = room < ovb ? room : ovb;
-          uint32_t first = bnd;
-          ovf = v3_count<true>(L, true, bnd - ov, limit, bnd, gsrc, ck, lane, end, acc, flags, first, clo, cn);
-          start = first;  // counts are valid from here
+          start = v3_sync(L, bnd - ov, bnd, limit, gsrc);   // first symbol start at / after the lane's boundary (speculative)
+          if (start >= limit) { end = start; }               // (a symbol that spans the whole sub-stream: the lane owns nothing)
+          ovf = v3_count(L, start < limit, start, limit, gsrc, ck, lane, end, acc, flags, cn);
         }
         dbg_passes++;
         for (int it = 0; it < 66 && !ovf; it++) {
@@ -1010,7 +1042,7 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
           if (changed) start = pe;
           // a lane whose corrected start already lies beyond its limit owns no symbols
           if (changed && start >= limit) { end = start; acc = 0; flags = 0; cn = 0; }
-          { uint32_t f_ = 0; ovf = v3_count<false>(L, changed && start < limit, start, limit, 0, gsrc, ck, lane, end, acc, flags, f_, clo, cn); }
+          ovf = v3_count(L, changed && start < limit, start, limit, gsrc, ck, lane, end, acc, flags, cn);
           dbg_passes++;
         }
         if (ovf) {
@@ -1053,17 +1085,16 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
           const uint32_t o_start = (uint32_t)__shfl((int)start, own, WAVE);
           const uint32_t o_obase = (uint32_t)__shfl((int)obase, own, WAVE);
           const uint32_t o_mbase = (uint32_t)__shfl((int)mbase, own, WAVE);
-          const uint32_t o_clo = (uint32_t)__shfl((int)clo, own, WAVE);
           const uint32_t o_cn = (uint32_t)__shfl((int)cn, own, WAVE);
           const uint32_t o_acc = (uint32_t)__shfl((int)acc, own, WAVE);
           const uint32_t o_limit = rel0 + (uint32_t)(own + 1) * subb;
           uint32_t p0 = o_start, a0 = 0, st0 = (uint32_t)V3_LIT_BITS << 12, p1 = 0xFFFFFFFFu, a1 = o_acc;
           if (has && k > 0) {
-            const uint32_t* q = ck + (o_clo + k - 1u) * V3_CK_ROW + (uint32_t)own;
+            const uint32_t* q = ck + k * V3_CK_ROW + (uint32_t)own;        // row k = state after k * V3_CK_STEPS steps
             p0 = q[0]; a0 = q[64]; st0 = q[128];
           }
           if (has && k < o_cn) {
-            const uint32_t* q = ck + (o_clo + k) * V3_CK_ROW + (uint32_t)own;
+            const uint32_t* q = ck + (k + 1u) * V3_CK_ROW + (uint32_t)own;
             p1 = q[0]; a1 = q[64];
           }
           const uint32_t seg_out = has ? (a1 & 0xFFFFFu) - (a0 & 0xFFFFFu) : 0u;
