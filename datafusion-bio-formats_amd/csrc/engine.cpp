@@ -247,6 +247,11 @@ struct Provider : BgzfSource {
 struct WorkItem {
   DecodeRange range;
   RowSelect sel{};
+  // Further regions served by the same decode: consecutive mapped regions of a partition whose records follow each other
+  // in the file (ascending, disjoint) and whose member ranges touch.  Region-major order is then file order, so one pass
+  // over the union of their members with the OR of their predicates returns the same rows in the same order as one pass
+  // per region -- without re-inflating the boundary members and without one small K1 launch per region.
+  std::vector<RowSelect> more;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -500,6 +505,20 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
       w.sel.start1 = r.has_start ? (int64_t)r.start : 0;
       w.sel.end1 = r.has_end ? (int64_t)r.end : INT64_MAX;
       w.sel.q_start1 = r.has_start ? (int64_t)r.start : 1;
+    }
+    // merge into the previous item when this region continues it in file order
+    if (w.sel.mode == 1 && !items.empty() && items.back().sel.mode == 1) {
+      WorkItem& a = items.back();
+      const RowSelect& last = a.more.empty() ? a.sel : a.more.back();
+      const bool after = w.sel.ref > last.ref || (w.sel.ref == last.ref && last.end1 != INT64_MAX && w.sel.start1 > last.end1);
+      const bool touches = w.range.b_lo <= a.range.b_hi + 64 && w.range.b_lo >= a.range.b_lo && w.range.b_hi >= a.range.b_hi;
+      if (after && touches) {
+        const uint64_t shift = p.blk_uoff[w.range.b_lo] - p.blk_uoff[a.range.b_lo];
+        a.range.stop_rel = std::max(a.range.stop_rel, w.range.stop_rel + shift);
+        a.range.b_hi = w.range.b_hi;
+        a.more.push_back(w.sel);
+        continue;
+      }
     }
     items.push_back(w);
   }
@@ -806,7 +825,8 @@ struct BamExecState {
       if (any) {
         DevBuf<uint32_t> keep(n_rec);
         DevBuf<uint64_t> kscan(n_rec + 1), tmp(scan_tmp_elems(n_rec));
-        launch_row_flags(rk, n_rec, sel, d_terms.p, keep.p, st);
+        launch_row_flags(rk, n_rec, sel, d_terms.p, keep.p, 0, st);
+        for (auto& extra : w.more) launch_row_flags(rk, n_rec, extra, d_terms.p, keep.p, 1, st);  // disjoint regions: OR
         launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n_rec, tmp.p, st);
         uint64_t tsel = 0;
         HIP_CHECK(hipMemcpyAsync(&tsel, kscan.p + n_rec, 8, hipMemcpyDeviceToHost, st));

@@ -51,6 +51,9 @@ namespace bioscan {
 #ifndef V3_OV_MIN
 #define V3_OV_MIN 96
 #endif
+#ifndef V3_OV_QUARTERS
+#define V3_OV_QUARTERS 2      // pre-roll = this many quarters of a sub-stream (before the clamps)
+#endif
 #ifndef V3_WIN_BYTES
 #define V3_WIN_BYTES 5632
 #endif
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
         if (sub_dw < 5) sub_dw = 5;
         if (force_dw) sub_dw = force_dw;
         const uint32_t subb = sub_dw * 32;
-        uint32_t ovb = subb >> 1;   // pre-roll of the speculative lanes
+        uint32_t ovb = (subb * (uint32_t)V3_OV_QUARTERS) >> 2;   // pre-roll of the speculative lanes
         if (ovb < (uint32_t)V3_OV_MIN) ovb = V3_OV_MIN;
         if (ovb > (uint32_t)V3_OV_MAX) ovb = V3_OV_MAX;
         const uint64_t wb = P >> 5;

@@ -93,7 +93,7 @@ struct RowSelect {
   int32_t zero_based;
   int32_t n_terms;
 };
-void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, hipStream_t st);
+void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st);
 void launch_compact_rows(const uint64_t* rec_off, const uint32_t* keep, const uint64_t* keep_scan, uint64_t n,
                          uint64_t* rows, uint64_t row_base, hipStream_t st);
 // tail run finder: first index >= i0 with refid==ref  /  first index > a with refid != ref

@@ -402,7 +402,7 @@ __device__ bool eval_terms(const FilterTerm* t, int n, bool has_chrom, int32_t c
   return true;
 }
 
-__global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep) {
+__global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep, int accumulate) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t refid = k.refid[i], pos = k.pos[i];
@@ -435,11 +435,12 @@ __global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTe
   }
   if (kp && sel.n_terms)
     kp = eval_terms(terms, sel.n_terms, has_chrom, chrom_ref, has_start, start_out, has_end, end1, fm >> 16, fm & 0xFFFFu);
-  keep[i] = kp ? 1u : 0u;
+  if (accumulate) { if (kp) keep[i] = 1u; }   // a further region of the same decode (regions are disjoint)
+  else keep[i] = kp ? 1u : 0u;
 }
-void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, hipStream_t st) {
+void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_row_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, k, n, sel, terms_dev, keep);
+  hipLaunchKernelGGL(k_row_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, k, n, sel, terms_dev, keep, accumulate);
 }
 
 __global__ void k_compact_rows(const uint64_t* __restrict__ rec_off, const uint32_t* __restrict__ keep,
