@@ -89,13 +89,8 @@ void BgzfSource::frame() {
 static void k1_launch_params(int device, uint32_t* grid, size_t* stride) {
   hipDeviceProp_t pr;
   HIP_CHECK(hipGetDeviceProperties(&pr, device));
-#ifdef BIOSCAN_K1_V2
-  const int occ = v2_resident_wg_per_cu();
-  *stride = V2_SCRATCH_STRIDE;
-#else
   const int occ = v3_resident_wg_per_cu();
   *stride = V3_SCRATCH_STRIDE;
-#endif
   const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
   *grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
   if (env_knobs().debug) fprintf(stderr, "[bioscan] K1 residency: %d waves per CU x %d CUs\n", per_cu, pr.multiProcessorCount);
@@ -115,10 +110,10 @@ void BgzfSource::make_resident() {
   d_status.alloc(std::max<size_t>(n_blocks(), 1));
   {
     size_t stride = 0;
-    k1_launch_params(device, &v2_grid, &stride);
-    v2_grid = std::min<uint32_t>(v2_grid, std::max<uint32_t>(n_blocks(), 1));
-    d_v2_ctr.alloc(32);
-    d_v2_scratch.alloc(((size_t)v2_grid + 8) * stride);
+    k1_launch_params(device, &k1_grid, &stride);
+    k1_grid = std::min<uint32_t>(k1_grid, std::max<uint32_t>(n_blocks(), 1));
+    d_k1_ctr.alloc(32);
+    d_k1_scratch.alloc(((size_t)k1_grid + 8) * stride);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
   file.reset();  // the compressed bytes now live in HBM; the host image is not read again
@@ -128,14 +123,9 @@ void BgzfSource::make_resident() {
 
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
-  HIP_CHECK(hipMemsetAsync(d_v2_ctr.p, 0, 128, stream));
-#ifdef BIOSCAN_K1_V2   // A/B build of the r01 kernel (make EXTRA=-DBIOSCAN_K1_V2); the shipped library runs v3
-  launch_bgzf_inflate_v2(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p,
-                         V2_SCRATCH_STRIDE, v2_grid, env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
-#else
-  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_v2_ctr.p, d_v2_scratch.p, v2_grid,
-                         env_knobs().debug ? d_v2_ctr.p + 2 : nullptr, stream);
-#endif
+  HIP_CHECK(hipMemsetAsync(d_k1_ctr.p, 0, 128, stream));
+  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
+                         env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream);
 }
 
 K1Ctx::~K1Ctx() {
@@ -213,13 +203,8 @@ void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, 
   if (b0 < img.m_lo || b0 + nb > img.m_hi) throw Error("internal: members outside the resident range of the device image");
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
-#ifdef BIOSCAN_K1_V2
-  launch_bgzf_inflate_v2(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, V2_SCRATCH_STRIDE, c.grid,
-                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
-#else
   launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, c.grid,
                          env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
-#endif
 }
 
 void BgzfSource::launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0) {
@@ -244,13 +229,14 @@ void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
   launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);
 }
 
-void BgzfSource::report_v2_debug(uint32_t nb) {
-  if (!env_knobs().debug) return;
+void BgzfSource::report_k1_debug(uint32_t nb) { report_k1_debug(d_k1_ctr.p, nb); }
+void BgzfSource::report_k1_debug(const uint32_t* ctr_dev, uint32_t nb) {
+  if (!env_knobs().debug || !ctr_dev) return;
   uint32_t h[32];
-  HIP_CHECK(hipMemcpy(h, d_v2_ctr.p, 128, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(h, ctr_dev, 128, hipMemcpyDeviceToHost));
   unsigned long long tc[5];
   memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
-  fprintf(stderr, "[bioscan] inflate v2: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
+  fprintf(stderr, "[bioscan] inflate: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
           h[2] ? (double)h[3] / h[2] : 0.0);
   double tot = 0;
   for (int i = 0; i < 5; i++) tot += (double)tc[i];
@@ -260,7 +246,7 @@ void BgzfSource::report_v2_debug(uint32_t nb) {
           h[2] ? (double)h[25] / h[2] : 0.0, h[26]);
   fprintf(stderr, "[bioscan]   LZ77 matches %u (%.1f per round), %.1f %% with a source inside the round's window\n", h[14], h[2] ? (double)h[14] / h[2] : 0.0,
           h[14] ? 100.0 * h[15] / h[14] : 0.0);
-  if (h[20])  // -DV2_FIXSTAT builds only: how much of the wave each fix pass of the cascade re-decodes
+  if (h[20])  // -DV3_FIXSTAT builds only: how much of the wave each fix pass of the cascade re-decodes
     for (int k = 0; k < 4; k++)
       fprintf(stderr, "[bioscan]   fix pass %d%s: run in %.1f %% of rounds, %.2f lanes re-decoded per run\n", k + 1, k == 3 ? "+" : "",
               h[2] ? 100.0 * h[20 + k] / h[2] : 0.0, h[20 + k] ? (double)h[16 + k] / h[20 + k] : 0.0);

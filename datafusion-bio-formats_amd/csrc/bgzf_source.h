@@ -64,9 +64,9 @@ struct BgzfSource {
   DevBuf<uint8_t> d_comp;
   DevBuf<uint64_t> d_coff, d_uoff;
   DevBuf<uint32_t> d_status;
-  DevBuf<uint32_t> d_v2_ctr;               // [0] member counter, [1..] debug counters
-  DevBuf<unsigned long long> d_v2_scratch;  // per-workgroup match lists of K1 v2
-  uint32_t v2_grid = 0;  // persistent grid of K1 (waves) of the whole-file image below
+  DevBuf<uint32_t> d_k1_ctr;               // [0] member counter, [1..] debug counters
+  DevBuf<unsigned long long> d_k1_scratch;  // per-wave scratch of K1 (match list + checkpoint rows)
+  uint32_t k1_grid = 0;  // persistent grid of K1 (waves) of the whole-file image below
   DevBuf<uint8_t> d_u;  // inflated bytes of the range decoded last
 
   ~BgzfSource();
@@ -78,7 +78,8 @@ struct BgzfSource {
   // Inflate members [b0, b0+nb) so that member b0's payload lands at dst[0].
   void launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
   void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
-  void report_v2_debug(uint32_t nb);
+  void report_k1_debug(uint32_t nb);
+  void report_k1_debug(const uint32_t* ctr_dev, uint32_t nb);  // BIOSCAN_DEBUG=1: pass / phase counters of the last K1 launch
   void check_inflate_status(uint32_t b0, uint32_t nb);
   // Per-device, per-range residency (BAM): the image of `device` that covers members [m_lo, m_hi), built or widened on
   // demand from the mapped file.  The three K1 / K2 steps on a caller-owned context (its stream, its scratch, status

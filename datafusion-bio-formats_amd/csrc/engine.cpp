@@ -711,6 +711,7 @@ struct BamExecState {
     t.start();
     p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
     s.ms_inflate = t.stop();
+    p.report_k1_debug(k1.ctr.p, m1 - m0);
     // CRC32 validation (noodles-bgzf checks every block)
     t.start();
     p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);

@@ -37,7 +37,7 @@ namespace bioscan {
 #define V3_SUB_DW 64          // longest sub-stream of a round, dwords
 #endif
 #ifndef V3_CK_STEPS
-#define V3_CK_STEPS 40        // decode steps between two checkpoints = longest segment of the write phase
+#define V3_CK_STEPS 24        // decode steps between two checkpoints = longest segment of the write phase
 #endif
 #ifndef V3_CK_MAX
 #define V3_CK_MAX 24          // checkpoints per lane and pass; a pass that needs more restarts its round with short sub-streams
@@ -55,7 +55,7 @@ namespace bioscan {
 #define V3_OV_QUARTERS 2      // pre-roll = this many quarters of a sub-stream (before the clamps)
 #endif
 #ifndef V3_WIN_BYTES
-#define V3_WIN_BYTES 5632
+#define V3_WIN_BYTES 4096
 #endif
 constexpr int V3_LIT_BITS = 9;                          // zlib's root sizes: ENOUGH_LENS = 852, ENOUGH_DISTS = 592
 constexpr int V3_DIST_BITS = 6;
@@ -664,31 +664,44 @@ __device__ void v3_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst,
 // only bytes before R: they need no ordering at all, so the list is walked twice -- first every match copies the part
 // of its source that precedes R (v3_far_copy) and the matches that also read the window are compacted to the front
 // of the list, then only those go through the dependency-ordered copy (v3_near_batch), in dense batches of 64.
-__device__ __forceinline__ void v3_far_copy(uint8_t* win, const uint8_t* out, uint32_t R, bool valid, uint32_t m_dst, uint32_t m_len,
-                                            uint32_t m_dist) {
+// v3_far_issue loads the first 16 bytes of the far part (sources before R are final bytes in HBM); v3_far_finish stores them
+// into the window and copies what lies beyond 16 bytes.  Split in two so that the caller can have the next batch's loads
+// in flight while it stores this batch's (the load latency was the largest single wait of the resolve).
+__device__ __forceinline__ uint32_t v3_far_count(uint32_t R, bool valid, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
   const uint32_t src_lo = m_dst - m_dist;
   uint32_t n_far = 0;
   if (valid && src_lo < R) { n_far = R - src_lo; if (n_far > m_len) n_far = m_len; }
+  return n_far;
+}
+__device__ __forceinline__ u32x4 v3_far_issue(const uint8_t* out, uint32_t n_far, uint32_t m_dst, uint32_t m_dist) {
+  u32x4 v = {0, 0, 0, 0};
+  if (n_far) v = ld16(out + (m_dst - m_dist));  // over-read is inside the (padded) buffer
+  return v;
+}
+__device__ __forceinline__ void v3_far_finish(uint8_t* win, const uint8_t* out, uint32_t R, uint32_t n_far, u32x4 v, uint32_t m_dst, uint32_t m_dist) {
   if (n_far) {
     // LDS takes unaligned 4 / 8-byte stores on gfx950: the bytes go out in the widest pieces that fit
     uint8_t* d = win + (m_dst - R);
-    const uint8_t* s = out + src_lo;
-    uint32_t k = 0;
-    for (; k + 16 <= n_far; k += 16) {
-      const u32x4 v = ld16(s + k);
-      st8(d + k, (uint64_t)v.x | ((uint64_t)v.y << 32));
-      st8(d + k + 8, (uint64_t)v.z | ((uint64_t)v.w << 32));
+    const uint8_t* s = out + (m_dst - m_dist);
+    if (n_far >= 16) {
+      st8(d, (uint64_t)v.x | ((uint64_t)v.y << 32));
+      st8(d + 8, (uint64_t)v.z | ((uint64_t)v.w << 32));
+      uint32_t k = 16;
+      for (; k + 16 <= n_far; k += 16) {
+        const u32x4 w = ld16(s + k);
+        st8(d + k, (uint64_t)w.x | ((uint64_t)w.y << 32));
+        st8(d + k + 8, (uint64_t)w.z | ((uint64_t)w.w << 32));
+      }
+      if (k < n_far) { v = ld16(s + k); d += k; n_far -= k; } else n_far = 0;
     }
-    const uint32_t rem = n_far - k;
+    const uint32_t rem = n_far;
     if (rem) {
-      const u32x4 v = ld16(s + k);  // over-read is inside the (padded) buffer
-      uint8_t* t = d + k;
       uint32_t o = 0;
-      if (rem & 8) { st8(t, (uint64_t)v.x | ((uint64_t)v.y << 32)); o = 8; }
-      if (rem & 4) { st4(t + o, o ? v.z : v.x); o += 4; }
+      if (rem & 8) { st8(d, (uint64_t)v.x | ((uint64_t)v.y << 32)); o = 8; }
+      if (rem & 4) { st4(d + o, o ? v.z : v.x); o += 4; }
       const uint32_t w = o == 0 ? v.x : o == 4 ? v.y : o == 8 ? v.z : v.w;
-      if (rem & 2) { st2(t + o, (uint16_t)w); if (rem & 1) t[o + 2] = (uint8_t)(w >> 16); }
-      else if (rem & 1) t[o] = (uint8_t)w;
+      if (rem & 2) { st2(d + o, (uint16_t)w); if (rem & 1) d[o + 2] = (uint8_t)(w >> 16); }
+      else if (rem & 1) d[o] = (uint8_t)w;
     }
   }
 }
@@ -757,18 +770,29 @@ __device__ __forceinline__ void v3_resolve(V3Lds& L, uint8_t* out, unsigned long
   if ((uint32_t)lane < tot_m) m_next = mlist[lane];
   if (use_win) {
     uint32_t n_near = 0;  // matches that also read this round's window, compacted to the front of the list
+    // software pipeline: batch k + 1's list entry and far source are loaded before batch k's bytes are stored
+    unsigned long long m = m_next;
+    if (WAVE + (uint32_t)lane < tot_m) m_next = mlist[WAVE + lane];
+    uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
+    uint32_t nf = v3_far_count(R, (uint32_t)lane < tot_m, md, ml, mdist);
+    u32x4 fv = v3_far_issue(out, nf, md, mdist);
     for (uint32_t k = 0; k < tot_m; k += WAVE) {
       const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
-      const unsigned long long m = m_next;
-      if (k + WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + WAVE + lane];  // prefetch the next batch
-      const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
       const bool valid_m = (uint32_t)lane < nmb;
-      v3_far_copy(L.win, out, R, valid_m, md, ml, mdist);
+      // next batch: entry (prefetched one batch earlier), far source load issued now
+      const unsigned long long m2 = m_next;
+      if (k + 2 * WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + 2 * WAVE + lane];
+      const uint32_t md2 = (uint32_t)(m2 & 0xFFFFFFFFull), ml2 = (uint32_t)((m2 >> 32) & 0xFFFu), mdist2 = (uint32_t)(m2 >> 44);
+      const uint32_t nf2 = v3_far_count(R, k + WAVE + (uint32_t)lane < tot_m, md2, ml2, mdist2);
+      const u32x4 fv2 = v3_far_issue(out, nf2, md2, mdist2);
+      // this batch: store
+      v3_far_finish(L.win, out, R, nf, fv, md, mdist);
       const bool near = valid_m && md - mdist + ml > R;
       const unsigned long long nmask = __ballot(near);
       if (near) mlist[n_near + __builtin_amdgcn_mbcnt_hi((uint32_t)(nmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nmask, 0u))] = m;  // < k + 64: never a slot still to be read
       n_near += (uint32_t)__popcll(nmask);
       if (dbg) { dbg_matches += nmb; dbg_near += (uint32_t)__popcll(nmask); }
+      m = m2; md = md2; ml = ml2; mdist = mdist2; nf = nf2; fv = fv2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -20,13 +20,6 @@ enum InflateStatus : uint32_t {
 // ---- K1: BGZF inflate -------------------------------------------------------------------------
 // comp: compressed file bytes (padded by >= 1 KiB readable slack), blk_coff[i] = byte offset of
 // BGZF member i, blk_uoff[i] = offset of its payload in `out`; blk_uoff[n] = total.
-// K1 v2 (inflate_v2.hip): wave-parallel Huffman decode, persistent grid.  counter: 1 u32; scratch:
-// grid * scratch_stride u64 match-list entries; dbg: 2 u32 counters (rounds, passes) or nullptr.
-constexpr uint32_t V2_SCRATCH_STRIDE = 19456;
-int v2_resident_wg_per_cu();  // occupancy of k_bgzf_inflate_v2 (workgroups per CU) from the HIP occupancy API
-void launch_bgzf_inflate_v2(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
-                            uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
-                            uint32_t scratch_stride, uint32_t grid, uint32_t* dbg, hipStream_t st);
 // K1 (inflate_v3.hip): long sub-streams, checkpointed count passes, segment mini-rounds.  Per-wave scratch stride in
 // u64: the match list of one mini-round (V3_ML_ENTRIES) followed by the checkpoint rows of one round.
 constexpr uint32_t V3_ML_ENTRIES = 1536;

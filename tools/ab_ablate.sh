@@ -6,7 +6,7 @@ make -C tools >/dev/null 2>&1
 tools/_build/synth_bam /tmp/ab.bam 16384 42 >/dev/null 2>&1 || tools/_build/synth_bam --help
 C=datafusion-bio-formats_amd/csrc
 for ab in ${ABS:-0 1 2 3}; do
-  touch $C/inflate_v2.hip; make -C $C EXTRA="-DV2_ABLATE=$ab" >/dev/null 2>&1   # ablation is a compile-time build: never the shipped library
+  touch $C/inflate_v3.hip; make -C $C EXTRA="$( [ "$ab" = 1 ] && echo -DV3_ABLATE_RESOLVE; [ "$ab" = 2 ] && echo -DV3_ABLATE_WRITE; [ "$ab" = 3 ] && echo "-DV3_ABLATE_RESOLVE -DV3_ABLATE_WRITE" )" >/dev/null 2>&1   # ablation is a compile-time build: never the shipped library
   python - <<PY
 import sys, importlib.util, os
 sys.path.insert(0, 'tests')
@@ -17,4 +17,4 @@ ms = min(pkg.bgzf_inflate(data, check_crc=False)[1] for _ in range(3))
 print('ablate=$ab k1_ms', round(ms, 3))
 PY
 done
-touch $C/inflate_v2.hip; make -C $C >/dev/null 2>&1
+touch $C/inflate_v3.hip; make -C $C >/dev/null 2>&1
