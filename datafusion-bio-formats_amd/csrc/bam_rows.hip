@@ -5,7 +5,7 @@
 // core columns.  A record's header is read once per pass and every Arrow byte is written exactly once:
 //   pass 1  one row per lane: fixed-width columns + validity words, and the SUM of every variable-length column's row
 //           lengths per tile of 256 rows (one u64 per column and tile -- no per-row length arrays, no offset arrays);
-//   scan    exclusive scan of the tile sums (one workgroup per column) -> tile bases and column totals;
+//   scan    two-level exclusive scan of the tile sums -> tile bases and column totals;
 //   bases   first byte of every RecordBatch of the chunk (tile base + the rows of that tile in front of the batch);
 //   pass 2  one workgroup per tile: lengths are recomputed from the records, scanned inside the tile, the per-batch int32
 //           offsets are written straight from that scan, chrom / cigar / mate_chrom are written one row per lane, and
@@ -148,30 +148,56 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass1(const uint8_t* __r
   }
 }
 
-// exclusive scan of one column's tile sums in place (one workgroup per column); entry n_tiles = the column's total
-__global__ __launch_bounds__(1024) void k_bam_tile_scan(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint32_t want) {
+// Exclusive scan of every column's tile sums, two levels: k_bam_tile_scan_blocks scans groups of 1024 tiles in place and
+// leaves each group's total in `aux`; k_bam_tile_scan_top scans the group totals (one workgroup per column) and writes the
+// column's grand total to entry n_tiles.  The first byte of tile t is tile_sums[k][t] + aux[k][t / 1024] (tile_base()).
+constexpr int TS_GROUP = 1024;
+__global__ __launch_bounds__(TS_GROUP) void k_bam_tile_scan_blocks(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint64_t n_groups,
+                                                                   uint64_t* __restrict__ aux, uint32_t want) {
+  const int k = blockIdx.y;
+  if (!((want >> k) & 1u)) return;
+  uint64_t* a = tile_sums + (uint64_t)k * (n_tiles + 1);
+  __shared__ uint64_t s_w[TS_GROUP / WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t i = (uint64_t)blockIdx.x * TS_GROUP + threadIdx.x;
+  const uint64_t v = i < n_tiles ? a[i] : 0;
+  const uint64_t inc = br_wave_incl_scan(v, lane);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  uint64_t base = 0, tot = 0;
+  for (int q = 0; q < TS_GROUP / WAVE; q++) { if (q < w) base += s_w[q]; tot += s_w[q]; }
+  if (i < n_tiles) a[i] = base + inc - v;
+  if (threadIdx.x == 0) aux[(uint64_t)k * (n_groups + 1) + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_bam_tile_scan_top(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint64_t n_groups,
+                                                            uint64_t* __restrict__ aux, uint32_t want) {
   if (!((want >> blockIdx.x) & 1u)) return;
-  uint64_t* a = tile_sums + (uint64_t)blockIdx.x * (n_tiles + 1);
+  uint64_t* a = aux + (uint64_t)blockIdx.x * (n_groups + 1);
   __shared__ uint64_t s_w[1024 / WAVE];
   __shared__ uint64_t carry_s;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (uint64_t b0 = 0; b0 < n_tiles; b0 += 1024) {
+  for (uint64_t b0 = 0; b0 < n_groups; b0 += 1024) {
     const uint64_t i = b0 + threadIdx.x;
-    const uint64_t v = i < n_tiles ? a[i] : 0;
+    const uint64_t v = i < n_groups ? a[i] : 0;
     const uint64_t inc = br_wave_incl_scan(v, lane);
     if (lane == 63) s_w[w] = inc;
     __syncthreads();
     uint64_t base = 0, tot = 0;
     for (int q = 0; q < 1024 / WAVE; q++) { if (q < w) base += s_w[q]; tot += s_w[q]; }
     const uint64_t cy = carry_s;
-    if (i < n_tiles) a[i] = cy + base + inc - v;
+    if (i < n_groups) a[i] = cy + base + inc - v;
     __syncthreads();
     if (threadIdx.x == 0) carry_s = cy + tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) a[n_tiles] = carry_s;
+  if (threadIdx.x == 0) tile_sums[(uint64_t)blockIdx.x * (n_tiles + 1) + n_tiles] = carry_s;
+}
+__device__ __forceinline__ uint64_t tile_base(const uint64_t* __restrict__ tile_sums, const uint64_t* __restrict__ aux, int k, uint64_t tile,
+                                              uint64_t n_tiles) {
+  const uint64_t n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;
+  return tile_sums[(uint64_t)k * (n_tiles + 1) + tile] + aux[(uint64_t)k * (n_groups + 1) + tile / TS_GROUP];
 }
 
 __device__ __forceinline__ uint64_t br_batch_start_row(uint64_t b, uint32_t bs, uint32_t phase) { return b ? b * bs - phase : 0; }
@@ -180,7 +206,8 @@ __device__ __forceinline__ uint64_t br_batch_start_row(uint64_t b, uint32_t bs, 
 __global__ __launch_bounds__(ROWS_TILE) void k_bam_batch_bases(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rows, uint64_t n,
                                                                RowsCols c, const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
                                                                int32_t binary_cigar, uint32_t bs, uint32_t phase,
-                                                               uint64_t n_tiles, const uint64_t* __restrict__ tile_sums) {
+                                                               uint64_t n_tiles, const uint64_t* __restrict__ tile_sums,
+                                                               const uint64_t* __restrict__ aux) {
   const uint32_t want = c.want;
   __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
   const uint64_t b = blockIdx.x;
@@ -206,7 +233,7 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_batch_bases(const uint8_t* __
   }
   __syncthreads();
   if (threadIdx.x < 6 && ((want >> threadIdx.x) & 1u)) {
-    uint64_t t = tile < n_tiles ? tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + tile] : tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + n_tiles];
+    uint64_t t = tile < n_tiles ? tile_base(tile_sums, aux, (int)threadIdx.x, tile, n_tiles) : tile_sums[(uint64_t)threadIdx.x * (n_tiles + 1) + n_tiles];
     for (int q = 0; q < ROWS_TILE / WAVE; q++) t += s_w[threadIdx.x][q];
     c.base[threadIdx.x][b] = t;
   }
@@ -224,7 +251,8 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
                                                               RowsCols c, const uint8_t* __restrict__ ref_names,
                                                               const uint32_t* __restrict__ ref_name_off, const uint32_t* __restrict__ ref_name_len,
                                                               int32_t n_ref, int32_t binary_cigar, uint32_t bs, uint32_t phase,
-                                                              uint64_t n_tiles, const uint64_t* __restrict__ tile_sums, uint32_t* qual_wide) {
+                                                              uint64_t n_tiles, const uint64_t* __restrict__ tile_sums,
+                                                              const uint64_t* __restrict__ aux, uint32_t* qual_wide) {
   __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
   __shared__ uint64_t s_rec[ROWS_TILE], s_on[ROWS_TILE], s_os[ROWS_TILE], s_oq[ROWS_TILE];
   __shared__ uint32_t s_meta[ROWS_TILE], s_lseq[ROWS_TILE];
@@ -260,7 +288,7 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     if (!((c.want >> k) & 1u)) continue;
-    uint64_t base = tile_sums[(uint64_t)k * (n_tiles + 1) + tile];
+    uint64_t base = tile_base(tile_sums, aux, k, tile, n_tiles);
     for (int q = 0; q < w; q++) base += s_w[k][q];
     off[k] += base;
   }
@@ -405,7 +433,16 @@ void launch_bam_rows_pass1(const uint8_t* u, const uint64_t* rows, uint64_t n, R
   const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
   hipLaunchKernelGGL(k_bam_rows_pass1, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_name_len, n_ref, zero_based,
                      binary_cigar, n_tiles, tile_sums, err);
-  if (c.want) hipLaunchKernelGGL(k_bam_tile_scan, dim3(6), dim3(1024), 0, st, tile_sums, n_tiles, c.want);
+  if (c.want) {
+    const uint64_t n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;
+    uint64_t* aux = tile_sums + 6 * (n_tiles + 1);  // 6 x (n_groups + 1) group totals behind the tile sums (bam_rows_scratch_elems)
+    hipLaunchKernelGGL(k_bam_tile_scan_blocks, dim3((uint32_t)n_groups, 6), dim3(TS_GROUP), 0, st, tile_sums, n_tiles, n_groups, aux, c.want);
+    hipLaunchKernelGGL(k_bam_tile_scan_top, dim3(6), dim3(1024), 0, st, tile_sums, n_tiles, n_groups, aux, c.want);
+  }
+}
+size_t bam_rows_scratch_elems(uint64_t n) {
+  const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE, n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;
+  return (size_t)(6 * (n_tiles + 1) + 6 * (n_groups + 1));
 }
 void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint8_t* ref_names,
                            const uint32_t* ref_name_off, const uint32_t* ref_name_len, int32_t n_ref, int32_t binary_cigar,
@@ -413,10 +450,11 @@ void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, R
   if (!n || !c.want) return;
   const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
   const uint64_t nb = (n + phase + batch_size - 1) / batch_size;
+  const uint64_t* aux = tile_sums + 6 * (n_tiles + 1);
   hipLaunchKernelGGL(k_bam_batch_bases, dim3((uint32_t)nb), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_name_len, n_ref, binary_cigar,
-                     batch_size, phase, n_tiles, tile_sums);
+                     batch_size, phase, n_tiles, tile_sums, aux);
   hipLaunchKernelGGL(k_bam_rows_pass2, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_names, ref_name_off, ref_name_len,
-                     n_ref, binary_cigar, batch_size, phase, n_tiles, tile_sums, qual_wide);
+                     n_ref, binary_cigar, batch_size, phase, n_tiles, tile_sums, aux, qual_wide);
 }
 
 }  // namespace bioscan

@@ -731,10 +731,10 @@ struct BamExecState {
       skip = 0;
       const uint64_t nseg = std::max<uint64_t>((L + SEG_BYTES - 1) / SEG_BYTES, 1);
       DevBuf<uint64_t> entry(nseg), exit_(nseg), base(nseg + 1), tmp(scan_tmp_elems(nseg));
-      DevBuf<uint32_t> count(nseg), dirty(nseg), ctr(2);
+      DevBuf<uint32_t> count(nseg), dirty(nseg), ctr(2), starts(nseg * (uint64_t)SEG_SLOT);
       HIP_CHECK(hipMemsetAsync(ctr.p, 0, 8, st));
       HIP_CHECK(hipMemsetAsync(dirty.p, 0, nseg * 4, st));
-      ChainBuffers cb{entry.p, exit_.p, count.p, dirty.p, ctr.p, ctr.p + 1};
+      ChainBuffers cb{entry.p, exit_.p, count.p, dirty.p, ctr.p, ctr.p + 1, starts.p};
       const int partial = last ? 0 : 1;
       launch_seg_guess(u, L, first_rec, nseg, (int32_t)p.hdr.ref_names.size(), cb, st);
       launch_seg_walk(u, L, nseg, cb, 0, partial, st);
@@ -760,7 +760,7 @@ struct BamExecState {
       HIP_CHECK(hipStreamSynchronize(st));
       n_rec = total_rec;
       rec_off.alloc(n_rec + 1);
-      launch_seg_emit(u, L, nseg, cb, base.p, rec_off.p, st);
+      launch_seg_gather(nseg, cb, base.p, rec_off.p, st);
       uint32_t errf = 0;
       HIP_CHECK(hipMemcpyAsync(&errf, ctr.p + 1, 4, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -936,7 +936,7 @@ struct BamExecState {
     for (int k = 0; k < 6; k++) if (core_col[var_idx[k]] >= 0) rc.want |= 1u << k;
     // pass 1: fixed columns, validity, tile sums of the variable-length columns (+ their scan)
     const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
-    DevBuf<uint64_t> tile_sums(6 * (n_tiles + 1));
+    DevBuf<uint64_t> tile_sums(bam_rows_scratch_elems(n));
     launch_bam_rows_pass1(u, rows, n, rc, img->d_ref_name_len.p, (int32_t)p.hdr.ref_names.size(), p.zero_based ? 1 : 0,
                           p.binary_cigar ? 1 : 0, tile_sums.p, err.p, st);
     uint64_t totals[6] = {0, 0, 0, 0, 0, 0};

@@ -47,15 +47,16 @@ struct ChainBuffers {
   uint32_t* dirty;   // [nseg]
   uint32_t* nfix;    // [1] device counter
   uint32_t* err;     // [1] device error flag
+  uint32_t* starts;  // [nseg][SEG_SLOT] record starts found by the walk, segment-relative
 };
+constexpr uint32_t SEG_SLOT = 2048;  // a record is >= 36 bytes: at most 1820 starts per 64 KiB segment
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref,
                       ChainBuffers cb, hipStream_t st);
 void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, int only_dirty, int allow_partial, hipStream_t st);
 void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st);
 void launch_last_exit(const uint64_t* exit_, uint64_t nseg, unsigned long long* res, hipStream_t st);
 void launch_first_bad_status(const uint32_t* status, uint32_t n, uint32_t* res, hipStream_t st);
-void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, const uint64_t* base,
-                     uint64_t* rec_off, hipStream_t st);
+void launch_seg_gather(uint64_t nseg, ChainBuffers cb, const uint64_t* base, uint64_t* rec_off, hipStream_t st);
 
 // ---- record key table (refid,pos,end,flag,mapq per record) ------------------------------------
 struct RecKeys {
@@ -112,8 +113,9 @@ struct RowsCols {   // device pointers; nullptr = not projected
   uint64_t* base[6];   // first byte of every batch [n_batches] (pass 2)
   uint32_t want;       // bit k: column k is projected
 };
-// pass 1 + the scan of its tile sums: tile_sums holds 6 x (n_tiles + 1) u64; afterwards entry [k][t] is the first byte of
-// tile t in column k and entry [k][n_tiles] the column's total
+// pass 1 + the scan of its tile sums: tile_sums holds bam_rows_scratch_elems(n) u64 (6 x (n_tiles + 1) tile sums, then the
+// group totals of the two-level scan); afterwards entry [k][n_tiles] is column k's total
+size_t bam_rows_scratch_elems(uint64_t n);
 void launch_bam_rows_pass1(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint32_t* ref_name_len, int32_t n_ref,
                            int32_t zero_based, int32_t binary_cigar, uint64_t* tile_sums, uint32_t* err, hipStream_t st);
 void launch_bam_rows_pass2(const uint8_t* u, const uint64_t* rows, uint64_t n, RowsCols c, const uint8_t* ref_names,

@@ -197,11 +197,15 @@ __global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nseg) return;
   if (only_dirty && !cb.dirty[s]) return;
-  uint64_t E = (s + 1) * (uint64_t)SEG_BYTES;
+  const uint64_t B = s * (uint64_t)SEG_BYTES;
+  uint64_t E = B + SEG_BYTES;
   if (E > ulen) E = ulen;
   uint64_t p = cb.entry[s];
   uint32_t cnt = 0;
   uint64_t ex = SEG_NONE;
+  // the record starts found on the way go into the segment's slot (segment-relative, SEG_SLOT entries: a record is at
+  // least 36 bytes); k_seg_gather copies the verified ones into the dense table, so the chain is walked once, not twice
+  uint32_t* slot = cb.starts + s * (uint64_t)SEG_SLOT;
   if (p != SEG_NONE) {
     ex = p;
     while (ex < E) {
@@ -212,6 +216,7 @@ __global__ void k_seg_walk(const uint8_t* __restrict__ u, uint64_t ulen, uint64_
       int32_t bs = ld_i32(u + ex);
       if (bs < 32) { ex = SEG_BAD; break; }
       if (ex + 4 + (uint64_t)bs > ulen) { ex = allow_partial ? (SEG_PARTIAL | ex) : SEG_BAD; break; }
+      slot[cnt] = (uint32_t)(ex - B);
       ex += 4 + (uint64_t)bs;
       cnt++;
     }
@@ -248,23 +253,21 @@ __global__ void k_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, C
   }
 }
 
-__global__ void k_seg_emit(const uint8_t* __restrict__ u, uint64_t ulen, uint64_t nseg, ChainBuffers cb,
-                           const uint64_t* __restrict__ base, uint64_t* __restrict__ rec_off) {
-  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dense record table from the segments' slots: one wave per segment, coalesced on both sides
+__global__ __launch_bounds__(256) void k_seg_gather(uint64_t nseg, ChainBuffers cb, const uint64_t* __restrict__ base,
+                                                    uint64_t* __restrict__ rec_off) {
+  const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= nseg) return;
-  uint64_t E = (s + 1) * (uint64_t)SEG_BYTES;
-  if (E > ulen) E = ulen;
-  uint64_t p = cb.entry[s];
-  if (p == SEG_NONE) return;
+  const int lane = threadIdx.x & 63;
+  if (cb.entry[s] == SEG_NONE) return;
   if (cb.exit_[s] == SEG_BAD) {
-    atomicExch(cb.err, 1u);
+    if (lane == 0) atomicExch(cb.err, 1u);
     return;
   }
-  uint64_t o = base[s];
-  for (uint32_t c = cb.count[s]; c > 0; c--) {  // the complete records the walk counted (a partial tail record is not one)
-    rec_off[o++] = p;
-    p += 4 + (uint64_t)ld_u32(u + p);
-  }
+  const uint32_t n = cb.count[s];
+  const uint64_t B = s * (uint64_t)SEG_BYTES, o = base[s];
+  const uint32_t* slot = cb.starts + s * (uint64_t)SEG_SLOT;
+  for (uint32_t k = lane; k < n; k += 64) rec_off[o + k] = B + slot[k];
 }
 
 void launch_seg_guess(const uint8_t* u, uint64_t ulen, uint64_t first_rec, uint64_t nseg, int32_t n_ref, ChainBuffers cb, hipStream_t st) {
@@ -276,8 +279,8 @@ void launch_seg_walk(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffer
 void launch_seg_verify(uint64_t ulen, uint64_t first_rec, uint64_t nseg, ChainBuffers cb, hipStream_t st) {
   hipLaunchKernelGGL(k_seg_verify, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, ulen, first_rec, nseg, cb);
 }
-void launch_seg_emit(const uint8_t* u, uint64_t ulen, uint64_t nseg, ChainBuffers cb, const uint64_t* base, uint64_t* rec_off, hipStream_t st) {
-  hipLaunchKernelGGL(k_seg_emit, dim3((uint32_t)((nseg + 63) / 64)), dim3(64), 0, st, u, ulen, nseg, cb, base, rec_off);
+void launch_seg_gather(uint64_t nseg, ChainBuffers cb, const uint64_t* base, uint64_t* rec_off, hipStream_t st) {
+  hipLaunchKernelGGL(k_seg_gather, dim3((uint32_t)((nseg + 3) / 4)), dim3(256), 0, st, nseg, cb, base, rec_off);
 }
 
 // exit of the last segment that holds a record start: res[0] = index + 1 of that segment (0: none), res[1] = its exit.
