@@ -9,7 +9,10 @@
 //   bases   first byte of every RecordBatch of the chunk (tile base + the rows of that tile in front of the batch);
 //   pass 2  one workgroup per tile: lengths are recomputed from the records, scanned inside the tile, the per-batch int32
 //           offsets are written straight from that scan, chrom / cigar / mate_chrom are written one row per lane, and
-//           name / sequence / quality by 16-lane groups from metadata staged in LDS (16-byte chunks, coalesced).
+//           name / sequence / quality by 16-lane groups from metadata staged in LDS (16-byte chunks, the loads of four
+//           steps in flight before the first store).
+// A lane's dependent loads are kept few (header = three loads, the first four CIGAR operations one, a reference name one):
+// the row-per-lane phases are bound by that chain of latencies, the 16-lane phase by HBM bandwidth (5.8 TB/s each way).
 // All integer / byte work: no MFMA.  Bound: HBM (the inflated records are read twice -- headers only in pass 1 -- and the
 // Arrow buffers written once).
 #include "kernels.h"
@@ -36,6 +39,7 @@ struct RowInfo {
   uint32_t len[6];
   int32_t refid, nref, pos, npos, tlen;
   uint32_t lrn, ncig, lseq, flag, mapq, end1;
+  br_u32x4 ops4;  // the first four CIGAR operations (when the CIGAR was read)
   bool bad_ref, bad_op, bad_rec;
 };
 
@@ -43,27 +47,38 @@ struct RowInfo {
 __device__ __forceinline__ RowInfo row_info(const uint8_t* r, const uint32_t* __restrict__ ref_name_len, int32_t n_ref,
                                             int32_t binary_cigar, bool want_cigar, bool want_end) {
   RowInfo ri;
-  ri.refid = (int32_t)br_ld32(r + 4); ri.pos = (int32_t)br_ld32(r + 8);
-  ri.lrn = r[12]; ri.mapq = r[13]; ri.ncig = br_ld16(r + 16); ri.flag = br_ld16(r + 18);
-  ri.lseq = br_ld32(r + 20); ri.nref = (int32_t)br_ld32(r + 24); ri.npos = (int32_t)br_ld32(r + 28); ri.tlen = (int32_t)br_ld32(r + 32);
+  // three loads, not eleven: records are ~300 bytes apart, so every load instruction of a wave touches 64 different
+  // lines, and the lines of 24 resident waves do not survive in the 32 KB L1 until the next field is read
+  const br_u32x4 h0 = *(const br_u32x4*)r, h1 = *(const br_u32x4*)(r + 16);
+  ri.refid = (int32_t)h0.y; ri.pos = (int32_t)h0.z;
+  ri.lrn = h0.w & 0xFFu; ri.mapq = (h0.w >> 8) & 0xFFu; ri.ncig = h1.x & 0xFFFFu; ri.flag = h1.x >> 16;
+  ri.lseq = h1.y; ri.nref = (int32_t)h1.z; ri.npos = (int32_t)h1.w; ri.tlen = (int32_t)br_ld32(r + 32);
   // Every later step trusts l_read_name / n_cigar_op / l_seq: they must fit inside block_size (noodles fails such a record
   // with an I/O error; a CRC-valid member can still carry one).  A bad record is treated as empty and reported.
   ri.bad_rec = ri.lrn == 0 || (int32_t)ri.lseq < 0 ||
-               32ull + ri.lrn + 4ull * ri.ncig + (((uint64_t)ri.lseq + 1) >> 1) + (uint64_t)ri.lseq > (uint64_t)br_ld32(r);
+               32ull + ri.lrn + 4ull * ri.ncig + (((uint64_t)ri.lseq + 1) >> 1) + (uint64_t)ri.lseq > (uint64_t)h0.x;
   if (ri.bad_rec) { ri.lrn = 1; ri.ncig = 0; ri.lseq = 0; }
   ri.bad_ref = ri.refid >= n_ref || ri.nref >= n_ref;
   if (ri.bad_ref) { ri.refid = -1; ri.nref = -1; }
   ri.bad_op = false;
+  ri.ops4 = br_u32x4{0, 0, 0, 0};
   uint32_t clen = 0, span = 0;
-  if (want_cigar || want_end) {
+  if ((want_cigar || want_end) && ri.ncig) {
+    // the first four operations in one load (short reads rarely have more; the load may run past the CIGAR, never past the
+    // padded buffer): a loop of dependent 4-byte loads costs one memory latency per operation
     const uint8_t* cg = r + 36 + ri.lrn;
-    for (uint32_t k = 0; k < ri.ncig; k++) {
-      const uint32_t v = br_ld32(cg + 4 * k);
+    ri.ops4 = *(const br_u32x4*)cg;
+    auto one = [&](uint32_t v) {
       const uint32_t op = v & 15u;
       if (op > 8u) ri.bad_op = true;
       if ((0x18Du >> op) & 1u) span += v >> 4;  // M(0) D(2) N(3) =(7) X(8) consume the reference
       clen += br_dec_digits(v >> 4) + 1;
-    }
+    };
+    one(ri.ops4.x);
+    if (ri.ncig > 1) one(ri.ops4.y);
+    if (ri.ncig > 2) one(ri.ops4.z);
+    if (ri.ncig > 3) one(ri.ops4.w);
+    for (uint32_t k = 4; k < ri.ncig; k++) one(br_ld32(cg + 4 * k));
   }
   ri.end1 = ri.pos < 0 ? 0u : (uint32_t)ri.pos + span;  // 1-based inclusive end; 0 = None (noodles: start + span - 1)
   ri.len[0] = ri.lrn ? ri.lrn - 1 : 0;  // noodles strips the trailing NUL; a missing name ("*\0") is rendered "*"
@@ -239,11 +254,22 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_batch_bases(const uint8_t* __
   }
 }
 
+#ifndef BR_UNROLL
+#define BR_UNROLL 4
+#endif
 // ---- pass 2 -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t br_write_dec(uint8_t* d, uint32_t v) {
   const uint32_t nd = br_dec_digits(v);
   for (int k = (int)nd - 1; k >= 0; k--) { d[k] = (uint8_t)('0' + v % 10); v /= 10; }
   return nd;
+}
+// a reference name of `len` bytes at names + off, whose first 8 bytes are v (the table is padded by 8 bytes)
+__device__ __forceinline__ void br_put_name(uint8_t* d, const uint8_t* __restrict__ names, uint32_t off, uint32_t len, uint64_t v) {
+  if (len > 8) { for (uint32_t k = 0; k < len; k++) d[k] = names[off + k]; return; }
+  if (len & 8) { ((br_u64*)d)->v = v; return; }
+  if (len & 4) { ((br_u32*)d)->v = (uint32_t)v; v >>= 32; d += 4; }
+  if (len & 2) { ((br_u16*)d)->v = (uint16_t)v; v >>= 16; d += 2; }
+  if (len & 1) *d = (uint8_t)v;
 }
 __device__ __forceinline__ uint32_t br_qual_swar(uint32_t w) { return ((w & 0x7F7F7F7Fu) + 0x21212121u) ^ (w & 0x80808080u); }  // (q + 33) mod 256 per byte
 
@@ -254,7 +280,7 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
                                                               uint64_t n_tiles, const uint64_t* __restrict__ tile_sums,
                                                               const uint64_t* __restrict__ aux, uint32_t* qual_wide) {
   __shared__ uint64_t s_w[6][ROWS_TILE / WAVE];
-  __shared__ uint64_t s_rec[ROWS_TILE], s_on[ROWS_TILE], s_os[ROWS_TILE], s_oq[ROWS_TILE];
+  __shared__ uint64_t s_rec[ROWS_TILE], s_on[ROWS_TILE + 1], s_os[ROWS_TILE + 1], s_oq[ROWS_TILE + 1];
   __shared__ uint32_t s_meta[ROWS_TILE], s_lseq[ROWS_TILE];
   __shared__ uint16_t s_pair[256];  // packed byte -> two ASCII bases (high nibble first), little-endian u16
   {
@@ -274,6 +300,11 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
     ro = rows[i];
     ri = row_info(u + ro, ref_name_len, n_ref, binary_cigar, want_cigar, false);
   }
+  // reference names: offset and first 8 bytes now, so that the two dependent loads overlap the scans below
+  uint32_t nm1_off = 0, nm3_off = 0;
+  uint64_t nm1 = 0, nm3 = 0;
+  if (act && c.val[1] && ri.refid >= 0) { nm1_off = ref_name_off[ri.refid]; nm1 = ((const br_u64*)(ref_names + nm1_off))->v; }
+  if (act && c.val[3] && ri.nref >= 0) { nm3_off = ref_name_off[ri.nref]; nm3 = ((const br_u64*)(ref_names + nm3_off))->v; }
   // exclusive scan of every projected column inside the tile
   uint64_t off[6];
 #pragma unroll
@@ -307,29 +338,27 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
       o32[j] = (int32_t)(off[k] - bb);
       if (closes) o32[j + 1] = (int32_t)(off[k] + ri.len[k] - bb);
     }
-    // chrom / mate_chrom / cigar: one row per lane
-    if (c.val[1] && ri.refid >= 0) {
-      uint8_t* d = c.val[1] + off[1];
-      const uint32_t a = ref_name_off[ri.refid], e = ref_name_off[ri.refid + 1];
-      for (uint32_t k = a; k < e; k++) d[k - a] = ref_names[k];
-    }
-    if (c.val[3] && ri.nref >= 0) {
-      uint8_t* d = c.val[3] + off[3];
-      const uint32_t a = ref_name_off[ri.nref], e = ref_name_off[ri.nref + 1];
-      for (uint32_t k = a; k < e; k++) d[k - a] = ref_names[k];
-    }
+    // chrom / mate_chrom / cigar: one row per lane.  Names of up to 8 bytes (chr1 ... chrUn) are one load and at most three
+    // stores; the CIGAR's first four operations are already in registers.
+    if (c.val[1] && ri.refid >= 0) br_put_name(c.val[1] + off[1], ref_names, nm1_off, ri.len[1], nm1);
+    if (c.val[3] && ri.nref >= 0) br_put_name(c.val[3] + off[3], ref_names, nm3_off, ri.len[3], nm3);
     if (c.val[2]) {
       const uint8_t* cg = u + ro + 36 + ri.lrn;
       uint8_t* d = c.val[2] + off[2];
       if (binary_cigar) {
-        for (uint32_t k = 0; k < 4 * ri.ncig; k++) d[k] = cg[k];
+        if (ri.ncig > 0) ((br_u32*)d)[0].v = ri.ops4.x;
+        if (ri.ncig > 1) ((br_u32*)d)[1].v = ri.ops4.y;
+        if (ri.ncig > 2) ((br_u32*)d)[2].v = ri.ops4.z;
+        if (ri.ncig > 3) ((br_u32*)d)[3].v = ri.ops4.w;
+        for (uint32_t k = 4; k < ri.ncig; k++) ((br_u32*)d)[k].v = br_ld32(cg + 4 * k);
       } else {
         const char ops[] = "MIDNSHP=X???????";
-        for (uint32_t k = 0; k < ri.ncig; k++) {
-          const uint32_t v2 = br_ld32(cg + 4 * k);
-          d += br_write_dec(d, v2 >> 4);
-          *d++ = (uint8_t)ops[v2 & 15u];
-        }
+        auto put = [&](uint32_t v2) { d += br_write_dec(d, v2 >> 4); *d++ = (uint8_t)ops[v2 & 15u]; };
+        if (ri.ncig > 0) put(ri.ops4.x);
+        if (ri.ncig > 1) put(ri.ops4.y);
+        if (ri.ncig > 2) put(ri.ops4.z);
+        if (ri.ncig > 3) put(ri.ops4.w);
+        for (uint32_t k = 4; k < ri.ncig; k++) put(br_ld32(cg + 4 * k));
       }
     }
   }
@@ -337,92 +366,128 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass2(const uint8_t* __r
   s_meta[threadIdx.x] = ri.lrn | (ri.ncig << 8);
   s_lseq[threadIdx.x] = act ? ri.lseq : 0u;
   s_on[threadIdx.x] = off[0]; s_os[threadIdx.x] = off[4]; s_oq[threadIdx.x] = off[5];
-  __syncthreads();
-  if (!c.val[0] && !c.val[4] && !c.val[5]) return;
-  // name / sequence / quality: four 16-lane groups per wave, each on its own row; 16 rows of the tile in flight
-  const int g = lane >> 4, sl = lane & 15;
   const uint32_t nrow = (uint32_t)((n - tile * ROWS_TILE) < ROWS_TILE ? (n - tile * ROWS_TILE) : ROWS_TILE);
+  if (threadIdx.x + 1 == nrow) {  // closing entries: where the tile's name / sequence / quality bytes end
+    s_on[nrow] = off[0] + ri.len[0]; s_os[nrow] = off[4] + ri.len[4]; s_oq[nrow] = off[5] + ri.len[5];
+  }
+  __syncthreads();
   uint8_t* const d_name = c.val[0];
   uint8_t* const d_seq = c.val[4];
   uint8_t* const d_qual = c.val[5];
+  if (!d_name && !d_seq && !d_qual) return;
+  // ---- name / sequence / quality ------------------------------------------------------------------------------------
+  // Four 16-lane groups per wave, each on its own row of the wave's 64; a lane moves 16-byte chunks at per-row addresses
+  // (a partial last chunk is served by the overlapping 16 bytes that END at the segment's end); all loads of BR_UNROLL
+  // steps are issued before the first store.  Measured on 13.6 M rows of 150-base reads: the loads alone and the stores
+  // alone each run at 5.8 TB/s -- this phase is at the HBM roofline; an LDS-staged variant with aligned, fully coalesced
+  // global accesses was built and is 40 % slower (four times the instructions per row, no traffic saved), aligning the
+  // accesses changes nothing (-3 %), and 8- or 32-lane groups are equal or worse.
+  constexpr uint32_t G = 16, GS = G * 16;  // lanes per row group, bytes one group moves per step
+  const int g = lane / (int)G, sl = lane % (int)G;
   bool wide = false;
-  for (uint32_t it = 0; it < ROWS_TILE / 16; it++) {
-    const uint32_t k = it * 16 + (uint32_t)w * 4 + (uint32_t)g;
-    if (k >= nrow) continue;
-    const uint32_t meta = s_meta[k], lseq = s_lseq[k];
+  auto seq16 = [&](uint64_t pkd) {
+    br_u32x4 v;
+    v.x = (uint32_t)s_pair[pkd & 0xFF] | ((uint32_t)s_pair[(pkd >> 8) & 0xFF] << 16);
+    v.y = (uint32_t)s_pair[(pkd >> 16) & 0xFF] | ((uint32_t)s_pair[(pkd >> 24) & 0xFF] << 16);
+    v.z = (uint32_t)s_pair[(pkd >> 32) & 0xFF] | ((uint32_t)s_pair[(pkd >> 40) & 0xFF] << 16);
+    v.w = (uint32_t)s_pair[(pkd >> 48) & 0xFF] | ((uint32_t)s_pair[(pkd >> 56) & 0xFF] << 16);
+    return v;
+  };
+  auto qual16 = [&](br_u32x4 v) {
+    v.x = br_qual_swar(v.x); v.y = br_qual_swar(v.y); v.z = br_qual_swar(v.z); v.w = br_qual_swar(v.w);
+    wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
+    return v;
+  };
+  // chunk of a segment of `len` bytes that lane-chunk c0 serves: a partial last chunk is served by the (overlapping) 16
+  // bytes that END at the segment's end, so no lane runs a byte loop unless the whole segment is shorter than 16 bytes
+  auto tail_chunk = [](uint32_t c0, uint32_t len) { return (c0 + 16 <= len || len < 16) ? c0 : len - 16; };
+  struct Geom {
+    uint64_t rec, ono, oso, oqo;     // record start in u; first byte of the row in the three value buffers
+    uint32_t no, so, qo;             // name / packed bases / qualities, relative to rec
+    uint32_t ln, lseq;
+  };
+  auto geom = [&](uint32_t k) {
+    Geom e;
+    const uint32_t meta = s_meta[k];
     const uint32_t lrn = meta & 0xFFu, ncig = meta >> 8;
-    const uint64_t ono = s_on[k], oso = s_os[k], oqo = s_oq[k];
-    const uint8_t* np = u + s_rec[k] + 36;  // read_name starts 36 bytes into the record
-    const uint8_t* sp = np + lrn + 4ull * ncig;
-    const uint8_t* qp = sp + ((lseq + 1) >> 1);
-    // First 256 bytes of each segment: one 16-byte chunk per lane, all three loads issued before any store.  A partial
-    // last chunk is served by the (overlapping) 16 bytes that END at the segment's end, so no lane runs a byte loop unless
-    // the whole segment is shorter than 16 bytes.
+    e.lseq = s_lseq[k];
+    e.ono = s_on[k]; e.oso = s_os[k]; e.oqo = s_oq[k];
+    e.rec = s_rec[k];
+    e.no = 36;  // read_name starts 36 bytes into the record
+    e.so = 36 + lrn + 4 * ncig;
+    e.qo = e.so + ((e.lseq + 1) >> 1);
+    e.ln = lrn ? lrn - 1 : 0;
+    return e;
+  };
+
+  // direct path for the U x 4 rows of this wave from kb on
+  constexpr uint32_t U = BR_UNROLL;
+  const uint32_t kend_w = nrow < ((uint32_t)w + 1) * WAVE ? nrow : ((uint32_t)w + 1) * WAVE;  // this wave's rows end here
+  auto direct_rows = [&](uint32_t kb) {
+    br_u32x4 vn[U], vq[U];
+    uint64_t pk[U];
     const uint32_t c0 = (uint32_t)sl * 16;
-    const uint32_t ln = lrn ? lrn - 1 : 0;
-    const bool n_on = d_name && c0 < ln, s_on_ = d_seq && c0 < lseq, q_on = d_qual && c0 < lseq;
-    const uint32_t cn = (c0 + 16 <= ln || ln < 16) ? c0 : ln - 16;
-    const uint32_t cq = (c0 + 16 <= lseq || lseq < 16) ? c0 : lseq - 16;
-    const uint32_t cs = (c0 + 16 <= lseq || lseq < 16) ? c0 : ((lseq - 16) & ~1u);  // packed bytes start on even bases
-    const bool n_vec = n_on && ln >= 16, s_vec = s_on_ && lseq >= 16, q_vec = q_on && lseq >= 16;
-    br_u32x4 vn = {0, 0, 0, 0}, vq = {0, 0, 0, 0};
-    uint64_t pk = 0;
-    if (n_vec) vn = *(const br_u32x4*)(np + cn);
-    if (s_vec) pk = ((const br_u64*)(sp + (cs >> 1)))->v;
-    if (q_vec) vq = *(const br_u32x4*)(qp + cq);
-    if (n_vec) *(br_u32x4*)(d_name + ono + cn) = vn;
-    else if (n_on) for (uint32_t j = c0; j < ln; j++) d_name[ono + j] = np[j];
-    if (s_vec) {
-      br_u32x4 v;
-      v.x = (uint32_t)s_pair[pk & 0xFF] | ((uint32_t)s_pair[(pk >> 8) & 0xFF] << 16);
-      v.y = (uint32_t)s_pair[(pk >> 16) & 0xFF] | ((uint32_t)s_pair[(pk >> 24) & 0xFF] << 16);
-      v.z = (uint32_t)s_pair[(pk >> 32) & 0xFF] | ((uint32_t)s_pair[(pk >> 40) & 0xFF] << 16);
-      v.w = (uint32_t)s_pair[(pk >> 48) & 0xFF] | ((uint32_t)s_pair[(pk >> 56) & 0xFF] << 16);
-      *(br_u32x4*)(d_seq + oso + cs) = v;
-      // odd-length tail: the vector ended one base early
-      if (cs != c0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
-    } else if (s_on_) {
-      for (uint32_t j = c0; j < lseq; j += 2) {
-        const uint16_t pr = s_pair[sp[j >> 1]];
-        d_seq[oso + j] = (uint8_t)pr;
-        if (j + 1 < lseq) d_seq[oso + j + 1] = (uint8_t)(pr >> 8);
+#pragma unroll
+    for (uint32_t q = 0; q < U; q++) {
+      const uint32_t k = kb + q * (WAVE / G) + (uint32_t)g;
+      vn[q] = br_u32x4{0, 0, 0, 0}; vq[q] = br_u32x4{0, 0, 0, 0}; pk[q] = 0;
+      if (k >= kend_w) continue;
+      const Geom e = geom(k);
+      const uint8_t* r = u + e.rec;
+      if (d_name && c0 < e.ln && e.ln >= 16) vn[q] = *(const br_u32x4*)(r + e.no + tail_chunk(c0, e.ln));
+      if (d_seq && c0 < e.lseq && e.lseq >= 16) pk[q] = ((const br_u64*)(r + e.so + ((tail_chunk(c0, e.lseq) & ~1u) >> 1)))->v;
+      if (d_qual && c0 < e.lseq && e.lseq >= 16) vq[q] = *(const br_u32x4*)(r + e.qo + tail_chunk(c0, e.lseq));
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < U; q++) {
+      const uint32_t k = kb + q * (WAVE / G) + (uint32_t)g;
+      if (k >= kend_w) continue;
+      const Geom e = geom(k);
+      const uint32_t ln = e.ln, lseq = e.lseq;
+      const uint8_t *np = u + e.rec + e.no, *sp = u + e.rec + e.so, *qp = u + e.rec + e.qo;
+      if (d_name && c0 < ln) {
+        if (ln >= 16) *(br_u32x4*)(d_name + e.ono + tail_chunk(c0, ln)) = vn[q];
+        else for (uint32_t j = 0; j < ln; j++) d_name[e.ono + j] = np[j];
+      }
+      if (d_seq && c0 < lseq) {
+        if (lseq >= 16) {
+          const uint32_t cs = tail_chunk(c0, lseq) & ~1u;  // packed bytes start on even bases
+          *(br_u32x4*)(d_seq + e.oso + cs) = seq16(pk[q]);
+          if (cs != c0 && (lseq & 1u)) d_seq[e.oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];  // the vector ended one base early
+        } else {
+          for (uint32_t j = 0; j < lseq; j += 2) {
+            const uint16_t pr = s_pair[sp[j >> 1]];
+            d_seq[e.oso + j] = (uint8_t)pr;
+            if (j + 1 < lseq) d_seq[e.oso + j + 1] = (uint8_t)(pr >> 8);
+          }
+        }
+      }
+      if (d_qual && c0 < lseq) {
+        if (lseq >= 16) *(br_u32x4*)(d_qual + e.oqo + tail_chunk(c0, lseq)) = qual16(vq[q]);
+        else for (uint32_t j = 0; j < lseq; j++) {
+          const uint32_t qv = ((uint32_t)qp[j] + 33u) & 0xFFu;
+          wide = wide || qv >= 128u;
+          d_qual[e.oqo + j] = (uint8_t)qv;
+        }
+      }
+      // rows longer than 256 bytes per segment (long reads): remaining chunks, same scheme
+      if (d_name) for (uint32_t cc0 = c0 + GS; cc0 < ln; cc0 += GS) {
+        const uint32_t cc = tail_chunk(cc0, ln);
+        *(br_u32x4*)(d_name + e.ono + cc) = *(const br_u32x4*)(np + cc);
+      }
+      if (d_seq) for (uint32_t cc0 = c0 + GS; cc0 < lseq; cc0 += GS) {
+        const uint32_t cc = tail_chunk(cc0, lseq) & ~1u;
+        *(br_u32x4*)(d_seq + e.oso + cc) = seq16(((const br_u64*)(sp + (cc >> 1)))->v);
+        if (cc != cc0 && (lseq & 1u)) d_seq[e.oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
+      }
+      if (d_qual) for (uint32_t cc0 = c0 + GS; cc0 < lseq; cc0 += GS) {
+        const uint32_t cc = tail_chunk(cc0, lseq);
+        *(br_u32x4*)(d_qual + e.oqo + cc) = qual16(*(const br_u32x4*)(qp + cc));
       }
     }
-    if (q_vec) {
-      vq.x = br_qual_swar(vq.x); vq.y = br_qual_swar(vq.y); vq.z = br_qual_swar(vq.z); vq.w = br_qual_swar(vq.w);
-      wide = wide || ((vq.x | vq.y | vq.z | vq.w) & 0x80808080u);  // a byte >= 128 is a two-byte UTF-8 char: exact wide path
-      *(br_u32x4*)(d_qual + oqo + cq) = vq;
-    } else if (q_on) {
-      for (uint32_t j = c0; j < lseq; j++) {
-        const uint32_t q = ((uint32_t)qp[j] + 33u) & 0xFFu;
-        wide = wide || q >= 128u;
-        d_qual[oqo + j] = (uint8_t)q;
-      }
-    }
-    // rows longer than 256 bytes per segment (long reads): remaining chunks, same scheme
-    if (d_name) for (uint32_t cc0 = c0 + 256; cc0 < ln; cc0 += 256) {
-      const uint32_t cc = cc0 + 16 <= ln ? cc0 : ln - 16;
-      *(br_u32x4*)(d_name + ono + cc) = *(const br_u32x4*)(np + cc);
-    }
-    if (d_seq) for (uint32_t cc0 = c0 + 256; cc0 < lseq; cc0 += 256) {
-      const uint32_t cc = cc0 + 16 <= lseq ? cc0 : ((lseq - 16) & ~1u);
-      const uint64_t p2 = ((const br_u64*)(sp + (cc >> 1)))->v;
-      br_u32x4 v;
-      v.x = (uint32_t)s_pair[p2 & 0xFF] | ((uint32_t)s_pair[(p2 >> 8) & 0xFF] << 16);
-      v.y = (uint32_t)s_pair[(p2 >> 16) & 0xFF] | ((uint32_t)s_pair[(p2 >> 24) & 0xFF] << 16);
-      v.z = (uint32_t)s_pair[(p2 >> 32) & 0xFF] | ((uint32_t)s_pair[(p2 >> 40) & 0xFF] << 16);
-      v.w = (uint32_t)s_pair[(p2 >> 48) & 0xFF] | ((uint32_t)s_pair[(p2 >> 56) & 0xFF] << 16);
-      *(br_u32x4*)(d_seq + oso + cc) = v;
-      if (cc != cc0 && (lseq & 1u)) d_seq[oso + lseq - 1] = (uint8_t)s_pair[sp[(lseq - 1) >> 1]];
-    }
-    if (d_qual) for (uint32_t cc0 = c0 + 256; cc0 < lseq; cc0 += 256) {
-      const uint32_t cc = cc0 + 16 <= lseq ? cc0 : lseq - 16;
-      br_u32x4 v = *(const br_u32x4*)(qp + cc);
-      v.x = br_qual_swar(v.x); v.y = br_qual_swar(v.y); v.z = br_qual_swar(v.z); v.w = br_qual_swar(v.w);
-      wide = wide || ((v.x | v.y | v.z | v.w) & 0x80808080u);
-      *(br_u32x4*)(d_qual + oqo + cc) = v;
-    }
-  }
+  };
+
+  for (uint32_t k0 = (uint32_t)w * WAVE; k0 < kend_w; k0 += U * (WAVE / G)) direct_rows(k0);
   if (d_qual && __any(wide) && lane == 0) atomicExch(qual_wide, 1u);
 }
 

@@ -230,7 +230,7 @@ struct Provider : BgzfSource {
       off.push_back((uint32_t)blob.size());
       len.push_back((uint32_t)n.size());
     }
-    img->d_ref_names.alloc(std::max<size_t>(blob.size(), 1));
+    img->d_ref_names.alloc(blob.size() + 8);  // bam_rows.hip reads names 8 bytes at a time
     img->d_ref_name_len.alloc(std::max<size_t>(len.size(), 1));
     DevBuf<uint32_t> o(off.size());
     if (!blob.empty()) HIP_CHECK(hipMemcpy(img->d_ref_names.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
