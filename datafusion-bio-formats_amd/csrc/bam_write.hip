@@ -103,15 +103,139 @@ __device__ __forceinline__ SerRow ser_row(const SerCols& c, uint64_t i, uint32_t
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_ser_sizes(SerCols c, uint64_t n, uint32_t* __restrict__ rec_bytes, uint32_t* err) {
+// ---- tag columns -> aux fields (sam_tag_io.rs:109-147, 206-656; noodles-bam's data encoder) -------------------------
+__device__ __forceinline__ uint32_t sam_int_width(uint8_t t) { return (t == 'c' || t == 'C') ? 1u : (t == 's' || t == 'S') ? 2u : 4u; }
+// the element at index j of a fixed-width buffer as (signed, value); false for a float / other kind
+__device__ __forceinline__ bool ser_int_at(uint8_t kind, const uint8_t* v, int64_t j, bool* neg, uint64_t* mag_or_val, int64_t* sv) {
+  switch (kind) {
+    case SK_I8: *sv = ((const int8_t*)v)[j]; break;
+    case SK_I16: *sv = ((const int16_t*)v)[j]; break;
+    case SK_I32: *sv = ((const int32_t*)v)[j]; break;
+    case SK_I64: *sv = ((const int64_t*)v)[j]; break;
+    case SK_U8: *mag_or_val = ((const uint8_t*)v)[j]; *neg = false; *sv = 0; return true;
+    case SK_U16: *mag_or_val = ((const uint16_t*)v)[j]; *neg = false; *sv = 0; return true;
+    case SK_U32: *mag_or_val = ((const uint32_t*)v)[j]; *neg = false; *sv = 0; return true;
+    case SK_U64: *mag_or_val = ((const uint64_t*)v)[j]; *neg = false; *sv = 0; return true;
+    default: return false;
+  }
+  *neg = *sv < 0;
+  *mag_or_val = (uint64_t)*sv;
+  return true;
+}
+// T::try_from(value) for the SAM integer types; the accepted value's low bytes are the encoding
+__device__ __forceinline__ bool sam_int_fits(uint8_t t, bool neg, uint64_t uv, int64_t sv) {
+  switch (t) {
+    case 'c': return neg ? sv >= -128 : uv <= 127u;
+    case 's': return neg ? sv >= -32768 : uv <= 32767u;
+    case 'i': return neg ? sv >= -2147483648ll : uv <= 2147483647u;
+    case 'C': return !neg && uv <= 255u;
+    case 'S': return !neg && uv <= 65535u;
+    case 'I': return !neg && uv <= 4294967295ull;
+    default: return false;
+  }
+}
+__device__ __forceinline__ bool f64_fits_f32(double v) { return isfinite(v) && v >= -3.4028234663852886e38 && v <= 3.4028234663852886e38; }
+__device__ __forceinline__ uint8_t ascii_upper(uint8_t b) { return (b >= 'a' && b <= 'z') ? (uint8_t)(b - 32) : b; }
+
+// Bytes of one tag column's aux field for the row (0: NULL, nothing is written); o == nullptr only measures and reports.
+__device__ uint32_t ser_tag_field(const SerTagCol& t, uint64_t row, uint32_t ci, uint8_t* o, unsigned long long* tag_err) {
+  const int64_t j = (int64_t)row + t.offset;
+  if (!bit_valid(t.valid, j)) return 0;
+  auto fail = [&](uint32_t code) {
+    if (tag_err) atomicMin(tag_err, ((unsigned long long)row << 16) | ((unsigned long long)ci << 8) | code);
+    return 0u;
+  };
+  auto head = [&](uint8_t type) { if (o) { o[0] = t.tag[0]; o[1] = t.tag[1]; o[2] = type; } };
+  bool neg = false;
+  uint64_t uv = 0;
+  int64_t sv = 0;
+  switch (t.sam_type) {
+    case 'i': case 'c': case 's': case 'C': case 'S': case 'I': {
+      if (!ser_int_at(t.kind, t.values, j, &neg, &uv, &sv)) return 0;  // (the host has rejected the column's type)
+      if (!sam_int_fits(t.sam_type, neg, uv, sv)) return fail(20);
+      const uint32_t w = sam_int_width(t.sam_type);
+      head(t.sam_type);
+      if (o) for (uint32_t k = 0; k < w; k++) o[3 + k] = (uint8_t)(uv >> (8 * k));
+      return 3 + w;
+    }
+    case 'f': {
+      float f;
+      if (t.kind == SK_F32) f = ((const float*)t.values)[j];
+      else { const double d = ((const double*)t.values)[j]; if (!f64_fits_f32(d)) return fail(21); f = (float)d; }
+      head('f');
+      if (o) bw_st32(o + 3, __float_as_uint(f));
+      return 7;
+    }
+    case 'A': {
+      uint8_t b;
+      if (t.kind == SK_UTF8) {
+        const int32_t a = t.off[j], e = t.off[j + 1];
+        if (e - a != 1 || t.values[a] >= 128) return fail(23);
+        b = t.values[a];
+      } else {
+        if (!ser_int_at(t.kind, t.values, j, &neg, &uv, &sv)) return 0;
+        if (neg || uv > 255u) return fail(24);
+        b = (uint8_t)uv;
+      }
+      head('A');
+      if (o) o[3] = b;
+      return 4;
+    }
+    case 'H': {
+      const int32_t a = t.off[j], e = t.off[j + 1];
+      if ((e - a) & 1) return fail(22);
+      for (int32_t k = a; k < e; k++) {
+        const uint8_t b = ascii_upper(t.values[k]);
+        if (!((b >= '0' && b <= '9') || (b >= 'A' && b <= 'F'))) return fail(22);
+        if (o) o[3 + (k - a)] = b;
+      }
+      head('H');
+      if (o) o[3 + (e - a)] = 0;
+      return 4 + (uint32_t)(e - a);
+    }
+    case 'B': {
+      const int32_t a = t.off[j], e = t.off[j + 1];
+      const uint32_t cnt = (uint32_t)(e - a);
+      const uint32_t w = t.subtype == 'f' ? 4u : sam_int_width(t.subtype);
+      head('B');
+      if (o) { o[3] = t.subtype; bw_st32(o + 4, cnt); }
+      for (int32_t k = a; k < e; k++) {
+        const int64_t q = (int64_t)k + t.eoffset;
+        if (!bit_valid(t.evalid, q)) return fail(25);
+        uint32_t bits;
+        if (t.subtype == 'f') {
+          if (t.ekind == SK_F32) bits = __float_as_uint(((const float*)t.values)[q]);
+          else { const double d = ((const double*)t.values)[q]; if (!f64_fits_f32(d)) return fail(26); bits = __float_as_uint((float)d); }
+        } else {
+          if (!ser_int_at(t.ekind, t.values, q, &neg, &uv, &sv)) return 0;
+          if (!sam_int_fits(t.subtype, neg, uv, sv)) return fail(26);
+          bits = (uint32_t)uv;
+        }
+        if (o) for (uint32_t b = 0; b < w; b++) o[8 + (uint32_t)(k - a) * w + b] = (uint8_t)(bits >> (8 * b));
+      }
+      return 8 + cnt * w;
+    }
+    default: {  // 'Z', and any other type character on a string column (sam_tag_io.rs:227-233)
+      const int32_t a = t.off[j], e = t.off[j + 1];
+      head('Z');
+      if (o) { for (int32_t k = a; k < e; k++) o[3 + (k - a)] = t.values[k]; o[3 + (e - a)] = 0; }
+      return 4 + (uint32_t)(e - a);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ser_sizes(SerCols c, SerTags tg, uint64_t n, uint32_t* __restrict__ rec_bytes, uint32_t* err,
+                                                   unsigned long long* tag_err) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const SerRow r = ser_row(c, i, err);
-  rec_bytes[i] = 4u + 32u + r.lrn + 4u * r.ncig + ((r.lseq + 1u) >> 1) + r.lseq;
+  uint32_t aux = 0;
+  for (int32_t k = 0; k < tg.n; k++) aux += ser_tag_field(tg.cols[k], i, (uint32_t)k, nullptr, tag_err);
+  rec_bytes[i] = 4u + 32u + r.lrn + 4u * r.ncig + ((r.lseq + 1u) >> 1) + r.lseq + aux;
 }
 
-__global__ __launch_bounds__(256) void k_ser_write(SerCols c, uint64_t n, const uint64_t* __restrict__ rec_off, uint8_t* __restrict__ out,
-                                                   uint32_t* err) {
+__global__ __launch_bounds__(256) void k_ser_write(SerCols c, SerTags tg, uint64_t n, const uint64_t* __restrict__ rec_off,
+                                                   uint8_t* __restrict__ out, uint32_t* err) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint32_t dummy = 0;
@@ -119,7 +243,7 @@ __global__ __launch_bounds__(256) void k_ser_write(SerCols c, uint64_t n, const 
   const SerRow r = ser_row(c, i, err);
   const int64_t j = (int64_t)i + c.offset;
   uint8_t* o = out + rec_off[i];
-  const uint32_t block_size = 32u + r.lrn + 4u * r.ncig + ((r.lseq + 1u) >> 1) + r.lseq;
+  const uint32_t block_size = (uint32_t)(rec_off[i + 1] - rec_off[i]) - 4u;  // aux fields included
   const int32_t refid = c.refid[i], nref = c.mate_refid[i];
   int32_t pos = -1, npos = -1;
   if (bit_valid(c.start_valid, j)) {
@@ -190,15 +314,17 @@ __global__ __launch_bounds__(256) void k_ser_write(SerCols c, uint64_t n, const 
   uint8_t* ql = sq + ((r.lseq + 1u) >> 1);
   if (r.lqual == 0) { for (uint32_t k = 0; k < r.lseq; k++) ql[k] = 0xFF; }
   else { for (uint32_t k = 0; k < r.lseq; k++) { const uint8_t b = r.qual[k]; ql[k] = b >= 33 ? (uint8_t)(b - 33) : 0; } }  // saturating_sub(33)
+  uint8_t* ax = ql + r.lseq;
+  for (int32_t k = 0; k < tg.n; k++) ax += ser_tag_field(tg.cols[k], i, (uint32_t)k, ax, nullptr);
 }
 
-void launch_ser_sizes(SerCols c, uint64_t n, uint32_t* rec_bytes, uint32_t* err, hipStream_t st) {
+void launch_ser_sizes(SerCols c, SerTags t, uint64_t n, uint32_t* rec_bytes, uint32_t* err, unsigned long long* tag_err, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_ser_sizes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, n, rec_bytes, err);
+  hipLaunchKernelGGL(k_ser_sizes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, t, n, rec_bytes, err, tag_err);
 }
-void launch_ser_write(SerCols c, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st) {
+void launch_ser_write(SerCols c, SerTags t, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st) {
   if (!n) return;
-  hipLaunchKernelGGL(k_ser_write, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, n, rec_off, out, err);
+  hipLaunchKernelGGL(k_ser_write, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, c, t, n, rec_off, out, err);
 }
 
 // =================================================================================================================

@@ -4,8 +4,12 @@
 // serialisation of bio-format-core/src/sam_record_serializer.rs and the BGZF framing of noodles-bgzf's Writer.  The
 // serialisation, CRC32 and DEFLATE run on the GPU (bam_write.hip); the host uploads the batch's column buffers, resolves
 // chrom / mate_chrom names against the header (a dictionary lookup) and writes the finished members to the file.
-// Core columns only: tag columns of a batch are not written (noted in DESIGN.md).
+// Tag columns (fields carrying bio.bam.tag.tag metadata) become aux fields in schema order (build_tag_data,
+// bio-format-core/src/sam_tag_io.rs:109-147); type errors are the reference's, worded on the host from the batch.
+#include <algorithm>
 #include <cerrno>
+#include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -172,6 +176,147 @@ static void up_fixed(const ArrowArray* a, DevCol* d, hipStream_t st) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(d->values.p, a->buffers[1], bytes, hipMemcpyHostToDevice, st));
 }
 
+// ---- tag columns ---------------------------------------------------------------------------------------------------
+// Arrow C Data metadata: int32 n, then n x (int32 key length, key, int32 value length, value)
+static std::unordered_map<std::string, std::string> field_metadata(const ArrowSchema* f) {
+  std::unordered_map<std::string, std::string> m;
+  const char* p = f->metadata;
+  if (!p) return m;
+  int32_t n;
+  memcpy(&n, p, 4); p += 4;
+  for (int32_t i = 0; i < n; i++) {
+    int32_t kl, vl;
+    memcpy(&kl, p, 4); p += 4;
+    std::string k(p, (size_t)kl); p += kl;
+    memcpy(&vl, p, 4); p += 4;
+    std::string v(p, (size_t)vl); p += vl;
+    m.emplace(std::move(k), std::move(v));
+  }
+  return m;
+}
+static uint8_t kind_of(const std::string& fmt) {
+  if (fmt == "c") return SK_I8; if (fmt == "s") return SK_I16; if (fmt == "i") return SK_I32; if (fmt == "l") return SK_I64;
+  if (fmt == "C") return SK_U8; if (fmt == "S") return SK_U16; if (fmt == "I") return SK_U32; if (fmt == "L") return SK_U64;
+  if (fmt == "f") return SK_F32; if (fmt == "g") return SK_F64; if (fmt == "u") return SK_UTF8; if (fmt == "+l") return SK_LIST;
+  return 0;
+}
+static size_t kind_width(uint8_t k) {
+  switch (k) { case SK_I8: case SK_U8: return 1; case SK_I16: case SK_U16: return 2; case SK_I32: case SK_U32: case SK_F32: return 4;
+               case SK_I64: case SK_U64: case SK_F64: return 8; default: return 0; }
+}
+static bool kind_is_int(uint8_t k) { return k >= SK_I8 && k <= SK_U64; }
+static std::string arrow_type_name(const ArrowSchema* f) {   // the DataType's Debug form for the common cases
+  const std::string fmt = f->format ? f->format : "";
+  static const std::unordered_map<std::string, std::string> names = {
+      {"c", "Int8"}, {"C", "UInt8"}, {"s", "Int16"}, {"S", "UInt16"}, {"i", "Int32"}, {"I", "UInt32"}, {"l", "Int64"}, {"L", "UInt64"},
+      {"f", "Float32"}, {"g", "Float64"}, {"u", "Utf8"}, {"U", "LargeUtf8"}, {"z", "Binary"}, {"b", "Boolean"}, {"n", "Null"}};
+  auto it = names.find(fmt);
+  if (it != names.end()) return it->second;
+  if (fmt == "+l" && f->n_children == 1) return "List(" + arrow_type_name(f->children[0]) + ")";
+  return fmt;
+}
+// f64 as Rust's Display prints it: shortest digits that round-trip, positional notation, no exponent
+static std::string rust_f64(double v) {
+  if (std::isnan(v)) return "NaN";
+  if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+  char buf[64];
+  int prec = 0;
+  for (; prec < 17; prec++) {
+    snprintf(buf, sizeof buf, "%.*e", prec, v);
+    if (strtod(buf, nullptr) == v) break;
+  }
+  std::string t = buf;                       // [-]d.ddddde[+-]xx
+  const bool neg = t[0] == '-';
+  if (neg) t.erase(0, 1);
+  const size_t ep = t.find('e');
+  const int ex = atoi(t.c_str() + ep + 1);
+  std::string dig = t.substr(0, ep);
+  dig.erase(std::remove(dig.begin(), dig.end(), '.'), dig.end());
+  std::string out;
+  if (ex >= 0) {
+    if ((int)dig.size() <= ex + 1) out = dig + std::string((size_t)(ex + 1 - (int)dig.size()), '0');
+    else out = dig.substr(0, (size_t)ex + 1) + "." + dig.substr((size_t)ex + 1);
+  } else {
+    out = "0." + std::string((size_t)(-ex - 1), '0') + dig;
+  }
+  while (out.find('.') != std::string::npos && out.back() == '0') out.pop_back();
+  if (!out.empty() && out.back() == '.') out.pop_back();
+  return (neg ? "-" : "") + out;
+}
+static bool host_valid(const ArrowArray* a, int64_t i) {
+  const uint8_t* v = (const uint8_t*)a->buffers[0];
+  const int64_t j = i + a->offset;
+  return a->null_count == 0 || !v || ((v[j >> 3] >> (j & 7)) & 1);
+}
+static std::string host_num(const ArrowArray* a, uint8_t kind, int64_t j) {   // element j (absolute index) as Rust prints it
+  const void* v = a->buffers[1];
+  switch (kind) {
+    case SK_I8: return std::to_string((int)((const int8_t*)v)[j]); case SK_I16: return std::to_string(((const int16_t*)v)[j]);
+    case SK_I32: return std::to_string(((const int32_t*)v)[j]); case SK_I64: return std::to_string(((const int64_t*)v)[j]);
+    case SK_U8: return std::to_string((unsigned)((const uint8_t*)v)[j]); case SK_U16: return std::to_string(((const uint16_t*)v)[j]);
+    case SK_U32: return std::to_string(((const uint32_t*)v)[j]); case SK_U64: return std::to_string(((const uint64_t*)v)[j]);
+    case SK_F32: return rust_f64((double)((const float*)v)[j]); case SK_F64: return rust_f64(((const double*)v)[j]);
+    default: return "?";
+  }
+}
+static bool host_int_fits(uint8_t t, const ArrowArray* a, uint8_t kind, int64_t j) {
+  const void* v = a->buffers[1];
+  bool neg = false; uint64_t u = 0; int64_t sv = 0;
+  switch (kind) {
+    case SK_I8: sv = ((const int8_t*)v)[j]; break; case SK_I16: sv = ((const int16_t*)v)[j]; break;
+    case SK_I32: sv = ((const int32_t*)v)[j]; break; case SK_I64: sv = ((const int64_t*)v)[j]; break;
+    case SK_U8: u = ((const uint8_t*)v)[j]; break; case SK_U16: u = ((const uint16_t*)v)[j]; break;
+    case SK_U32: u = ((const uint32_t*)v)[j]; break; case SK_U64: u = ((const uint64_t*)v)[j]; break;
+    default: return true;
+  }
+  if (kind <= SK_I64) { neg = sv < 0; u = (uint64_t)sv; }
+  switch (t) {
+    case 'c': return neg ? sv >= -128 : u <= 127u; case 's': return neg ? sv >= -32768 : u <= 32767u;
+    case 'i': return neg ? sv >= -2147483648ll : u <= 2147483647u; case 'C': return !neg && u <= 255u;
+    case 'S': return !neg && u <= 65535u; case 'I': return !neg && u <= 4294967295ull; default: return true;
+  }
+}
+struct TagPlan {            // one tag column: what the device needs + what the host needs to word an error
+  SerTagCol d{};
+  const ArrowArray* a = nullptr;
+  const ArrowSchema* f = nullptr;
+  DevCol dev;
+  DevBuf<uint8_t> evalid;
+};
+[[noreturn]] static void throw_tag_err(const std::vector<std::unique_ptr<TagPlan>>& plans, unsigned long long key) {
+  const int64_t row = (int64_t)(key >> 16);
+  const uint32_t ci = (uint32_t)((key >> 8) & 0xFFu), code = (uint32_t)(key & 0xFFu);
+  const TagPlan& t = *plans.at(ci);
+  const int64_t j = row + t.a->offset;
+  auto str_at = [&]() {
+    const int32_t* off = (const int32_t*)t.a->buffers[1];
+    return std::string((const char*)t.a->buffers[2] + off[j], (size_t)(off[j + 1] - off[j]));
+  };
+  switch (code) {
+    case 20: throw Error("Integer value " + host_num(t.a, t.d.kind, j) + " does not fit SAM type '" + std::string(1, (char)t.d.sam_type) + "'");
+    case 21: throw Error("Float value " + host_num(t.a, t.d.kind, j) + " does not fit SAM type 'f'");
+    case 22: { std::string v = str_at(); for (auto& ch : v) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32); throw Error("Invalid SAM hex tag value '" + v + "'"); }
+    case 23: throw Error("Character tags must be a single ASCII byte, got '" + str_at() + "'");
+    case 24: throw Error("Character tag value " + host_num(t.a, t.d.kind, j) + " does not fit into a single byte");
+    case 25: throw Error("SAM array tags cannot contain null elements");
+    case 26: {
+      const int32_t* off = (const int32_t*)t.a->buffers[1];
+      const ArrowArray* ch = t.a->children[0];
+      for (int32_t k = off[j]; k < off[j + 1]; k++) {
+        const int64_t q = (int64_t)k + ch->offset;
+        bool bad;
+        if (t.d.subtype == 'f') {
+          const double v = t.d.ekind == SK_F64 ? ((const double*)ch->buffers[1])[q] : (double)((const float*)ch->buffers[1])[q];
+          bad = !(std::isfinite(v) && v >= -3.4028234663852886e38 && v <= 3.4028234663852886e38);
+        } else bad = !host_int_fits(t.d.subtype, ch, t.d.ekind, q);
+        if (bad) throw Error("Array element " + host_num(ch, t.d.ekind, q) + " does not fit SAM subtype '" + std::string(1, (char)t.d.subtype) + "'");
+      }
+      throw Error("Array element does not fit its SAM subtype");
+    }
+    default: throw Error("Failed to write BAM records: tag error " + std::to_string(code));
+  }
+}
+
 static void throw_ser_err(uint32_t e) {
   switch (e) {
     case 0: return;
@@ -311,20 +456,122 @@ int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* ba
   HIP_CHECK(hipMemcpyAsync(d_refid.p, refid.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(d_mrefid.p, mrefid.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   c.refid = d_refid.p; c.mate_refid = d_mrefid.p;
+  // tag columns: every field that carries bio.bam.tag.tag metadata, in schema order (table_provider.rs:1137-1143,
+  // sam_record_serializer.rs:281-299); the SAM type comes from bio.bam.tag.type, "Z" when absent (sam_tag_io.rs:129-133)
+  std::vector<std::unique_ptr<TagPlan>> plans;
+  for (int64_t ci = 0; ci < schema->n_children; ci++) {
+    const ArrowSchema* f = schema->children[ci];
+    const auto md = field_metadata(f);
+    if (!md.count("bio.bam.tag.tag")) continue;
+    const std::string tname = f->name ? f->name : "";
+    const ArrowArray* a = batch->children[ci];
+    if (a->length != n) throw Error("Failed to write BAM records: columns differ in length or offset");
+    if (a->null_count == a->length && a->length > 0) continue;   // nothing to write; the reference never looks at the type
+    if (tname.size() != 2) continue;                             // sam_tag_io.rs:135-138
+    std::string spec = "Z";
+    if (auto it = md.find("bio.bam.tag.type"); it != md.end()) spec = it->second;
+    // parse_sam_tag_type (tag_registry.rs:78-106)
+    char sam_type = 0, subtype = 0;
+    {
+      const size_t colon = spec.find(':');
+      if (colon == std::string::npos) {
+        if (spec.size() != 1) throw Error("Invalid SAM tag type metadata: Invalid SAM tag type '" + spec + "': type must be a single character");
+        sam_type = spec[0];
+      } else if (spec.compare(0, colon, "B") == 0 && spec.find(':', colon + 1) == std::string::npos) {
+        const std::string sub = spec.substr(colon + 1);
+        if (sub.size() != 1) throw Error("Invalid SAM tag type metadata: Invalid SAM tag array type '" + spec + "': subtype must be a single character");
+        if (!strchr("cCsSiIf", sub[0])) throw Error("Invalid SAM tag type metadata: Unsupported SAM array subtype '" + sub + "'");
+        sam_type = 'B'; subtype = sub[0];
+      } else {
+        throw Error("Invalid SAM tag type metadata: Invalid SAM tag type '" + spec + "': expected 'TYPE' or 'B:SUBTYPE'");
+      }
+    }
+    const std::string fmt = f->format ? f->format : "";
+    const uint8_t kind = kind_of(fmt);
+    const std::string tn = arrow_type_name(f);
+    std::unique_ptr<TagPlan> t(new TagPlan);
+    t->a = a; t->f = f;
+    t->d.tag[0] = (uint8_t)tname[0]; t->d.tag[1] = (uint8_t)tname[1];
+    t->d.kind = kind; t->d.offset = a->offset;
+    if (strchr("icsCSI", sam_type)) {
+      if (!kind_is_int(kind)) throw Error("Tag value type mismatch for integer: " + tn);
+    } else if (sam_type == 'f') {
+      if (kind != SK_F32 && kind != SK_F64) throw Error("Tag value type mismatch for float: " + tn);
+    } else if (sam_type == 'Z') {
+      if (kind != SK_UTF8) throw Error("Tag value type mismatch for string: " + tn);
+    } else if (sam_type == 'H') {
+      if (kind != SK_UTF8) throw Error("Tag value type mismatch for hex string: " + tn);
+    } else if (sam_type == 'A') {
+      if (kind != SK_UTF8 && !kind_is_int(kind)) throw Error("Tag value type mismatch for character: " + tn);
+    } else if (sam_type == 'B') {
+      if (kind != SK_LIST) throw Error("Tag value type mismatch for array: " + tn);
+      const ArrowSchema* cf = f->children[0];
+      const uint8_t ek = kind_of(cf->format ? cf->format : "");
+      if (!subtype) {  // sam_array_subtype_from_arrow_type (tag_registry.rs:48-59)
+        switch (ek) { case SK_I8: subtype = 'c'; break; case SK_U8: subtype = 'C'; break; case SK_I16: subtype = 's'; break;
+                      case SK_U16: subtype = 'S'; break; case SK_I32: subtype = 'i'; break; case SK_U32: subtype = 'I'; break;
+                      case SK_F32: subtype = 'f'; break; default: break; }
+        if (!subtype) throw Error("Unable to determine SAM array subtype for Arrow type " + arrow_type_name(cf));
+      }
+      const bool ok = subtype == 'f' ? (ek == SK_F32 || ek == SK_F64) : kind_is_int(ek);
+      if (!ok) throw Error("Unsupported array element type for SAM subtype '" + std::string(1, subtype) + "': " + arrow_type_name(cf));
+      t->d.ekind = ek;
+    } else {
+      if (kind != SK_UTF8) continue;   // any other type character: a string column is written as Z, anything else skipped (:227-233)
+      sam_type = 'Z';
+    }
+    t->d.sam_type = (uint8_t)sam_type; t->d.subtype = (uint8_t)subtype;
+    // upload
+    t->d.valid = up_valid(a, &t->dev, st);
+    if (kind == SK_UTF8) { up_var(a, &t->dev, st); t->d.off = t->dev.off.p; t->d.values = t->dev.values.p; }
+    else if (kind == SK_LIST) {
+      const ArrowArray* ch = a->children[0];
+      const size_t n_off = (size_t)(a->offset + a->length + 1);
+      t->dev.off.alloc(n_off);
+      HIP_CHECK(hipMemcpyAsync(t->dev.off.p, a->buffers[1], n_off * 4, hipMemcpyHostToDevice, st));
+      const size_t bytes = (size_t)(ch->offset + ch->length) * kind_width(t->d.ekind);
+      t->dev.values.alloc(bytes + 8);
+      if (bytes) HIP_CHECK(hipMemcpyAsync(t->dev.values.p, ch->buffers[1], bytes, hipMemcpyHostToDevice, st));
+      t->d.off = t->dev.off.p; t->d.values = t->dev.values.p; t->d.eoffset = ch->offset;
+      if (ch->null_count != 0 && ch->buffers[0]) {
+        const size_t vb = (size_t)((ch->offset + ch->length + 7) / 8);
+        t->evalid.alloc(vb + 1);
+        HIP_CHECK(hipMemcpyAsync(t->evalid.p, ch->buffers[0], vb, hipMemcpyHostToDevice, st));
+        t->d.evalid = t->evalid.p;
+      }
+    } else {
+      const size_t bytes = (size_t)(a->offset + a->length) * kind_width(kind);
+      t->dev.values.alloc(bytes + 8);
+      if (bytes) HIP_CHECK(hipMemcpyAsync(t->dev.values.p, a->buffers[1], bytes, hipMemcpyHostToDevice, st));
+      t->d.values = t->dev.values.p;
+    }
+    if (plans.size() >= 255) throw Error("Failed to write BAM records: more than 255 tag columns");
+    plans.push_back(std::move(t));
+  }
+  std::vector<SerTagCol> tag_cols;
+  for (auto& t : plans) tag_cols.push_back(t->d);
+  DevBuf<SerTagCol> d_tag_cols(std::max<size_t>(tag_cols.size(), 1));
+  if (!tag_cols.empty()) HIP_CHECK(hipMemcpyAsync(d_tag_cols.p, tag_cols.data(), tag_cols.size() * sizeof(SerTagCol), hipMemcpyHostToDevice, st));
+  SerTags tg{(int32_t)tag_cols.size(), d_tag_cols.p};
+  DevBuf<unsigned long long> tag_err(1);
+  HIP_CHECK(hipMemsetAsync(tag_err.p, 0xFF, 8, st));
   // sizes -> offsets -> bytes
   DevBuf<uint32_t> rec_bytes((size_t)n), err(1);
   DevBuf<uint64_t> rec_off((size_t)n + 1), tmp(scan_tmp_elems((uint64_t)n));
   HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
-  launch_ser_sizes(c, (uint64_t)n, rec_bytes.p, err.p, st);
+  launch_ser_sizes(c, tg, (uint64_t)n, rec_bytes.p, err.p, tag_err.p, st);
   launch_exclusive_scan_u32_to_u64(rec_bytes.p, rec_off.p, (uint64_t)n, tmp.p, st);
   uint64_t total = 0;
   uint32_t e = 0;
+  unsigned long long te = ~0ull;
   HIP_CHECK(hipMemcpyAsync(&total, rec_off.p + n, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(&te, tag_err.p, 8, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   throw_ser_err(e);
+  if (te != ~0ull) throw_tag_err(plans, te);
   w.reserve(total);
-  launch_ser_write(c, (uint64_t)n, rec_off.p, w.d_stream.p + w.stream_len, err.p, st);
+  launch_ser_write(c, tg, (uint64_t)n, rec_off.p, w.d_stream.p + w.stream_len, err.p, st);
   HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   throw_ser_err(e);

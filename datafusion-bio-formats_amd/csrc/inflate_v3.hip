@@ -425,9 +425,12 @@ __device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t c
 // (pos, acc, tb | mb << 12 | pending match length << 16) to checkpoint row c of the wave's scratch; ck_n = number of the
 // lane's valid rows (rows 1 .. ck_n).  Returns true (uniform) when a pass needs more than V3_CK_MAX rows: the caller
 // restarts the round with short sub-streams.
+#ifdef V3_UTIL
+__device__ unsigned long long v3_util[4];  // dev diagnostic: loop iterations / lane-steps of the first count pass, of the fix passes
+#endif
 __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, uint32_t limit,
                                          const uint32_t* __restrict__ gsrc, uint32_t* __restrict__ ck, int lane,
-                                         uint32_t& end_out, uint32_t& acc_out, uint32_t& flags, uint32_t& ck_n) {
+                                         uint32_t& end_out, uint32_t& acc_out, uint32_t& flags, uint32_t& ck_n, int kind = 0) {
   static_assert(offsetof(V3Lds, null_slot) - offsetof(V3Lds, lit_fast) == V3_NULL_BASE, "null slots must sit at V3_NULL_BASE");
   uint32_t pos = start;
   uint32_t acc = 0;
@@ -441,7 +444,13 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
   uint32_t cd = V3_CK_STEPS, c = 0;  // wave-uniform: steps to the next checkpoint, checkpoint row
   uint32_t cn = 0;
   bool overflow = false;
+#ifdef V3_UTIL
+  uint32_t u_it = 0, u_act = 0;
+#endif
   while (__ballot(tb < V3_NULL_BASE) != 0ull) {
+#ifdef V3_UTIL
+    u_it++; u_act += (uint32_t)__popcll(__ballot(tb < V3_NULL_BASE));
+#endif
     if (cd == 0) {
       cd = V3_CK_STEPS;
       c++;
@@ -499,6 +508,9 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
     asm volatile("; V3LOOP_END %0" ::"n"(0));
 #endif
   }
+#ifdef V3_UTIL
+  if (lane == 0) { atomicAdd(&v3_util[2 * kind], (unsigned long long)u_it); atomicAdd(&v3_util[2 * kind + 1], (unsigned long long)u_act); }
+#endif
   if (active) {
     end_out = tb == STOP_EOB ? pos - (uint32_t)L.eob_fix : pos;
     acc_out = acc; ck_n = cn;
@@ -1069,7 +1081,7 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
           if (changed) start = pe;
           // a lane whose corrected start already lies beyond its limit owns no symbols
           if (changed && start >= limit) { end = start; acc = 0; flags = 0; cn = 0; }
-          ovf = v3_count(L, changed && start < limit, start, limit, gsrc, ck, lane, end, acc, flags, cn);
+          ovf = v3_count(L, changed && start < limit, start, limit, gsrc, ck, lane, end, acc, flags, cn, 1);
           dbg_passes++;
         }
         if (ovf) {
@@ -1228,6 +1240,16 @@ void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const
                      scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg);
 #ifdef V3_GUARD
   v3_guard_report();
+#endif
+#ifdef V3_UTIL
+  {
+    unsigned long long u[4] = {0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(u, HIP_SYMBOL(v3_util), sizeof u);
+    if (n_blocks > 1000)
+      fprintf(stderr, "[v3 util] first count pass: %llu steps, %.1f lanes busy per step; fix passes: %llu steps, %.1f lanes busy per step (cumulative)\n",
+              u[0], u[0] ? (double)u[1] / u[0] : 0.0, u[2], u[2] ? (double)u[3] / u[2] : 0.0);
+  }
 #endif
 }
 

@@ -136,9 +136,27 @@ struct SerCols {   // one RecordBatch on the device, Arrow layouts as uploaded; 
   const int32_t* refid; const int32_t* mate_refid;  // per row (index 0 = row 0 of the batch), from chrom / mate_chrom; -1 = none
   int32_t zero_based;
 };
+// One tag column of the batch (build_tag_data, bio-format-core/src/sam_tag_io.rs:109-147): a non-NULL value becomes the aux
+// field tag[2] + type + value.  kind / ekind: Arrow storage of the column / of a list's elements.
+enum SerKind : uint8_t { SK_I8 = 1, SK_I16, SK_I32, SK_I64, SK_U8, SK_U16, SK_U32, SK_U64, SK_F32, SK_F64, SK_UTF8, SK_LIST };
+struct SerTagCol {
+  uint8_t tag[2];
+  uint8_t sam_type;        // 'i' 'c' 's' 'C' 'S' 'I' 'f' 'Z' 'H' 'A' 'B'
+  uint8_t subtype;         // 'B': element type on disk ('c' 'C' 's' 'S' 'i' 'I' 'f')
+  uint8_t kind, ekind;
+  int64_t offset, eoffset; // logical offsets of the column / of the list's child array
+  const uint8_t* valid;    // validity bitmap or null
+  const uint8_t* values;   // fixed width: elements; Utf8: bytes; List: the child's elements
+  const int32_t* off;      // Utf8 / List offsets
+  const uint8_t* evalid;   // the list child's validity bitmap or null
+};
+struct SerTags { int32_t n; const SerTagCol* cols; };
+// tag_err (atomicMin, start at ~0): row << 16 | column << 8 | code -- 20 integer does not fit its SAM type, 21 float does not fit 'f',
+// 22 invalid hex string, 23 character tag is not one ASCII byte, 24 character tag value does not fit a byte, 25 NULL element in an
+// array tag, 26 array element does not fit its subtype.  The host words the message from the batch it still holds.
 // err: 1 flag > 65535, 2 malformed CIGAR, 3 quality / sequence length mismatch, 4 read name too long, 5 more than 65535 CIGAR ops
-void launch_ser_sizes(SerCols c, uint64_t n, uint32_t* rec_bytes, uint32_t* err, hipStream_t st);
-void launch_ser_write(SerCols c, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st);
+void launch_ser_sizes(SerCols c, SerTags t, uint64_t n, uint32_t* rec_bytes, uint32_t* err, unsigned long long* tag_err, hipStream_t st);
+void launch_ser_write(SerCols c, SerTags t, uint64_t n, const uint64_t* rec_off, uint8_t* out, uint32_t* err, hipStream_t st);
 // crc[b] = CRC32 of payload[off[b] .. off[b + 1]) (k_bgzf_crc32 in store mode)
 void launch_crc32_store(const uint8_t* payload, const uint64_t* off, uint32_t n_members, uint32_t* crc, hipStream_t st);
 // one BGZF member per payload range: complete members (header, DEFLATE data, CRC32, ISIZE) in slots of `slot_stride` bytes

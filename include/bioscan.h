@@ -243,7 +243,10 @@ int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t 
  * schema): records are serialised, CRC32-summed and DEFLATE-compressed on the device into BGZF members of at most 65280
  * payload bytes (fixed-Huffman blocks, stored blocks where that is smaller).  finish = the last short member, the BGZF
  * EOF marker, close.  Errors of the reference are kept ("does not fit into 16-bit SAM flags", CIGAR parse errors).
- * Tag columns are not written yet. */
+ * Tag columns: every field that carries "bio.bam.tag.tag" metadata becomes an aux field of the record, in schema order, NULL
+ * values skipped (build_tag_data, bio-format-core/src/sam_tag_io.rs:109-147); the SAM type comes from "bio.bam.tag.type" ("Z"
+ * when absent; "B:<subtype>" for arrays), accepted Arrow storages and every conversion error are arrow_to_sam_tag_value's
+ * (:206-656): Int8..Int64 / UInt8..UInt64 for c s i C S I and A, Float32 / Float64 for f, Utf8 for Z H A, List of those for B. */
 typedef struct bioscan_bam_writer bioscan_bam_writer;
 int bioscan_bam_writer_open(const char* path, const char* header_text, const char* const* ref_names, const int64_t* ref_lengths,
                             int32_t n_ref, int32_t coordinate_system_zero_based, int32_t device_id, bioscan_bam_writer** out);

@@ -422,6 +422,155 @@ def rec_aux(u: bytes, r: Rec):
 
 
 # =======================================================================================
+# Tag columns -> aux fields: the write side (build_tag_data sam_tag_io.rs:109-147, arrow_to_sam_tag_value :206-235,
+# integer / float / string / hex / character / array conversions :237-656, parse_sam_tag_type tag_registry.rs:78-106) and
+# the layout noodles-bam's encoder gives each value (SAM spec 4.2.4: tag[2] type[1] value; Z / H NUL-terminated; B = subtype,
+# u32 count, elements).  Errors carry the reference's message.
+# =======================================================================================
+class TagWriteError(Exception):
+    pass
+
+
+_INT_RANGE = {"c": (-128, 127), "s": (-32768, 32767), "i": (-2 ** 31, 2 ** 31 - 1), "C": (0, 255), "S": (0, 65535), "I": (0, 2 ** 32 - 1)}
+_INT_FMT = {"c": "<b", "s": "<h", "i": "<i", "C": "<B", "S": "<H", "I": "<I"}
+_F32_MAX = 3.4028234663852886e38
+
+
+def _rust_f64(v: float) -> str:
+    if v != v:
+        return "NaN"
+    if v in (float("inf"), float("-inf")):
+        return "inf" if v > 0 else "-inf"
+    r = repr(float(v))
+    if "e" in r or "E" in r:
+        from decimal import Decimal
+        r = format(Decimal(r), "f")
+    if r.endswith(".0"):
+        r = r[:-2]
+    return r
+
+
+def parse_sam_tag_type(spec: str):  # tag_registry.rs:78-106
+    parts = spec.split(":")
+    if len(parts) == 1:
+        if len(parts[0]) != 1:
+            raise TagWriteError(f"Invalid SAM tag type metadata: Invalid SAM tag type '{spec}': type must be a single character")
+        return parts[0], None
+    if len(parts) == 2 and parts[0] == "B":
+        if len(parts[1]) != 1:
+            raise TagWriteError(f"Invalid SAM tag type metadata: Invalid SAM tag array type '{spec}': subtype must be a single character")
+        if parts[1] not in "cCsSiIf":
+            raise TagWriteError(f"Invalid SAM tag type metadata: Unsupported SAM array subtype '{parts[1]}'")
+        return "B", parts[1]
+    raise TagWriteError(f"Invalid SAM tag type metadata: Invalid SAM tag type '{spec}': expected 'TYPE' or 'B:SUBTYPE'")
+
+
+def _is_int_type(t: pa.DataType) -> bool:
+    return pa.types.is_integer(t)
+
+
+def _rust_type(t: pa.DataType) -> str:
+    """the DataType's Debug form, for the types the tests use"""
+    names = {pa.int8(): "Int8", pa.uint8(): "UInt8", pa.int16(): "Int16", pa.uint16(): "UInt16", pa.int32(): "Int32",
+             pa.uint32(): "UInt32", pa.int64(): "Int64", pa.uint64(): "UInt64", pa.float32(): "Float32", pa.float64(): "Float64",
+             pa.utf8(): "Utf8", pa.large_utf8(): "LargeUtf8", pa.binary(): "Binary", pa.bool_(): "Boolean"}
+    if t in names:
+        return names[t]
+    if pa.types.is_list(t):
+        return f"List({_rust_type(t.value_type)})"
+    return str(t)
+
+
+def tag_aux_bytes(tag: str, spec: str, arrow_type: pa.DataType, value) -> bytes:
+    """One non-NULL value of a tag column as its aux field (b"" when the reference writes nothing)."""
+    sam_type, sub = parse_sam_tag_type(spec)
+    head = tag.encode("latin-1")
+    if sam_type in _INT_RANGE:
+        if not _is_int_type(arrow_type):
+            raise TagWriteError(f"Tag value type mismatch for integer: {_rust_type(arrow_type)}")
+        lo, hi = _INT_RANGE[sam_type]
+        if not lo <= value <= hi:
+            raise TagWriteError(f"Integer value {value} does not fit SAM type '{sam_type}'")
+        return head + sam_type.encode() + struct.pack(_INT_FMT[sam_type], value)
+    if sam_type == "f":
+        if pa.types.is_float32(arrow_type):
+            return head + b"f" + struct.pack("<f", value)
+        if pa.types.is_float64(arrow_type):
+            if value != value or abs(value) == float("inf") or not -_F32_MAX <= value <= _F32_MAX:
+                raise TagWriteError(f"Float value {_rust_f64(value)} does not fit SAM type 'f'")
+            return head + b"f" + struct.pack("<f", value)
+        raise TagWriteError(f"Tag value type mismatch for float: {_rust_type(arrow_type)}")
+    if sam_type == "Z":
+        if not pa.types.is_string(arrow_type):
+            raise TagWriteError(f"Tag value type mismatch for string: {_rust_type(arrow_type)}")
+        return head + b"Z" + value.encode() + b"\0"
+    if sam_type == "H":
+        if not pa.types.is_string(arrow_type):
+            raise TagWriteError(f"Tag value type mismatch for hex string: {_rust_type(arrow_type)}")
+        norm = "".join(chr(ord(ch) - 32) if "a" <= ch <= "z" else ch for ch in value)
+        if len(norm.encode()) % 2 or any(ch not in "0123456789ABCDEF" for ch in norm):
+            raise TagWriteError(f"Invalid SAM hex tag value '{norm}'")
+        return head + b"H" + norm.encode() + b"\0"
+    if sam_type == "A":
+        if pa.types.is_string(arrow_type):
+            b = value.encode()
+            if len(b) != 1 or b[0] >= 128:
+                raise TagWriteError(f"Character tags must be a single ASCII byte, got '{value}'")
+            return head + b"A" + b
+        if _is_int_type(arrow_type):
+            if not 0 <= value <= 255:
+                raise TagWriteError(f"Character tag value {value} does not fit into a single byte")
+            return head + b"A" + bytes([value])
+        raise TagWriteError(f"Tag value type mismatch for character: {_rust_type(arrow_type)}")
+    if sam_type == "B":
+        if not pa.types.is_list(arrow_type):
+            raise TagWriteError(f"Tag value type mismatch for array: {_rust_type(arrow_type)}")
+        et = arrow_type.value_type
+        if sub is None:  # sam_array_subtype_from_arrow_type (tag_registry.rs:48-59)
+            sub = {pa.int8(): "c", pa.uint8(): "C", pa.int16(): "s", pa.uint16(): "S", pa.int32(): "i", pa.uint32(): "I",
+                   pa.float32(): "f"}.get(et)
+            if sub is None:
+                raise TagWriteError(f"Unable to determine SAM array subtype for Arrow type {_rust_type(et)}")
+        if any(v is None for v in value):
+            raise TagWriteError("SAM array tags cannot contain null elements")
+        out = head + b"B" + sub.encode() + struct.pack("<I", len(value))
+        if sub == "f":
+            if not pa.types.is_floating(et) or pa.types.is_float16(et):
+                raise TagWriteError(f"Unsupported array element type for SAM subtype 'f': {_rust_type(et)}")
+            for v in value:
+                if pa.types.is_float64(et) and (v != v or abs(v) == float("inf") or not -_F32_MAX <= v <= _F32_MAX):
+                    raise TagWriteError(f"Array element {_rust_f64(v)} does not fit SAM subtype 'f'")
+                out += struct.pack("<f", v)
+            return out
+        if not _is_int_type(et):
+            raise TagWriteError(f"Unsupported array element type for SAM subtype '{sub}': {_rust_type(et)}")
+        lo, hi = _INT_RANGE[sub]
+        for v in value:
+            if not lo <= v <= hi:
+                raise TagWriteError(f"Array element {v} does not fit SAM subtype '{sub}'")
+            out += struct.pack(_INT_FMT[sub], v)
+        return out
+    if pa.types.is_string(arrow_type):  # any other type character on a string column (sam_tag_io.rs:227-233)
+        return head + b"Z" + value.encode() + b"\0"
+    return b""
+
+
+def build_tag_data(batch: pa.RecordBatch, row: int) -> bytes:
+    """Aux bytes of one row: the columns that carry bio.bam.tag.tag metadata, in schema order; NULL values are skipped."""
+    out = b""
+    for i, f in enumerate(batch.schema):
+        md = f.metadata or {}
+        if b"bio.bam.tag.tag" not in md:
+            continue
+        v = batch.column(i)[row]
+        if not v.is_valid or len(f.name) != 2:
+            continue
+        spec = md.get(b"bio.bam.tag.type", b"Z").decode()
+        out += tag_aux_bytes(f.name, spec, f.type, v.as_py())
+    return out
+
+
+# =======================================================================================
 # Tag coercion (sam_tag_io.rs:658-1036)
 # =======================================================================================
 class TagError(Exception):

@@ -193,3 +193,20 @@ def test_infer_scalar_integer_types(oracle):
     assert oracle.infer_type_from_value("C", 1) == ("i", pa.int32())
     assert oracle.infer_type_from_value("s", -1) == ("i", pa.int32())
     assert oracle.infer_type_from_value("I", 2 ** 32 - 1) == ("I", pa.uint32())
+
+
+def test_tag_write_kats(oracle):
+    """bio-format-core/src/sam_tag_io.rs:1049-1089: a UInt32 column written under 'i' metadata is an Int32 aux value and u32::MAX
+    does not fit; build_tag_data takes the SAM type from the field's bio.bam.tag.type."""
+    import pyarrow as pa
+    assert oracle.tag_aux_bytes("NM", "i", pa.uint32(), 42) == b"NMi" + (42).to_bytes(4, "little")
+    with pytest.raises(oracle.TagWriteError, match="does not fit SAM type 'i'"):
+        oracle.tag_aux_bytes("NM", "i", pa.uint32(), 2 ** 32 - 1)
+    f = pa.field("NM", pa.int32(), True, metadata={"bio.bam.tag.tag": "NM", "bio.bam.tag.type": "i"})
+    b = pa.RecordBatch.from_arrays([pa.array([7], pa.int32())], schema=pa.schema([f]))
+    assert oracle.build_tag_data(b, 0) == b"NMi\x07\x00\x00\x00"
+    # tag_registry.rs:883-900 parse_sam_tag_type
+    assert oracle.parse_sam_tag_type("i") == ("i", None) and oracle.parse_sam_tag_type("B:C") == ("B", "C")
+    for bad in ("ii", "B:CC", "B:x", "i:i", "B:C:S"):
+        with pytest.raises(oracle.TagWriteError):
+            oracle.parse_sam_tag_type(bad)
