@@ -6,12 +6,14 @@
 //   serialize  one row per lane: record sizes (pass 1), exclusive scan, record bytes (pass 2) -- header fields, read name,
 //              CIGAR parsed from its string (or copied when binary), 4-bit packed bases, qualities minus 33;
 //   crc32      one member per lane (k_bgzf_crc32 in store mode);
-//   deflate    one BGZF member (<= 65280 payload bytes) per wavefront: 64 positions per step, a 4096-entry hash table of
-//              3-byte prefixes in LDS proposes one candidate per lane (+ the distance-1 candidate for runs), lanes measure
-//              their matches, a scalar walk picks the greedy parse of the 64 positions, the chosen tokens are coded with
-//              the FIXED Huffman code (RFC 1951 3.2.6), their bit offsets come from a wave prefix sum and the bits are
-//              OR-ed into an LDS staging window that is flushed as whole dwords.  A member whose fixed-Huffman form would
-//              be larger than the payload is written as a stored block, so a member never exceeds 64 KiB.
+//   deflate    one BGZF member (<= 65280 payload bytes) per wavefront, two passes: (1) parse -- 64 positions per step, a
+//              4096-entry hash table of 3-byte prefixes in LDS proposes one candidate per lane (+ the distance-1 candidate
+//              for runs), lanes measure their matches, a scalar walk picks the greedy parse of the 64 positions; the tokens
+//              go to a scratch list and the symbols are counted in LDS; the block's OWN length-limited Huffman codes are
+//              built (literal/length, distance, and the code-length code of the header); (2) the tokens are coded -- bit
+//              offsets from a wave prefix sum, bits OR-ed into an LDS staging window that is flushed as whole dwords.  The
+//              cheaper of the dynamic block (header included) and the FIXED code (RFC 1951 3.2.6) is written; a member whose
+//              coded form would be larger than the payload is written as a stored block, so a member never exceeds 64 KiB.
 // Every member is valid BGZF (gzip header with the BC subfield, CRC32, ISIZE): zlib, libdeflate and K1 read it back.
 #include "kernels.h"
 
@@ -332,7 +334,9 @@ void launch_ser_write(SerCols c, SerTags t, uint64_t n, const uint64_t* rec_off,
 // =================================================================================================================
 constexpr int DF_HASH_BITS = 12;
 constexpr uint32_t DF_NONE = 0xFFFFu;
-constexpr int DF_WORDS = 64;  // staging window: a carried partial dword + 64 tokens of <= 31 bits = at most 63 dwords
+constexpr int DF_WORDS = 160;  // staging window: a carried partial dword + 64 tokens of <= 48 bits (97 dwords); the block header (<= 75 dwords)
+constexpr int DF_NLIT = 286, DF_NDIST = 30, DF_NPRE = 19;
+constexpr uint32_t DF_TOK_MATCH = 0x80000000u;  // token: literal = byte (256 = END-OF-BLOCK); match = flag | (dist - 1) << 8 | (len - 3)
 
 __device__ __forceinline__ uint32_t df_excl_scan(uint32_t v, int lane, uint32_t* total) {
   uint32_t inc = v;
@@ -343,6 +347,11 @@ __device__ __forceinline__ uint32_t df_excl_scan(uint32_t v, int lane, uint32_t*
   }
   *total = __builtin_amdgcn_readlane(inc, 63);
   return inc - v;
+}
+__device__ __forceinline__ uint32_t df_wave_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+  return v;
 }
 
 // common prefix length of a[0..) and b[0..), at most `cap` (reads up to 7 bytes past cap: buffers are padded)
@@ -356,11 +365,149 @@ __device__ __forceinline__ uint32_t df_match_len(const uint8_t* a, const uint8_t
   return k < cap ? k : cap;
 }
 
+// length / distance -> symbol, number of extra bits, extra bits (RFC 1951 3.2.5)
+__device__ __forceinline__ void df_len_sym(uint32_t len, uint32_t* sym, uint32_t* eb, uint32_t* ex) {
+  const uint32_t lc = len - 3;
+  if (lc == 255) { *sym = 285; *eb = 0; *ex = 0; }
+  else if (lc < 8) { *sym = 257 + lc; *eb = 0; *ex = 0; }
+  else { const uint32_t b = (31u - (uint32_t)__builtin_clz(lc)) - 2u; *eb = b; *sym = 261 + 4 * b + ((lc >> b) & 3u); *ex = lc & ((1u << b) - 1u); }
+}
+__device__ __forceinline__ void df_dist_sym(uint32_t dist, uint32_t* sym, uint32_t* eb, uint32_t* ex) {
+  const uint32_t dc = dist - 1;
+  if (dc < 4) { *sym = dc; *eb = 0; *ex = 0; }
+  else { const uint32_t b = (31u - (uint32_t)__builtin_clz(dc)) - 1u; *eb = b; *sym = 2 * b + 2 + ((dc >> b) & 1u); *ex = dc & ((1u << b) - 1u); }
+}
+
+struct DfLds {
+  uint16_t table[1 << DF_HASH_BITS];
+  uint32_t W[DF_WORDS];
+  uint32_t hl[DF_NLIT + 2], hd[DF_NDIST + 2], hp[DF_NPRE + 1];  // symbol counts
+  uint32_t cl[DF_NLIT + 2], cd[DF_NDIST + 2], cp[DF_NPRE + 1];  // bit-reversed code << 8 | length
+  uint16_t sorted[DF_NLIT + 2];
+  uint32_t weight[2 * DF_NLIT];
+  uint16_t parent[2 * DF_NLIT];
+  uint8_t len[DF_NLIT + 2];
+  uint16_t hsym[DF_NLIT + DF_NDIST + 4];  // block header: code-length symbol | extra bits << 5 | number of extra bits << 12
+  uint32_t nh, ok;
+};
+__device__ __forceinline__ void df_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Length-limited canonical Huffman code of freq[0 .. n): code[s] = bit-reversed code << 8 | length (0 for unused symbols).
+// The symbols are ranked in parallel; the tree (two-queue merge over the sorted leaves), the depths, the length limit
+// (over-long codes are clamped, the Kraft sum is repaired by lengthening the longest shorter codes, what is left over is given
+// back to the most frequent symbols of each length) and the canonical numbering run on lane 0: a few microseconds per
+// member, beside ~1000 parse steps.  A one-symbol alphabet gets a second, unused symbol so that the code is complete
+// (zlib rejects incomplete literal/length and code-length codes).  Returns false if no complete code was found (the
+// caller falls back to the fixed code).
+__device__ bool df_build_code(DfLds& L, const uint32_t* freq, int n, int limit, uint32_t* code, int lane) {
+  uint32_t cnt = 0;
+  for (int s = lane; s < n; s += WAVE) cnt += freq[s] != 0 ? 1u : 0u;
+  const int used = (int)df_wave_sum(cnt);
+  for (int s = lane; s < n; s += WAVE) {
+    L.len[s] = 0;
+    code[s] = 0;
+    const uint32_t f = freq[s];
+    if (!f) continue;
+    uint32_t r = 0;
+    for (int t = 0; t < n; t++) { const uint32_t g = freq[t]; r += (g != 0 && (g < f || (g == f && t < s))) ? 1u : 0u; }
+    L.sorted[r] = (uint16_t)s;
+  }
+  df_sync();
+  if (lane == 0) {
+    bool ok = true;
+    if (used == 0) { L.len[0] = 1; L.len[1] = 1; }
+    else if (used == 1) { const int s0 = L.sorted[0]; L.len[s0] = 1; L.len[s0 == 0 ? 1 : 0] = 1; }
+    else {
+      const int Lf = used;
+      for (int k = 0; k < Lf; k++) L.weight[k] = freq[L.sorted[k]];
+      int i = 0, j = Lf;
+      for (int nx = Lf; nx < 2 * Lf - 1; nx++) {
+        int a, b;
+        if (i < Lf && (j >= nx || L.weight[i] <= L.weight[j])) a = i++; else a = j++;
+        if (i < Lf && (j >= nx || L.weight[i] <= L.weight[j])) b = i++; else b = j++;
+        L.weight[nx] = L.weight[a] + L.weight[b];
+        L.parent[a] = (uint16_t)nx; L.parent[b] = (uint16_t)nx;
+      }
+      bool over = false;
+      L.weight[2 * Lf - 2] = 0;  // from here on weight[] of an internal node is its depth
+      for (int k = 2 * Lf - 3; k >= 0; k--) {
+        const uint32_t d = L.weight[L.parent[k]] + 1;
+        if (k >= Lf) L.weight[k] = d;
+        else { if (d > (uint32_t)limit) over = true; L.len[L.sorted[k]] = (uint8_t)(d > (uint32_t)limit ? (uint32_t)limit : d); }
+      }
+      if (over) {
+        const uint32_t full = 1u << limit;
+        uint32_t K = 0;
+        for (int k = 0; k < Lf; k++) K += 1u << (limit - L.len[L.sorted[k]]);
+        while (K > full) {
+          int best = -1;
+          uint32_t bl = 0;
+          for (int k = 0; k < Lf; k++) { const uint32_t l = L.len[L.sorted[k]]; if (l < (uint32_t)limit && l > bl) { bl = l; best = k; } }
+          if (best < 0) { ok = false; break; }
+          L.len[L.sorted[best]]++;
+          K -= 1u << (limit - bl - 1);
+        }
+        uint32_t slack = ok ? full - K : 0u;
+        for (int l = limit; l >= 2 && slack; l--) {
+          const uint32_t gain = 1u << (limit - l);
+          for (int k = Lf - 1; k >= 0 && slack >= gain; k--)
+            if (L.len[L.sorted[k]] == l) { L.len[L.sorted[k]] = (uint8_t)(l - 1); slack -= gain; }
+        }
+        if (slack) ok = false;
+      }
+    }
+    if (ok) {
+      uint32_t next[17];
+      uint32_t blc[17];
+      for (int l = 0; l <= 16; l++) blc[l] = 0;
+      for (int s = 0; s < n; s++) blc[L.len[s]]++;
+      blc[0] = 0;
+      uint32_t c = 0;
+      for (int l = 1; l <= 16; l++) { c = (c + blc[l - 1]) << 1; next[l] = c; }
+      for (int s = 0; s < n; s++) {
+        const uint32_t l = L.len[s];
+        if (l) { const uint32_t cc = next[l]++; code[s] = ((__brev(cc) >> (32 - l)) << 8) | l; }
+      }
+    }
+    L.ok = ok ? 1u : 0u;
+  }
+  df_sync();
+  return L.ok != 0;
+}
+
+// the fixed code of RFC 1951 3.2.6 in the same tables
+__device__ void df_fixed_code(DfLds& L, int lane) {
+  for (int s = lane; s < DF_NLIT + 2; s += WAVE) {
+    uint32_t c, l;
+    if (s < 144) { c = 0x30u + s; l = 8; } else if (s < 256) { c = 0x190u + (s - 144); l = 9; } else if (s < 280) { c = s - 256; l = 7; } else { c = 0xC0u + (s - 280); l = 8; }
+    L.cl[s] = ((__brev(c) >> (32 - l)) << 8) | l;
+  }
+  if (lane < DF_NDIST + 2) L.cd[lane] = ((__brev((uint32_t)lane) >> 27) << 8) | 5u;
+  df_sync();
+}
+
+// serial bit writer of lane 0 into the (zeroed) staging window
+__device__ __forceinline__ void df_put(uint32_t* W, uint32_t* bitpos, uint32_t v, uint32_t nb) {
+  const uint32_t wi = *bitpos >> 5, lo = *bitpos & 31u;
+  W[wi] |= v << lo;
+  if (lo + nb > 32) W[wi + 1] |= v >> (32 - lo);
+  *bitpos += nb;
+}
+
+// One BGZF member per wavefront.  Pass 1 parses (64 positions per step; a 4096-entry hash table of 3-byte prefixes proposes one
+// candidate per lane, + the distance-1 candidate for runs; a scalar walk over the lanes' token lengths picks the greedy
+// parse), stores the tokens and counts the symbols.  Then the block's own Huffman codes are built (df_build_code), the cost
+// of the dynamic block (header included) is compared with the fixed code's, and pass 2 codes the tokens: bit offsets by a
+// wave prefix sum, bits OR-ed into an LDS window that is flushed as whole dwords.  A member whose coded form would be
+// larger than its payload is written as a stored block, so no member exceeds 64 KiB.
 __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict__ payload, const uint64_t* __restrict__ m_off, uint32_t n_members,
                                                         const uint32_t* __restrict__ crc, uint8_t* __restrict__ slots, uint32_t slot_stride,
-                                                        uint32_t* __restrict__ sizes) {
-  __shared__ uint16_t table[1 << DF_HASH_BITS];
-  __shared__ uint32_t W[DF_WORDS];
+                                                        uint32_t* __restrict__ sizes, uint32_t* __restrict__ tokens_all) {
+  __shared__ DfLds L;
   const uint32_t m = blockIdx.x;
   if (m >= n_members) return;
   const int lane = threadIdx.x;
@@ -368,14 +515,15 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
   const uint32_t n = (uint32_t)(m_off[m + 1] - m_off[m]);
   uint8_t* slot = slots + (uint64_t)m * slot_stride;
   uint8_t* data = slot + 18;  // DEFLATE stream (dwords are stored unaligned: gfx950 global stores need no alignment)
-  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) table[k] = (uint16_t)DF_NONE;
-  W[lane] = lane == 0 ? 3u : 0u;   // block header: BFINAL = 1, BTYPE = 01 (fixed Huffman) -> bits 1, 1, 0
-  uint32_t carry_bits = 3;         // bits of the partial dword W[0]
-  uint32_t word_base = 0;          // dwords flushed so far
-  uint64_t total_bits = 3;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  uint32_t pos = 0;
+  uint32_t* tokens = tokens_all + (uint64_t)m * 65536u;
+  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) L.table[k] = (uint16_t)DF_NONE;
+  for (int k = lane; k < DF_NLIT + 2; k += WAVE) L.hl[k] = 0;
+  if (lane < DF_NDIST + 2) L.hd[lane] = 0;
+  if (lane < DF_NPRE + 1) L.hp[lane] = 0;
+  for (int k = lane; k < DF_WORDS; k += WAVE) L.W[k] = 0;
+  df_sync();
+  // ---- pass 1: parse ----
+  uint32_t pos = 0, ntok = 0, eb_acc = 0;
   while (pos < n) {
     const uint32_t p = pos + (uint32_t)lane;
     const bool inb = p < n;
@@ -383,10 +531,9 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
     uint32_t v = 0;
     if (inb) v = ((const bw_u32*)(in + p))->v;  // (the payload buffer is padded)
     const uint32_t h = ((v & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - DF_HASH_BITS);
-    const uint32_t cand = can ? (uint32_t)table[h] : DF_NONE;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (can) table[h] = (uint16_t)p;   // lanes with equal hashes: any of them is a valid candidate for later positions
+    const uint32_t cand = can ? (uint32_t)L.table[h] : DF_NONE;
+    df_sync();
+    if (can) L.table[h] = (uint16_t)p;   // lanes with equal hashes: any of them is a valid candidate for later positions
     uint32_t best_len = 0, best_dist = 0;
     if (can) {
       const uint32_t cap = n - p < 258u ? n - p : 258u;
@@ -408,75 +555,167 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
       k += (uint32_t)__builtin_amdgcn_readlane((int)tok_len, (int)k);
     }
     const bool chosen = (sel >> lane) & 1ull;
-    // fixed Huffman code of the token, LSB-first (RFC 1951 3.2.5 / 3.2.6)
-    uint64_t bits = 0;
-    uint32_t nbits = 0;
     if (chosen) {
+      const uint32_t idx = ntok + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u));
       if (best_len >= 3) {
-        const uint32_t lc = best_len - 3;
-        uint32_t sym, leb, lex;
-        if (lc == 255) { sym = 285; leb = 0; lex = 0; }
-        else if (lc < 8) { sym = 257 + lc; leb = 0; lex = 0; }
-        else { leb = (31u - (uint32_t)__builtin_clz(lc)) - 2u; sym = 261 + 4 * leb + ((lc >> leb) & 3u); lex = lc & ((1u << leb) - 1u); }
-        uint32_t lcode, llen;
-        if (sym < 280) { lcode = sym - 256; llen = 7; } else { lcode = 0xC0 + (sym - 280); llen = 8; }
-        const uint32_t dc = best_dist - 1;
-        uint32_t dsym, deb, dex;
-        if (dc < 4) { dsym = dc; deb = 0; dex = 0; }
-        else { deb = (31u - (uint32_t)__builtin_clz(dc)) - 1u; dsym = 2 * deb + 2 + ((dc >> deb) & 1u); dex = dc & ((1u << deb) - 1u); }
-        bits = (uint64_t)(__brev(lcode) >> (32 - llen));
-        nbits = llen;
-        bits |= (uint64_t)lex << nbits; nbits += leb;
-        bits |= (uint64_t)(__brev(dsym) >> 27) << nbits; nbits += 5;
-        bits |= (uint64_t)dex << nbits; nbits += deb;
+        uint32_t ls, leb, lex, ds, deb, dex;
+        df_len_sym(best_len, &ls, &leb, &lex);
+        df_dist_sym(best_dist, &ds, &deb, &dex);
+        atomicAdd(&L.hl[ls], 1u);
+        atomicAdd(&L.hd[ds], 1u);
+        eb_acc += leb + deb;
+        tokens[idx] = DF_TOK_MATCH | ((best_dist - 1u) << 8) | (best_len - 3u);
       } else {
-        const uint32_t b = v & 0xFFu;
-        if (b < 144) { bits = __brev(0x30u + b) >> 24; nbits = 8; }
-        else { bits = __brev(0x190u + (b - 144)) >> 23; nbits = 9; }
+        atomicAdd(&L.hl[v & 0xFFu], 1u);
+        tokens[idx] = v & 0xFFu;
       }
     }
-    // bit offsets by a wave prefix sum; the bits are OR-ed into the staging window (<= 31 + 64 x 31 bits: 63 dwords)
+    ntok += (uint32_t)__popcll(sel);
+    pos += k;
+  }
+  if (lane == 0) { tokens[ntok] = 256u; L.hl[256] = 1; }
+  ntok++;
+  const uint32_t ebits = df_wave_sum(eb_acc);
+  df_sync();
+  // ---- the block's own codes; cost of the dynamic block against the fixed one ----
+  bool dynamic = df_build_code(L, L.hl, DF_NLIT, 15, L.cl, lane);
+  dynamic = df_build_code(L, L.hd, DF_NDIST, 15, L.cd, lane) && dynamic;
+  uint32_t hclen = 4, hlit = 0, hdist = 0, head_bits = 0;
+  if (dynamic) {
+    if (lane == 0) {
+      int nl = DF_NLIT, nd = DF_NDIST;
+      while (nl > 257 && (L.cl[nl - 1] & 0xFFu) == 0) nl--;
+      while (nd > 1 && (L.cd[nd - 1] & 0xFFu) == 0) nd--;
+      // code-length sequence with the zero runs folded (symbols 17 and 18)
+      uint32_t nh = 0;
+      const int tot = nl + nd;
+      auto clen = [&](int q) { return q < nl ? (L.cl[q] & 0xFFu) : (L.cd[q - nl] & 0xFFu); };
+      for (int q = 0; q < tot;) {
+        const uint32_t c = clen(q);
+        if (c == 0) {
+          int run = 1;
+          while (q + run < tot && run < 138 && clen(q + run) == 0) run++;
+          if (run >= 11) { L.hsym[nh++] = (uint16_t)(18u | ((uint32_t)(run - 11) << 5) | (7u << 12)); L.hp[18]++; q += run; continue; }
+          if (run >= 3) { L.hsym[nh++] = (uint16_t)(17u | ((uint32_t)(run - 3) << 5) | (3u << 12)); L.hp[17]++; q += run; continue; }
+        }
+        L.hsym[nh++] = (uint16_t)c;
+        L.hp[c]++;
+        q++;
+      }
+      L.nh = nh;
+      L.weight[2 * DF_NLIT - 1] = (uint32_t)nl | ((uint32_t)nd << 16);
+    }
+    df_sync();
+    dynamic = df_build_code(L, L.hp, DF_NPRE, 7, L.cp, lane);
+    const uint32_t nlnd = L.weight[2 * DF_NLIT - 1];
+    hlit = (nlnd & 0xFFFFu) - 257u;
+    hdist = (nlnd >> 16) - 1u;
+    if (dynamic) {
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      hclen = 19;
+      while (hclen > 4 && (L.cp[order[hclen - 1]] & 0xFFu) == 0) hclen--;
+      uint32_t hb = 0;
+      for (uint32_t q = (uint32_t)lane; q < L.nh; q += WAVE) { const uint32_t e = L.hsym[q]; hb += (L.cp[e & 31u] & 0xFFu) + (e >> 12); }
+      head_bits = 14u + 3u * hclen + df_wave_sum(hb);
+    }
+  }
+  uint32_t dyn_bits = 0, fix_bits = 0;
+  {
+    uint32_t db = 0, fb = 0;
+    for (int s = lane; s < DF_NLIT; s += WAVE) {
+      const uint32_t f = L.hl[s];
+      db += f * (L.cl[s] & 0xFFu);
+      fb += f * (s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u);
+    }
+    if (lane < DF_NDIST) { db += L.hd[lane] * (L.cd[lane] & 0xFFu); fb += L.hd[lane] * 5u; }
+    dyn_bits = 3u + head_bits + df_wave_sum(db) + ebits;
+    fix_bits = 3u + df_wave_sum(fb) + ebits;
+  }
+  if (!dynamic || fix_bits <= dyn_bits) { dynamic = false; df_fixed_code(L, lane); }
+  // ---- block header ----
+  uint32_t carry_bits = 0, word_base = 0;
+  uint64_t total_bits = 0;
+  if (lane == 0) {
+    uint32_t bp = 0;
+    if (!dynamic) df_put(L.W, &bp, 3u, 3);   // BFINAL = 1, BTYPE = 01
+    else {
+      const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      df_put(L.W, &bp, 5u, 3);               // BFINAL = 1, BTYPE = 10
+      df_put(L.W, &bp, hlit, 5); df_put(L.W, &bp, hdist, 5); df_put(L.W, &bp, hclen - 4u, 4);
+      for (uint32_t q = 0; q < hclen; q++) df_put(L.W, &bp, L.cp[order[q]] & 0xFFu, 3);
+      for (uint32_t q = 0; q < L.nh; q++) {
+        const uint32_t e = L.hsym[q], c = L.cp[e & 31u];
+        df_put(L.W, &bp, c >> 8, c & 0xFFu);
+        if (e >> 12) df_put(L.W, &bp, (e >> 5) & 0x7Fu, e >> 12);
+      }
+    }
+    L.nh = bp;
+  }
+  df_sync();
+  {
+    const uint32_t T = L.nh;
+    total_bits = T;
+    const uint32_t full = T >> 5;
+    for (uint32_t q = (uint32_t)lane; q < full; q += WAVE) bw_st32(data + 4ull * q, L.W[q]);
+    const uint32_t carry_word = L.W[full];
+    df_sync();
+    for (int q = lane; q < DF_WORDS; q += WAVE) L.W[q] = (q == 0) ? carry_word : 0u;
+    df_sync();
+    word_base = full;
+    carry_bits = T & 31u;
+  }
+  // ---- pass 2: code the tokens ----
+  for (uint32_t base = 0; base < ntok; base += WAVE) {
+    const uint32_t ti = base + (uint32_t)lane;
+    uint64_t bits = 0;
+    uint32_t nbits = 0;
+    if (ti < ntok) {
+      const uint32_t t = tokens[ti];
+      if (t & DF_TOK_MATCH) {
+        uint32_t ls, leb, lex, ds, deb, dex;
+        df_len_sym((t & 0xFFu) + 3u, &ls, &leb, &lex);
+        df_dist_sym(((t >> 8) & 0x7FFFu) + 1u, &ds, &deb, &dex);
+        const uint32_t c1 = L.cl[ls], c2 = L.cd[ds];
+        bits = (uint64_t)(c1 >> 8); nbits = c1 & 0xFFu;
+        bits |= (uint64_t)lex << nbits; nbits += leb;
+        bits |= (uint64_t)(c2 >> 8) << nbits; nbits += c2 & 0xFFu;
+        bits |= (uint64_t)dex << nbits; nbits += deb;
+      } else {
+        const uint32_t c1 = L.cl[t & 0x1FFu];
+        bits = (uint64_t)(c1 >> 8); nbits = c1 & 0xFFu;
+      }
+    }
     uint32_t tot;
     const uint32_t off = carry_bits + df_excl_scan(nbits, lane, &tot);
     if (nbits) {
       const uint32_t wi = off >> 5, lo = off & 31u;
-      atomicOr(&W[wi], (uint32_t)(bits << lo));
-      if (lo + nbits > 32) atomicOr(&W[wi + 1], (uint32_t)(bits >> (32 - lo)));
+      const uint64_t sh = bits << lo;               // <= 31 + 48 bits: three dwords at most
+      atomicOr(&L.W[wi], (uint32_t)sh);
+      if (lo + nbits > 32) atomicOr(&L.W[wi + 1], (uint32_t)(sh >> 32));
+      if (lo + nbits > 64) atomicOr(&L.W[wi + 2], (uint32_t)(bits >> (64 - lo)));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    df_sync();
     const uint32_t T = carry_bits + tot;
     const uint32_t full = T >> 5;   // whole dwords: flushed; the partial one is carried into the next step
-    const uint32_t wv = W[lane];
-    if ((uint32_t)lane < full) bw_st32(data + 4ull * (word_base + (uint32_t)lane), wv);
-    const uint32_t carry_word = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)full);
-    __builtin_amdgcn_wave_barrier();
-    W[lane] = lane == 0 ? carry_word : 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    for (uint32_t q = (uint32_t)lane; q < full; q += WAVE) bw_st32(data + 4ull * (word_base + q), L.W[q]);
+    const uint32_t carry_word = L.W[full];
+    df_sync();
+    for (uint32_t q = (uint32_t)lane; q <= full + 1 && q < (uint32_t)DF_WORDS; q += WAVE) L.W[q] = (q == 0) ? carry_word : 0u;
+    df_sync();
     word_base += full;
     carry_bits = T & 31u;
     total_bits += tot;
-    pos += k;
   }
-  // END-OF-BLOCK: seven zero bits (already zero in the window); flush the tail, partial dword included
-  {
-    const uint32_t T = carry_bits + 7;
-    total_bits += 7;
-    const uint32_t full = (T + 31) >> 5;
-    if ((uint32_t)lane < full) bw_st32(data + 4ull * (word_base + (uint32_t)lane), W[lane]);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
+  if (lane == 0 && carry_bits) bw_st32(data + 4ull * word_base, L.W[0]);  // the last partial dword
+  df_sync();
   uint32_t data_bytes = (uint32_t)((total_bits + 7) >> 3);
   if (data_bytes > n + 5u) {
-    // the fixed-Huffman form is larger than the payload: a stored block instead (BFINAL = 1, BTYPE = 00, LEN, NLEN, bytes),
+    // the coded form is larger than the payload: a stored block instead (BFINAL = 1, BTYPE = 00, LEN, NLEN, bytes),
     // so that no member exceeds 64 KiB (65280 + 5 + 26 bytes)
     if (lane == 0) { data[0] = 1; data[1] = (uint8_t)n; data[2] = (uint8_t)(n >> 8); data[3] = (uint8_t)~n; data[4] = (uint8_t)(~n >> 8); }
     for (uint32_t q = lane; q < n; q += WAVE) data[5 + q] = in[q];
     data_bytes = n + 5u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    df_sync();
   }
   // gzip member header with the BGZF extra subfield, and the trailer (SAM spec 4.1)
   const uint32_t bsize = 18u + data_bytes + 8u;
@@ -504,9 +743,9 @@ __global__ __launch_bounds__(256) void k_compact_members(const uint8_t* __restri
 }
 
 void launch_bgzf_deflate(const uint8_t* payload, const uint64_t* m_off, uint32_t n_members, const uint32_t* crc, uint8_t* slots,
-                         uint32_t slot_stride, uint32_t* sizes, hipStream_t st) {
+                         uint32_t slot_stride, uint32_t* sizes, uint32_t* tokens, hipStream_t st) {
   if (!n_members) return;
-  hipLaunchKernelGGL(k_bgzf_deflate, dim3(n_members), dim3(WAVE), 0, st, payload, m_off, n_members, crc, slots, slot_stride, sizes);
+  hipLaunchKernelGGL(k_bgzf_deflate, dim3(n_members), dim3(WAVE), 0, st, payload, m_off, n_members, crc, slots, slot_stride, sizes, tokens);
 }
 void launch_compact_members(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes, const uint64_t* off, uint32_t n_members,
                             uint8_t* out, hipStream_t st) {

@@ -40,15 +40,22 @@ struct Compressor {
     if (st) { (void)hipSetDevice(device); (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   }
   // compresses d_payload[0 .. len) (device, padded by >= 16 readable bytes) into members of <= BGZF_MAX_PAYLOAD bytes and
-  // appends them to `out`
+  // appends them to `out`; at most MAX_BATCH members per launch (the parse of a member lives in 256 KB of token scratch)
+  static constexpr uint32_t MAX_BATCH = 2048;
   void compress(const uint8_t* d_payload, uint64_t len, std::vector<uint8_t>* out, uint64_t* n_members) {
-    if (!len) return;
     HIP_CHECK(hipSetDevice(device));
-    const uint32_t nm = (uint32_t)((len + BGZF_MAX_PAYLOAD - 1) / BGZF_MAX_PAYLOAD);
+    const uint64_t nm_all = (len + BGZF_MAX_PAYLOAD - 1) / BGZF_MAX_PAYLOAD;
+    for (uint64_t m0 = 0; m0 < nm_all; m0 += MAX_BATCH) {
+      const uint32_t nm = (uint32_t)std::min<uint64_t>(MAX_BATCH, nm_all - m0);
+      compress_batch(d_payload + m0 * BGZF_MAX_PAYLOAD, std::min<uint64_t>(len - m0 * BGZF_MAX_PAYLOAD, (uint64_t)nm * BGZF_MAX_PAYLOAD), nm, out);
+    }
+    if (n_members) *n_members += nm_all;
+  }
+  void compress_batch(const uint8_t* d_payload, uint64_t len, uint32_t nm, std::vector<uint8_t>* out) {
     std::vector<uint64_t> off(nm + 1);
     for (uint32_t m = 0; m <= nm; m++) off[m] = std::min<uint64_t>((uint64_t)m * BGZF_MAX_PAYLOAD, len);
     DevBuf<uint64_t> d_off(nm + 1), d_out_off(nm + 1);
-    DevBuf<uint32_t> d_crc(nm), d_sizes(nm);
+    DevBuf<uint32_t> d_crc(nm), d_sizes(nm), tokens((uint64_t)nm * BGZF_TOKENS_PER_MEMBER);
     DevBuf<uint8_t> slots((uint64_t)nm * BGZF_SLOT_BYTES);
     HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), (nm + 1) * 8, hipMemcpyHostToDevice, st));
     hipEvent_t a, b;
@@ -56,7 +63,7 @@ struct Compressor {
     HIP_CHECK(hipEventCreate(&b));
     HIP_CHECK(hipEventRecord(a, st));
     launch_crc32_store(d_payload, d_off.p, nm, d_crc.p, st);
-    launch_bgzf_deflate(d_payload, d_off.p, nm, d_crc.p, slots.p, BGZF_SLOT_BYTES, d_sizes.p, st);
+    launch_bgzf_deflate(d_payload, d_off.p, nm, d_crc.p, slots.p, BGZF_SLOT_BYTES, d_sizes.p, tokens.p, st);
     HIP_CHECK(hipEventRecord(b, st));
     std::vector<uint32_t> sizes(nm);
     HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes.p, nm * 4, hipMemcpyDeviceToHost, st));
@@ -78,7 +85,6 @@ struct Compressor {
     out->resize(base + out_off[nm]);
     HIP_CHECK(hipMemcpyAsync(out->data() + base, packed.p, out_off[nm], hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    if (n_members) *n_members += nm;
   }
 };
 

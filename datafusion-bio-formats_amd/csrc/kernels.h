@@ -162,9 +162,11 @@ void launch_crc32_store(const uint8_t* payload, const uint64_t* off, uint32_t n_
 // one BGZF member per payload range: complete members (header, DEFLATE data, CRC32, ISIZE) in slots of `slot_stride` bytes
 // (>= BGZF_SLOT_BYTES), their sizes in sizes[]; launch_compact_members lays them back to back at out + off[m]
 constexpr uint32_t BGZF_MAX_PAYLOAD = 65280;   // what noodles-bgzf / htslib put into one member
-constexpr uint32_t BGZF_SLOT_BYTES = 81920;    // fixed-Huffman worst case (9 bits per byte) + header, trailer, slack
+constexpr uint32_t BGZF_SLOT_BYTES = 81920;    // coded worst case (a member that would exceed its payload + 5 is stored; 9 bits per byte while coding) + header, trailer, slack
+// tokens: scratch of BGZF_TOKENS_PER_MEMBER dwords per member (the parse of pass 1, read back by pass 2)
+constexpr uint32_t BGZF_TOKENS_PER_MEMBER = 65536;
 void launch_bgzf_deflate(const uint8_t* payload, const uint64_t* m_off, uint32_t n_members, const uint32_t* crc, uint8_t* slots,
-                         uint32_t slot_stride, uint32_t* sizes, hipStream_t st);
+                         uint32_t slot_stride, uint32_t* sizes, uint32_t* tokens, hipStream_t st);
 void launch_compact_members(const uint8_t* slots, uint32_t slot_stride, const uint32_t* sizes, const uint64_t* off, uint32_t n_members,
                             uint8_t* out, hipStream_t st);
 

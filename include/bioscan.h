@@ -241,7 +241,7 @@ int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t 
  * write = write_records of one RecordBatch (a struct array holding at least name, chrom, start, flags, cigar [Utf8 or
  * Binary], mapping_quality, mate_chrom, mate_start, sequence, quality_scores, template_length -- the reader's own
  * schema): records are serialised, CRC32-summed and DEFLATE-compressed on the device into BGZF members of at most 65280
- * payload bytes (fixed-Huffman blocks, stored blocks where that is smaller).  finish = the last short member, the BGZF
+ * payload bytes (dynamic-Huffman blocks; fixed-code or stored blocks where those are smaller).  finish = the last short member, the BGZF
  * EOF marker, close.  Errors of the reference are kept ("does not fit into 16-bit SAM flags", CIGAR parse errors).
  * Tag columns: every field that carries "bio.bam.tag.tag" metadata becomes an aux field of the record, in schema order, NULL
  * values skipped (build_tag_data, bio-format-core/src/sam_tag_io.rs:109-147); the SAM type comes from "bio.bam.tag.type" ("Z"
