@@ -166,7 +166,6 @@ __global__ __launch_bounds__(ROWS_TILE) void k_bam_rows_pass1(const uint8_t* __r
 // Exclusive scan of every column's tile sums, two levels: k_bam_tile_scan_blocks scans groups of 1024 tiles in place and
 // leaves each group's total in `aux`; k_bam_tile_scan_top scans the group totals (one workgroup per column) and writes the
 // column's grand total to entry n_tiles.  The first byte of tile t is tile_sums[k][t] + aux[k][t / 1024] (tile_base()).
-constexpr int TS_GROUP = 1024;
 __global__ __launch_bounds__(TS_GROUP) void k_bam_tile_scan_blocks(uint64_t* __restrict__ tile_sums, uint64_t n_tiles, uint64_t n_groups,
                                                                    uint64_t* __restrict__ aux, uint32_t want) {
   const int k = blockIdx.y;
@@ -498,12 +497,13 @@ void launch_bam_rows_pass1(const uint8_t* u, const uint64_t* rows, uint64_t n, R
   const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
   hipLaunchKernelGGL(k_bam_rows_pass1, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, rows, n, c, ref_name_len, n_ref, zero_based,
                      binary_cigar, n_tiles, tile_sums, err);
-  if (c.want) {
-    const uint64_t n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;
-    uint64_t* aux = tile_sums + 6 * (n_tiles + 1);  // 6 x (n_groups + 1) group totals behind the tile sums (bam_rows_scratch_elems)
-    hipLaunchKernelGGL(k_bam_tile_scan_blocks, dim3((uint32_t)n_groups, 6), dim3(TS_GROUP), 0, st, tile_sums, n_tiles, n_groups, aux, c.want);
-    hipLaunchKernelGGL(k_bam_tile_scan_top, dim3(6), dim3(1024), 0, st, tile_sums, n_tiles, n_groups, aux, c.want);
-  }
+  if (c.want) launch_tile_scan(tile_sums, n_tiles, c.want, st);
+}
+void launch_tile_scan(uint64_t* tile_sums, uint64_t n_tiles, uint32_t want, hipStream_t st) {
+  const uint64_t n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;
+  uint64_t* aux = tile_sums + 6 * (n_tiles + 1);  // 6 x (n_groups + 1) group totals behind the tile sums (bam_rows_scratch_elems)
+  hipLaunchKernelGGL(k_bam_tile_scan_blocks, dim3((uint32_t)n_groups, 6), dim3(TS_GROUP), 0, st, tile_sums, n_tiles, n_groups, aux, want);
+  hipLaunchKernelGGL(k_bam_tile_scan_top, dim3(6), dim3(1024), 0, st, tile_sums, n_tiles, n_groups, aux, want);
 }
 size_t bam_rows_scratch_elems(uint64_t n) {
   const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE, n_groups = (n_tiles + TS_GROUP - 1) / TS_GROUP;

@@ -1180,41 +1180,35 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       int src = plan.has_projection ? plan.projection[c] : (int)c;
       if (col_of[src] < 0) col_of[src] = (int)c;
     }
-    DevBuf<uint64_t> srcs[4];
-    FastqCols fc{};
-    uint64_t** sp[4] = {&fc.src_name, &fc.src_desc, &fc.src_seq, &fc.src_qual};
-    uint32_t** lp[4] = {&fc.len_name, &fc.len_desc, &fc.len_seq, &fc.len_qual};
+    // two passes, no per-row length / source arrays (fastq_kernels.hip): pass 1 -> tile sums -> column totals -> pass 2
+    FqCols fc{};
     for (int k = 0; k < 4; k++) {
       if (col_of[k] < 0) continue;
       Column& col = res->cols[col_of[k]];
       col.n_rows = n;
-      srcs[k].alloc(n);
-      col.d_len.alloc(n);
-      *sp[k] = srcs[k].p;
-      *lp[k] = col.d_len.p;
+      fc.want |= 1u << k;
       if (k == 1) { col.d_valid.alloc(nwords); fc.v_desc = col.d_valid.p; arrow_bytes += nwords * 8; }
     }
-    launch_fastq_fields(u, x0, hi - base, nl.p, n_nl, n, fc, err.p, st);
-    uint32_t e = read_err(err, st);
+    const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
+    DevBuf<uint64_t> tile_sums(bam_rows_scratch_elems(n));
+    launch_fastq_pass1(u, x0, hi - base, nl.p, n_nl, n, fc, tile_sums.p, err.p, st);
+    uint64_t totals[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++)
+      if ((fc.want >> k) & 1u) HIP_CHECK(hipMemcpyAsync(&totals[k], tile_sums.p + (uint64_t)k * (n_tiles + 1) + n_tiles, 8, hipMemcpyDeviceToHost, st));
+    uint32_t e = read_err(err, st);  // synchronises: the totals are here as well
     if (e == 1) throw Error("FASTQ read error: invalid name prefix");
     if (e == 2) throw Error("FASTQ read error: invalid description prefix");
-    DevBuf<uint64_t> stmp(scan_tmp_elems(n));
     for (int k = 0; k < 4; k++) {
       if (col_of[k] < 0) continue;
       Column& col = res->cols[col_of[k]];
-      col.d_off64.alloc(n + 1);
-      launch_exclusive_scan_u32_to_u64(col.d_len.p, col.d_off64.p, n, stmp.p, st);
-      uint64_t tot = 0;
-      HIP_CHECK(hipMemcpyAsync(&tot, col.d_off64.p + n, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      col.total_bytes = tot;
-      col.d_values.alloc(std::max<uint64_t>(tot, 1));
+      col.total_bytes = totals[k];
+      col.d_values.alloc(std::max<uint64_t>(totals[k], 1));
       col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
-      launch_batch_offsets(col.d_off64.p, n, batch_size, 0, col.d_off32.p, st);
-      launch_scatter_ranges(u, srcs[k].p, n, col.d_off64.p, col.d_values.p, tot, st);
-      arrow_bytes += tot + nb * ((uint64_t)batch_size + 1) * 4;
-      col.d_len.reset();
+      col.d_base.alloc(nb);
+      fc.val[k] = col.d_values.p; fc.off32[k] = col.d_off32.p; fc.base[k] = col.d_base.p;
+      arrow_bytes += totals[k] + nb * ((uint64_t)batch_size + 1) * 4;
     }
+    launch_fastq_pass2(u, x0, hi - base, nl.p, n_nl, n, fc, batch_size, tile_sums.p, st);
     HIP_CHECK(hipStreamSynchronize(st));
   }
   res->stats.ms_extract = t.stop();

@@ -191,22 +191,32 @@ void launch_tag_list_scatter(const uint8_t* u, const uint64_t* rows, uint64_t n,
                              int32_t elem, const uint64_t* off64, uint8_t* dst, uint32_t* err, hipStream_t st);
 
 // ---- FASTQ (fastq_kernels.hip) -------------------------------------------------------------------
-struct FastqCols {   // nullptr = not projected
-  uint64_t* src_name; uint32_t* len_name;
-  uint64_t* src_desc; uint32_t* len_desc; uint64_t* v_desc;
-  uint64_t* src_seq; uint32_t* len_seq;
-  uint64_t* src_qual; uint32_t* len_qual;
-};
 void launch_fastq_sync(const uint8_t* u, uint64_t start, uint64_t ulen, const uint64_t* win_end, const uint64_t* win_coff,
                        const uint64_t* win_next, uint32_t n_win, uint64_t end_comp, int check_end, unsigned long long* result,
                        hipStream_t st);
 uint64_t nl_chunks(uint64_t lo, uint64_t hi);
 void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st);
 void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base, uint64_t* nl, hipStream_t st);
-void launch_fastq_fields(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec,
-                         FastqCols c, uint32_t* err, hipStream_t st);
 void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
                               unsigned long long* result, hipStream_t st);
+// FASTQ records -> the four Utf8 columns in two passes (the scheme of bam_rows.hip: no per-row length / source arrays):
+//   pass 1  one record per lane: field lengths from the newline index, description validity, '@' / '+' checks, the SUM of every
+//           projected column's lengths per 256-row tile; launch_tile_scan turns the sums into tile bases + column totals
+//   pass 2  one workgroup per tile: the geometry is recomputed, scanned inside the tile, the per-batch int32 offsets are written
+//           from that scan and the bytes are copied by 16-lane groups (16-byte chunks, two rows in flight per group)
+// k: 0 name, 1 description, 2 sequence, 3 quality.
+struct FqCols {
+  uint8_t* val[4]; int32_t* off32[4]; uint64_t* base[4];
+  uint64_t* v_desc;
+  uint32_t want;
+};
+constexpr int TS_GROUP = 1024;   // tile sums are scanned in groups of 1024 tiles (bam_rows.hip)
+// tile_sums: 6 x (n_tiles + 1) entries followed by 6 x (n_groups + 1) group totals (bam_rows_scratch_elems sizes it)
+void launch_tile_scan(uint64_t* tile_sums, uint64_t n_tiles, uint32_t want, hipStream_t st);
+void launch_fastq_pass1(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec, FqCols c,
+                        uint64_t* tile_sums, uint32_t* err, hipStream_t st);
+void launch_fastq_pass2(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec, FqCols c,
+                        uint32_t batch_size, const uint64_t* tile_sums, hipStream_t st);
 // total_bytes = off64[n] (the caller has just read it): the average row length picks the kernel shape
 void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
                            hipStream_t st);
