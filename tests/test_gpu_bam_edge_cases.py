@@ -117,3 +117,28 @@ def test_truncated_bgzf_header_is_an_error(pkg, tmp_path):
     open(path, "wb").write(data)
     with pytest.raises(pkg.BioscanError, match="truncated block header|invalid block"):
         pkg.BamTableProvider(path, None, True, None, index_path="")
+
+
+def test_reference_names_of_every_length(pkg, oracle, tmp_path):
+    """chrom / mate_chrom are written from an 8-byte load of the name table (up to three stores) or, beyond 8 bytes, a byte
+    loop: names of 1 .. 9, 15, 16, 17 and 40 bytes, the last one at the very end of the table."""
+    lens = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 40]
+    refs = [("".join(chr(ord("a") + (i + j) % 26) for j in range(l)), 1000 + i) for i, l in enumerate(lens)]
+    rng = random.Random(3)
+    recs = []
+    for k in range(600):
+        r = k % len(refs)
+        m = rng.randrange(-1, len(refs))
+        ncig = k % 7                                                  # 0 .. 6 operations: both sides of the four-operation load
+        cigar = tuple((rng.randrange(1, 400), "MIDNSHP=X"[(k + j) % 9]) for j in range(ncig))
+        recs.append(bb.record(name="r%d" % k, refid=r, pos=rng.randrange(0, 900), cigar=cigar, seq="ACGT" * (k % 9), next_refid=m,
+                              next_pos=-1 if m < 0 else rng.randrange(0, 900)))
+    path = str(tmp_path / "refs.bam")
+    open(path, "wb").write(bb.bam(refs, recs))
+    for binary in (False, True):
+        prov = pkg.BamTableProvider(path, None, True, None, binary, index_path="")
+        orc = oracle.BamOracle(path, zero_based=True, index_path=None, binary_cigar=binary)
+        for bs in (8192, 100):
+            got = list(prov.scan().execute(0, bs))
+            _, want = orc.execute_sequential(None, bs)
+            _cmp_batches(got, want, ("ref names", binary, bs))
