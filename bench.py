@@ -292,6 +292,10 @@ def main():
     ap.add_argument("--format", default="bam", choices=["bam", "fastq", "vcf-sites", "vcf-samples"],
                     help="bam (default, BASELINE.json config 2) or fastq (BGZF-FASTQ + GZI full scan: the only scan the "
                          "reference publishes numbers for, openspec/.../design.md:29-36)")
+    ap.add_argument("--partition-threads", type=int, default=1,
+                    help="indexed mode: partitions of a rank executed concurrently from this many threads, the way DataFusion drives "
+                         "execute(partition); 1 (default) = one after another, which keeps stage_ms and the roofline's launch time "
+                         "free of overlap -- with more threads they are sums of overlapping stream times")
     ap.add_argument("--mode", default="sequential", choices=["sequential", "indexed"],
                     help="sequential: each rank scans its own file as one partition (weak scaling, default). "
                          "indexed: every rank opens the SAME file, the BAI plan (target_partitions = 8 x ranks) is "
@@ -398,10 +402,21 @@ def main():
         assert plan.num_partitions() == 1
         my_parts = [0]
 
+    # indexed mode: the rank's partitions are executed the way DataFusion drives an ExecutionPlan -- execute(partition) from
+    # several worker threads at once (the reference: one OS thread per partition, bio-format-core/src/sync_stream.rs:19-29);
+    # every execute owns its stream and scratch, so the partitions' kernels interleave on the device
+    pool = None
+    if args.partition_threads > 1 and len(my_parts) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=min(args.partition_threads, len(my_parts)))
+
     def run_step():
         tot = None
-        for p in my_parts:
-            st = plan.execute_device(p, args.batch_size)
+        if pool is not None:
+            results = list(pool.map(lambda p: plan.execute_device(p, args.batch_size), my_parts))
+        else:
+            results = [plan.execute_device(p, args.batch_size) for p in my_parts]
+        for st in results:
             if tot is None:
                 tot = dict(st)
             else:
@@ -541,7 +556,10 @@ def main():
                        "n_blocks_per_gpu": meta["n_blocks"], "compressed_bytes_per_gpu": meta["compressed_bytes"],
                        "inflated_bytes_per_gpu": meta["inflated_bytes"], "records_per_gpu": meta["n_records"],
                        "projection": args.projection, "batch_size": args.batch_size, "mode": args.mode, "deflate_level": meta["level"],
-                       "deflater": meta["deflate"], "parallelism": f"{world} independent block-range shard(s), no collective"},
+                       "deflater": meta["deflate"], "parallelism": f"{world} independent block-range shard(s), no collective",
+                       **({"partition_threads": args.partition_threads,
+                           "stage_ms_note": "partitions run concurrently: stage_ms and roofline.avg_launch_ms are sums of overlapping stream times"}
+                          if pool is not None else {})},
             "decoded_GB_s": round(tot_u / per_step / 1e9, 3),
             "pipeline_algorithmic_GB_s": round((tot_c + 2 * tot_u + tot_a) / per_step / 1e9, 3),
             "pipeline_hbm_frac": round((tot_c + 2 * tot_u + tot_a) / per_step / 1e9 / (HBM_PEAK_GBS * world), 5),
