@@ -52,7 +52,7 @@ static void throw_vcf_err(uint32_t e) {
     case VERR_MISSING_START: throw Error("Missing variant start");
     case VERR_BAD_END: throw Error("VCF read error: invalid INFO END value");
     case VERR_BAD_QUAL: throw Error("VCF qual error: invalid float literal");
-    case VERR_FLOAT_PRECISION: throw Error("VCF read error: float literal with more than 19 significant digits lies on a rounding boundary of f32 (needs arbitrary-precision parsing: not supported on device)");
+    case VERR_FLOAT_PRECISION: throw Error("VCF read error: more than 65536 float literals of one chunk lie within 2^-52 of a rounding boundary of f32");
     case VERR_DUP_INFO_KEY: throw Error("VCF read error: duplicate INFO key in one record");
     case VERR_BAD_INT: throw Error("Error reading INFO / FORMAT field: invalid integer");
     case VERR_BAD_FLOAT: throw Error("Error reading INFO / FORMAT field: invalid float literal");
@@ -625,8 +625,8 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
 
   lap("planning done");
   Timer t(st);
-  DevBuf<uint32_t> err(1);
-  HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
+  DevBuf<uint32_t> err(VCF_ERR_DWORDS);  // error word + the queue of float cells to be rounded exactly (vcf_kernels.h)
+  HIP_CHECK(hipMemsetAsync(err.p, 0, 16, st));
   lap("timer+err ready");
   DevBuf<uint64_t> nl, nl_tabs, tab, base_nl, base_tab, scan_tmp;
   DevBuf<uint32_t> cnt_nl, cnt_tab;
@@ -1030,10 +1030,14 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
       }
       HIP_CHECK(hipStreamSynchronize(st));
     }
-    uint32_t e = 0;
-    HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
+    uint32_t e2[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(e2, err.p, 8, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    throw_vcf_err(e);
+    throw_vcf_err(e2[0]);
+    if (e2[1]) {  // float literals within 2^-52 of a rounding boundary: decided by exact integer comparison
+      launch_f32_fix(err.p, e2[1], st);
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
   } else {
     // zero rows: struct / list kids still need their (empty) shape for export
     std::function<void(VNode&)> shape = [&](VNode& nd) {

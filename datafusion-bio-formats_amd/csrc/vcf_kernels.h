@@ -103,6 +103,12 @@ struct VcfCellDirect {
   uint64_t* valid[VCF_MAX_DIRECT];
   uint64_t* src[VCF_MAX_DIRECT];
 };
+// The error word of a scan is followed by a queue of float cells whose rounding the parsing kernels could not prove:
+// err[0] error code, err[1] number of queued cells, entries from err + 4.  launch_f32_fix rewrites them exactly.
+struct F32Fix { const uint8_t* p; void* dst; uint32_t len, as_f64, approx, pad; };
+constexpr uint32_t F32_FIX_CAP = 65536;   // 2 MB of queue per scan; more such cells in one chunk are an error
+constexpr size_t VCF_ERR_DWORDS = 4 + F32_FIX_CAP * (sizeof(F32Fix) / 4);
+void launch_f32_fix(uint32_t* err, uint32_t n_queued, hipStream_t st);
 void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
                              const int16_t* fpos, int S, int gt_field, VcfCellDirect D, uint64_t* sp_off, uint32_t* sp_len,
                              uint8_t* sp_state, uint32_t* err, hipStream_t st);

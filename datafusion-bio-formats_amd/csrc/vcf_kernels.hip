@@ -229,9 +229,106 @@ __device__ __forceinline__ float f64_to_f32_rne(double d) {
   const uint64_t r = q + ((rest > half || (rest == half && (q & 1))) ? 1 : 0);
   return __uint_as_float(sign | (uint32_t)r);           // r == 2^23 is the smallest normal: the same encoding
 }
-// Correctly rounded decimal -> f32 (what Rust's `str::parse::<f32>` returns).  0 ok; 1 malformed;
-// 2 needs arbitrary precision: more than 19 significant digits AND within one part in 2^52 of a rounding boundary
-// (reported as an error, never guessed).
+// ---- exact slow path of the float parser: big integers ------------------------------------------------------------
+// Reached only when the fast paths below cannot prove the rounding (a literal within one part in 2^52 of the midpoint of two
+// neighbouring f32 values -- the midpoints themselves have up to ~150 significant digits).  The literal's digits (the first
+// BIG_DIGITS significant ones exactly, the rest as a sticky bit) and the midpoint M x 2^q are compared as integers:
+// D x 10^k <=> M x 2^q after the powers of five and two have been moved to the side where they are non-negative.
+constexpr int BIG_N = 48;        // 1536 bits: 300 digits (997 bits) x 2^(<= 350) or 2^53 x 5^(<= 346) x 2^(<= 350)
+constexpr int BIG_DIGITS = 300;
+struct Big { uint32_t w[BIG_N]; };
+__device__ __noinline__ void big_mul_add(Big* a, uint32_t mul, uint32_t add) {
+  uint64_t carry = add;
+  for (int i = 0; i < BIG_N; i++) { const uint64_t t = (uint64_t)a->w[i] * mul + carry; a->w[i] = (uint32_t)t; carry = t >> 32; }
+}
+__device__ __noinline__ void big_shl(Big* a, uint32_t bits) {
+  const int ws = (int)(bits >> 5), bs = (int)(bits & 31);
+  for (int i = BIG_N - 1; i >= 0; i--) {
+    uint32_t v = 0;
+    if (i - ws >= 0) v = a->w[i - ws] << bs;
+    if (bs && i - ws - 1 >= 0) v |= a->w[i - ws - 1] >> (32 - bs);
+    a->w[i] = v;
+  }
+}
+__device__ __noinline__ int big_cmp(const Big* a, const Big* b) {
+  for (int i = BIG_N - 1; i >= 0; i--) if (a->w[i] != b->w[i]) return a->w[i] < b->w[i] ? -1 : 1;
+  return 0;
+}
+__device__ void big_pow5(Big* a, int64_t k) {
+  while (k >= 13) { big_mul_add(a, 1220703125u, 0); k -= 13; }   // 5^13
+  uint32_t r = 1;
+  for (; k > 0; k--) r *= 5u;
+  if (r != 1) big_mul_add(a, r, 0);
+}
+// sign of (D x 10^k [+ a little when sticky]) - mid, mid > 0 finite
+__device__ __noinline__ int big_cmp_mid(const Big* D, int64_t k, bool sticky, double mid) {
+  int e;
+  const double fr = frexp(mid, &e);
+  const uint64_t M = (uint64_t)ldexp(fr, 53);
+  const int64_t q = (int64_t)e - 53;
+  Big A = *D, B;
+  for (int i = 0; i < BIG_N; i++) B.w[i] = 0;
+  B.w[0] = (uint32_t)M; B.w[1] = (uint32_t)(M >> 32);
+  int64_t sh;  // A x 2^sh <=> B
+  if (k >= 0) { big_pow5(&A, k); sh = k - q; } else { big_pow5(&B, -k); sh = k - q; }
+  if (sh >= 0) big_shl(&A, (uint32_t)sh); else big_shl(&B, (uint32_t)(-sh));
+  const int c = big_cmp(&A, &B);
+  return c != 0 ? c : (sticky ? 1 : 0);
+}
+// |value| of the literal at p (already known to be well formed, finite, non-zero), correctly rounded; `approx` is any f32
+// within a few ulps of it
+__device__ __noinline__ float parse_f32_exact(const uint8_t* p, uint32_t len, float approx) {
+  Big D;
+  for (int i = 0; i < BIG_N; i++) D.w[i] = 0;
+  uint32_t i = 0;
+  if (i < len && (p[i] == '+' || p[i] == '-')) i++;
+  int nd = 0;
+  int64_t k = 0;
+  bool dot = false, sticky = false, lead = true;
+  for (; i < len; i++) {
+    const uint8_t c = p[i];
+    const uint32_t d = (uint32_t)c - '0';
+    if (d <= 9) {
+      if (lead && d == 0) { if (dot) k--; continue; }
+      lead = false;
+      if (nd < BIG_DIGITS) { big_mul_add(&D, 10u, d); nd++; if (dot) k--; }
+      else { if (d) sticky = true; if (!dot) k++; }
+    } else if (c == '.') dot = true;
+    else break;
+  }
+  if (i < len && (p[i] == 'e' || p[i] == 'E')) {
+    i++;
+    bool eneg = false;
+    if (i < len && (p[i] == '+' || p[i] == '-')) { eneg = p[i] == '-'; i++; }
+    int64_t ex = 0;
+    for (; i < len; i++) { const uint32_t d = (uint32_t)p[i] - '0'; if (d > 9) break; if (ex < 100000) ex = ex * 10 + d; }
+    k += eneg ? -ex : ex;
+  }
+  // candidates: approx and its two neighbours on the f32 grid (2^128 stands in for infinity)
+  const double TOP = 3.402823669209384634633746074317682e38;  // 2^128
+  auto as_d = [&](float f) { return isinf(f) ? TOP : (double)f; };
+  const uint32_t ab = __float_as_uint(approx);
+  const float c0 = approx;
+  const float lo = ab ? __uint_as_float(ab - 1) : 0.0f;                  // previous float (approx >= 0)
+  const float hi = isinf(approx) ? approx : __uint_as_float(ab + 1);      // next float (0x7F7FFFFF + 1 = +inf)
+  auto even = [](float f) { return (__float_as_uint(f) & 1u) == 0u; };
+  if (ab) {
+    const double mid1 = 0.5 * (as_d(lo) + as_d(c0));
+    const int c1 = big_cmp_mid(&D, k, sticky, mid1);
+    if (c1 < 0) return lo;
+    if (c1 == 0) return even(lo) ? lo : c0;
+  }
+  if (isinf(c0)) return c0;
+  const double mid2 = 0.5 * (as_d(c0) + as_d(hi));
+  const int c2 = big_cmp_mid(&D, k, sticky, mid2);
+  if (c2 < 0) return c0;
+  if (c2 == 0) return even(c0) ? c0 : hi;
+  return hi;
+}
+
+// Correctly rounded decimal -> f32 (what Rust's `str::parse::<f32>` returns).  0 ok; 1 malformed.  Short literals are rounded
+// once from exact integer arithmetic, the others from an f64 estimate with an error bound; when the bound straddles the midpoint
+// of two f32 values the digits are compared with that midpoint as big integers (parse_f32_exact), so the result is never a guess.
 __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
   uint32_t i = 0;
   bool neg = false;
@@ -276,6 +373,7 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
   }
   if (i != len) return 1;
   float r;
+  bool unsure = false;
   if (m == 0) r = 0.0f;
   else if (e10 + nd > 40) r = __builtin_huge_valf();
   else if (e10 + nd < -50) r = 0.0f;
@@ -297,7 +395,7 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
       q <<= 1;
       if (top || rem >= dn) { rem -= dn; q |= 1; }
     }
-    if (sticky && (q & 0x7F) == 0x7F) return 2;  // dropped digits could carry into the rounding position
+    unsure = sticky && (q & 0x7F) == 0x7F;  // dropped digits could carry into the rounding position
     if (rem || sticky) q |= 1ull;
     r = ldexpf((float)q, dz - lz - 32);  // m >= 1 and 10^k <= 10^19: never below 1e-19, far from the subnormal range
   } else {
@@ -310,14 +408,37 @@ __device__ int parse_f32_text(const uint8_t* p, uint32_t len, float* out) {
     kerr += 0.5;
     const double eps = (kerr + 0.5) * 2.220446049250313e-16;
     const float flo = f64_to_f32_rne(d * (1.0 - eps)), fhi = f64_to_f32_rne(d * (1.0 + eps));
-    if (__float_as_uint(flo) != __float_as_uint(fhi)) return 2;
-    r = fhi;
+    r = flo;
+    unsure = __float_as_uint(flo) != __float_as_uint(fhi);
   }
   *out = neg ? -r : r;
-  return 0;
+  return unsure ? 2 : 0;
 }
 
 __device__ __forceinline__ void set_err(uint32_t* err, uint32_t code) { atomicCAS(err, 0u, code); }
+// A literal the fast paths could not round with certainty (parse_f32_text returned 2 and a provisional value): the cell is
+// queued behind the error word and k_f32_fix rewrites it from the exact comparison after the kernel -- the big-integer code
+// stays out of the hot kernels (inlined or called, it cost them 80 .. 250 registers).
+__device__ void f32_defer(uint32_t* err, const uint8_t* p, uint32_t len, void* dst, uint32_t as_f64, float approx) {
+  const uint32_t idx = atomicAdd(&err[1], 1u);
+  if (idx >= F32_FIX_CAP) { set_err(err, VERR_FLOAT_PRECISION); return; }
+  F32Fix* e = (F32Fix*)(err + 4) + idx;
+  e->p = p; e->dst = dst; e->len = len; e->as_f64 = as_f64; e->approx = __float_as_uint(approx); e->pad = 0;
+}
+__global__ __launch_bounds__(64) void k_f32_fix(uint32_t* err) {
+  const uint32_t n = err[1] < F32_FIX_CAP ? err[1] : F32_FIX_CAP;
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= n) return;
+  const F32Fix e = ((const F32Fix*)(err + 4))[t];
+  const float a = fabsf(__uint_as_float(e.approx));
+  float f = parse_f32_exact(e.p, e.len, a);
+  if (e.len && e.p[0] == '-') f = -f;
+  if (e.as_f64) *(double*)e.dst = (double)f; else *(float*)e.dst = f;
+}
+void launch_f32_fix(uint32_t* err, uint32_t n_queued, hipStream_t st) {
+  const uint32_t n = n_queued < F32_FIX_CAP ? n_queued : F32_FIX_CAP;
+  if (n) hipLaunchKernelGGL(k_f32_fix, dim3((n + 63) / 64), dim3(64), 0, st, err);
+}
 __device__ __forceinline__ int hexval(uint32_t c) {
   if (c - '0' <= 9u) return (int)(c - '0');
   c |= 0x20u;
@@ -609,8 +730,8 @@ __global__ __launch_bounds__(256) void k_vcf_core(const uint8_t* __restrict__ u,
       if (!(b - a == 1 && u[a] == '.')) {
         float f;
         const int rc = parse_f32_text(u + a, (uint32_t)(b - a), &f);
-        if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_QUAL);
-        else { q = (double)f; valid = true; }
+        if (rc == 1) set_err(err, VERR_BAD_QUAL);
+        else { q = (double)f; valid = true; if (rc == 2) f32_defer(err, u + a, (uint32_t)(b - a), &C.qual[r], 1, f); }
       }
       C.qual[r] = q;
     }
@@ -710,7 +831,7 @@ __global__ __launch_bounds__(256) void k_span_num(const uint8_t* __restrict__ u,
         } else {
           float f;
           const int rc = parse_f32_text(p, l, &f);
-          if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT); else { out = __float_as_uint(f); v = true; }
+          if (rc == 1) set_err(err, VERR_BAD_FLOAT); else { out = __float_as_uint(f); v = true; if (rc == 2) f32_defer(err, p, l, &values[c], 0, f); }
         }
       }
     }
@@ -860,7 +981,7 @@ __global__ __launch_bounds__(256) void k_span_list_elems(const uint8_t* __restri
           } else {
             float f;
             const int rc = parse_f32_text(p + a, el, &f);
-            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT); else out = __float_as_uint(f);
+            if (rc == 1) set_err(err, VERR_BAD_FLOAT); else { out = __float_as_uint(f); if (rc == 2) f32_defer(err, p + a, el, &values[o], 0, f); }
           }
         }
         values[o] = out;
@@ -929,7 +1050,7 @@ void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, 
 // One thread per (row, selected sample) cell c = r*NS + os: the ':'-separated value of each selected FORMAT
 // key -> sp_*[s*N + c] (N = n*NS).  gt_field = index of GT among the selected keys (-1 none): its span drops
 // a leading phasing character and is validated (alleles are digits or '.', separators '/' or '|').
-__global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+__global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
                                                            uint64_t n, const int32_t* __restrict__ sample_col, int NS,
                                                            const int16_t* __restrict__ fpos, int S, int gt_field, VcfCellDirect D,
                                                            uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
@@ -940,6 +1061,7 @@ __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restr
   // 32-bit division when the cell index fits (64-bit division is emulated with ~100 instructions)
   const uint64_t r = !act ? 0 : (N <= 0xFFFFFFFFull ? (uint64_t)((uint32_t)c / (uint32_t)NS) : c / NS);
   const int os = (int)(c - r * NS);
+  uint32_t dfix = 0;               // bit s: the float of direct field s is to be rounded exactly afterwards
   uint32_t dval[VCF_MAX_DIRECT];   // direct Int32 / Float32 value, or the length of a direct string
   uint32_t dsrc[VCF_MAX_DIRECT];   // direct string: start relative to the cell
   uint32_t dok = 0;                // bit s: direct field s has a value
@@ -1019,10 +1141,17 @@ __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restr
           } else if (ckind == 2) {    // Float32: correctly rounded parse of the span
             float f;
             const int rc = parse_f32_text(u + a + start, sl, &f);
-            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT);
+            if (rc == 1) set_err(err, VERR_BAD_FLOAT);
             else {
 #pragma unroll
               for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = __float_as_uint(f); dok |= 1u << s; }
+              if (rc == 2) {  // rounding not proven: queued for k_f32_fix where the cell is stored (its span rides in dsrc)
+                if (start >= (1u << 20) || sl >= (1u << 12)) set_err(err, VERR_FLOAT_PRECISION);
+                else {
+#pragma unroll
+                  for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dsrc[s] = start | (sl << 20); dfix |= 1u << s; }
+                }
+              }
             }
           } else if (ckind == 3) {    // GT as a direct string: validated, leading phasing mark dropped
             uint32_t tl = 0;
@@ -1073,10 +1202,17 @@ __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restr
           } else if (ckind == 2) {    // Float32: correctly rounded parse of the span
             float f;
             const int rc = parse_f32_text(u + a + start, sl, &f);
-            if (rc) set_err(err, rc == 2 ? VERR_FLOAT_PRECISION : VERR_BAD_FLOAT);
+            if (rc == 1) set_err(err, VERR_BAD_FLOAT);
             else {
 #pragma unroll
               for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = __float_as_uint(f); dok |= 1u << s; }
+              if (rc == 2) {  // rounding not proven: queued for k_f32_fix where the cell is stored (its span rides in dsrc)
+                if (start >= (1u << 20) || sl >= (1u << 12)) set_err(err, VERR_FLOAT_PRECISION);
+                else {
+#pragma unroll
+                  for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dsrc[s] = start | (sl << 20); dfix |= 1u << s; }
+                }
+              }
             }
           } else if (ckind == 3) {    // GT as a direct string: validated on the fly, leading phasing mark dropped
             uint32_t x = start;
@@ -1118,6 +1254,7 @@ __global__ __launch_bounds__(256) void k_vcf_format_cells(const uint8_t* __restr
       if (act) {
         D.values[s][c] = dval[s];
         if (D.kind[s] == 3) D.src[s][c] = a + dsrc[s];
+        if ((dfix >> s) & 1u) f32_defer(err, u + a + (dsrc[s] & 0xFFFFFu), dsrc[s] >> 20, &D.values[s][c], 0, __uint_as_float(dval[s]));
       }
       const unsigned long long m = __ballot((dok >> s) & 1u);
       if ((threadIdx.x & 63) == 0 && (c & ~63ull) < N) D.valid[s][c >> 6] = m;

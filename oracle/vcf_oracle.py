@@ -347,8 +347,48 @@ def _percent_decode(s: str) -> str:
 
 
 def parse_f32(s: str) -> float:
-    """Rust `str::parse::<f32>` (correctly rounded) -> python float holding the f32 value."""
-    return float(np.float32(s))
+    """Rust `str::parse::<f32>` (correctly rounded, ties to even) -> python float holding the f32 value.  numpy's
+    float32(str) goes through a double and rounds twice; this rounds once, with exact rational arithmetic."""
+    from fractions import Fraction
+    t = s.strip()
+    low = t.lower().lstrip("+-")
+    neg = t.startswith("-")
+    if low in ("inf", "infinity"):
+        return float("-inf") if neg else float("inf")
+    if low == "nan":
+        return float("nan")
+    import re as _re
+    if not _re.fullmatch(r"[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?", t):
+        raise ValueError(f"invalid float literal: {s!r}")
+    mant, _, ex = low.partition("e")
+    ip, _, fp = mant.partition(".")
+    digits = (ip + fp).lstrip("0")
+    if not digits:
+        return -0.0 if neg else 0.0
+    k = (int(ex) if ex else 0) - len(fp)
+    if len(digits) + k > 60:
+        return float("-inf") if neg else float("inf")
+    if len(digits) + k < -60:
+        return -0.0 if neg else 0.0
+    v = Fraction(int(digits)) * (Fraction(10) ** k)
+    # exponent e with 2^e <= v < 2^(e+1)
+    e = v.numerator.bit_length() - v.denominator.bit_length()
+    if Fraction(2) ** e > v:
+        e -= 1
+    if Fraction(2) ** (e + 1) <= v:
+        e += 1
+    q = max(e, -126) - 23                    # grid spacing 2^q (subnormals share 2^-149)
+    scaled = v / (Fraction(2) ** q)
+    n = scaled.numerator // scaled.denominator
+    rem = scaled - n
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (n & 1)):
+        n += 1
+    r = Fraction(n) * (Fraction(2) ** q)
+    if r >= Fraction(2) ** 128:
+        out = float("inf")
+    else:
+        out = float(r)
+    return -out if neg else out
 
 
 def parse_i32(s: str) -> int:

@@ -345,6 +345,64 @@ def test_float_parse_fuzz(pkg, tmp_path):
             assert q == w and x == w, (v, q, x, w)
 
 
+def test_float_literals_on_rounding_boundaries(pkg, vo, tmp_path):
+    """Literals that sit exactly on the midpoint of two f32 values (26 to 118 significant digits), a hair above and below them,
+    the overflow boundary and 40-digit literals: the device's estimate cannot decide these and its exact integer comparison
+    (k_f32_fix) must -- ties to even, like Rust's parser.  Expected values come from exact rational arithmetic in the oracle."""
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+    import struct
+    getcontext().prec = 400
+
+    def f32(bits):
+        return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+    rnd = random.Random(5)
+    vals = []
+    bit_patterns = [0x3F800000, 0x3F800001, 0x00000001, 0x00000002, 0x007FFFFF, 0x00800000, 0x4B000000, 0x7F7FFFFE, 0x3DCCCCCC, 0x0A4FB11E]
+    bit_patterns += [rnd.randrange(1, 0x7F7FFFFF) for _ in range(120)]
+    for bits in bit_patterns:
+        lo, hi = f32(bits), f32(bits + 1)
+        mid = (Fraction(lo) + Fraction(hi)) / 2
+        d = Decimal(mid.numerator) / Decimal(mid.denominator)          # exact: the midpoint is a dyadic rational
+        exact = format(d, "f") if 1e-6 < mid < 1e21 else "%se%d" % (str(d.scaleb(-d.adjusted())), d.adjusted())
+        assert Fraction(Decimal(exact)) == mid
+        frac = "." not in exact.split("e")[0] and "e" not in exact
+        for lit in (exact, "-" + exact):
+            vals.append(lit)
+        m, _, ex = exact.partition("e")
+        if "." not in m:
+            m += "."
+        for tail in ("0000000000000000000000001", "1"):
+            vals.append(m + tail + ("e" + ex if ex else ""))             # a hair above the tie: rounds up
+        # a hair below: the last digit lowered by one and nines appended
+        body = m.rstrip(".")
+        if body[-1] != "0":
+            vals.append(body[:-1] + str(int(body[-1]) - 1) + "9999999999999999999999999999" + ("e" + ex if ex else ""))
+    vals += ["340282356779733661637539395458142568448", "340282356779733661637539395458142568447.9999", "340282356779733661637539395458142568448.0001",
+             "3.4028235677973366e38", "3.4028235677973365e38", "0.1000000000000000055511151231257827021181583404541015625",
+             "16777217.000000000000000000000000000000000001", "16777217", "16777216.999999999999999999999999999999",
+             "1.00000005960464477539062500000000000000000000000000001", "1.000000059604644775390625", "0.999999970197677612304687500"]
+    lines = ["##fileformat=VCFv4.3", "##INFO=<ID=X,Number=1,Type=Float,Description=\"x\">", "##INFO=<ID=L,Number=.,Type=Float,Description=\"l\">",
+             "##FORMAT=<ID=GL,Number=1,Type=Float,Description=\"g\">",
+             "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2"]
+    for i, v in enumerate(vals):
+        lines.append(f"c\t{i + 1}\t.\tA\tT\t{v}\t.\tX={v};L=1.5,{v}\tGL\t{v}\t0.25")
+    p = tmp_path / "ties.vcf"
+    p.write_text("\n".join(lines) + "\n")
+    t = GpuTable(pkg, str(p), info_fields=["X", "L"], format_fields=["GL"])
+    r = t.read(["qual", "X", "L", "genotypes"])
+    want = [vo.parse_f32(v) for v in vals]
+    n_inf = 0
+    for i, (v, w) in enumerate(zip(vals, want)):
+        gl = r["genotypes"][i]["GL"]
+        got = (r["qual"][i], r["X"][i], r["L"][i][1], gl[0])
+        assert all(g == w for g in got), (v, got, w)
+        assert r["L"][i][0] == 1.5 and gl[1] == 0.25
+        n_inf += w == float("inf")
+    assert n_inf >= 3
+
+
 def test_vcf_errors_are_loud(pkg, tmp_path):
     """Malformed input and unsupported encodings raise (the reference yields DataFusionError::Execution);
     nothing is silently skipped or guessed."""
