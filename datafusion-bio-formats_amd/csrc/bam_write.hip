@@ -7,8 +7,9 @@
 //              CIGAR parsed from its string (or copied when binary), 4-bit packed bases, qualities minus 33;
 //   crc32      one member per lane (k_bgzf_crc32 in store mode);
 //   deflate    one BGZF member (<= 65280 payload bytes) per wavefront, two passes: (1) parse -- 64 positions per step, a
-//              4096-entry hash table of 3-byte prefixes in LDS proposes one candidate per lane (+ the distance-1 candidate
-//              for runs), lanes measure their matches, a scalar walk picks the greedy parse of the 64 positions; the tokens
+//              two-way 4096-entry hash table of 3-byte prefixes in LDS proposes two candidates per lane (+ the distance-1
+//              candidate for runs), lanes measure their matches, a match yields to a longer one at the next position, a
+//              scalar walk picks the parse of the 64 positions; the tokens
 //              go to a scratch list and the symbols are counted in LDS; the block's OWN length-limited Huffman codes are
 //              built (literal/length, distance, and the code-length code of the header); (2) the tokens are coded -- bit
 //              offsets from a wave prefix sum, bits OR-ed into an LDS staging window that is flushed as whole dwords.  The
@@ -379,7 +380,7 @@ __device__ __forceinline__ void df_dist_sym(uint32_t dist, uint32_t* sym, uint32
 }
 
 struct DfLds {
-  uint16_t table[1 << DF_HASH_BITS];
+  uint16_t table[2][1 << DF_HASH_BITS];   // two ways: the two most recent positions of every hash
   uint32_t W[DF_WORDS];
   uint32_t hl[DF_NLIT + 2], hd[DF_NDIST + 2], hp[DF_NPRE + 1];  // symbol counts
   uint32_t cl[DF_NLIT + 2], cd[DF_NDIST + 2], cp[DF_NPRE + 1];  // bit-reversed code << 8 | length
@@ -498,9 +499,9 @@ __device__ __forceinline__ void df_put(uint32_t* W, uint32_t* bitpos, uint32_t v
   *bitpos += nb;
 }
 
-// One BGZF member per wavefront.  Pass 1 parses (64 positions per step; a 4096-entry hash table of 3-byte prefixes proposes one
-// candidate per lane, + the distance-1 candidate for runs; a scalar walk over the lanes' token lengths picks the greedy
-// parse), stores the tokens and counts the symbols.  Then the block's own Huffman codes are built (df_build_code), the cost
+// One BGZF member per wavefront.  Pass 1 parses (64 positions per step; a two-way 4096-entry hash table of 3-byte prefixes
+// proposes two candidates per lane, + the distance-1 candidate for runs; lazy evaluation; a scalar walk over the lanes' token
+// lengths picks the parse), stores the tokens and counts the symbols.  Then the block's own Huffman codes are built (df_build_code), the cost
 // of the dynamic block (header included) is compared with the fixed code's, and pass 2 codes the tokens: bit offsets by a
 // wave prefix sum, bits OR-ed into an LDS window that is flushed as whole dwords.  A member whose coded form would be
 // larger than its payload is written as a stored block, so no member exceeds 64 KiB.
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
   uint8_t* slot = slots + (uint64_t)m * slot_stride;
   uint8_t* data = slot + 18;  // DEFLATE stream (dwords are stored unaligned: gfx950 global stores need no alignment)
   uint32_t* tokens = tokens_all + (uint64_t)m * 65536u;
-  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) L.table[k] = (uint16_t)DF_NONE;
+  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) { L.table[0][k] = (uint16_t)DF_NONE; L.table[1][k] = (uint16_t)DF_NONE; }
   for (int k = lane; k < DF_NLIT + 2; k += WAVE) L.hl[k] = 0;
   if (lane < DF_NDIST + 2) L.hd[lane] = 0;
   if (lane < DF_NPRE + 1) L.hp[lane] = 0;
@@ -531,9 +532,12 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
     uint32_t v = 0;
     if (inb) v = ((const bw_u32*)(in + p))->v;  // (the payload buffer is padded)
     const uint32_t h = ((v & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - DF_HASH_BITS);
-    const uint32_t cand = can ? (uint32_t)L.table[h] : DF_NONE;
+    const uint32_t cand = can ? (uint32_t)L.table[0][h] : DF_NONE;
+    const uint32_t cand2 = can ? (uint32_t)L.table[1][h] : DF_NONE;
     df_sync();
-    if (can) L.table[h] = (uint16_t)p;   // lanes with equal hashes: any of them is a valid candidate for later positions
+    // the newest position moves in, the previous newest moves to the second way (lanes with equal hashes: any of them is a
+    // valid candidate for later positions)
+    if (can) { L.table[1][h] = (uint16_t)cand; L.table[0][h] = (uint16_t)p; }
     uint32_t best_len = 0, best_dist = 0;
     if (can) {
       const uint32_t cap = n - p < 258u ? n - p : 258u;
@@ -541,11 +545,18 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
         const uint32_t l = df_match_len(in + cand, in + p, cap);
         if (l >= 3) { best_len = l; best_dist = p - cand; }
       }
+      if (cand2 != DF_NONE && cand2 < p && p - cand2 <= 32768u && best_len < cap) {
+        const uint32_t l = df_match_len(in + cand2, in + p, cap);
+        if (l >= 3 && l > best_len) { best_len = l; best_dist = p - cand2; }
+      }
       if (p >= 1) {  // runs: the previous byte (positions of this very step are not in the table yet)
         const uint32_t l = df_match_len(in + p - 1, in + p, cap);
         if (l >= 3 && l > best_len) { best_len = l; best_dist = 1; }
       }
     }
+    // lazy evaluation (zlib's): a match gives way to a literal when the next position has a longer one
+    const uint32_t next_len = __shfl_down(best_len, 1, WAVE);
+    if (best_len >= 3 && lane < WAVE - 1 && next_len > best_len) best_len = 0;
     const uint32_t tok_len = best_len >= 3 ? best_len : 1u;
     // greedy parse of the 64 positions: a scalar walk over the lanes' token lengths
     unsigned long long sel = 0;

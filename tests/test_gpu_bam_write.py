@@ -66,13 +66,13 @@ def test_bgzf_deflate_members_are_valid_and_round_trip(pkg):
 
 
 def test_compression_ratio_on_bam_like_data(pkg, golden):
-    """Not a parity property, a sanity bound: the block's own Huffman codes + greedy single-candidate matching on real BAM
-    payload stay under 0.33 of the input (measured 0.3065; zlib -6 reaches 0.2375 on the same bytes, the fixed code alone
-    0.58), and the members are dynamic-Huffman blocks (BTYPE = 10)."""
+    """Not a parity property, a sanity bound: the block's own Huffman codes + two match candidates per position + lazy
+    evaluation on real BAM payload stay under 0.30 of the input (measured 0.278; zlib -6 reaches 0.2375 on the same bytes,
+    the fixed code alone 0.58), and the members are dynamic-Huffman blocks (BTYPE = 10)."""
     data = open(os.path.join(golden, "multi_chrom_large.bam"), "rb").read()
     raw = b"".join(p for p, _ in _members(data))
     comp, _ = pkg.bgzf_deflate(raw)
-    assert len(comp) < 0.33 * len(raw), (len(comp), len(raw))
+    assert len(comp) < 0.30 * len(raw), (len(comp), len(raw))
     mem = _members(comp)
     assert all((m[18] >> 1) & 3 == 2 and m[18] & 1 for p, m in mem if len(p) > 1000)
 
