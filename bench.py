@@ -499,7 +499,7 @@ def main():
                "ms_to_first_batch": round(r["seconds_to_first_batch"] * 1e3, 2), "n_batches": r["n_batches"],
                "first_run_seconds": round(runs[0]["seconds"], 3),
                "what": "bioscan_execute + bioscan_next until end of stream, every batch released at once; compressed file resident in "
-                       "HBM, chunks of %d BGZF members, Arrow buffers copied D2H into recycled pinned blocks "
+                       "HBM, chunks of 2048 doubling to %d BGZF members, Arrow buffers copied D2H into recycled pinned blocks "
                        "(BIOSCAN_HOST_POOL_GB=%s)" % (int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384)), os.environ.get("BIOSCAN_HOST_POOL_GB", "64"))}
 
     if cpu_sample is not None:

@@ -609,6 +609,16 @@ struct BamExecState {
   const uint32_t batch_size;
   const bool to_host;
   const uint32_t chunk_members;
+  // A host stream starts with small chunks and doubles them up to chunk_members: the first batch leaves after ~2048 members'
+  // worth of work and PCIe time instead of a whole chunk's (the reference hands out its first batch after 8192 records);
+  // only when the chunk size was not set by the caller (tests drive exact chunk sizes).
+  const bool ramp;
+  uint32_t chunks_done = 0;
+  uint32_t chunk_len(uint32_t k) const {
+    if (!ramp) return chunk_members;
+    const uint64_t c = 2048ull << std::min<uint32_t>(k, 16);
+    return (uint32_t)std::min<uint64_t>(c, chunk_members);
+  }
   std::shared_ptr<DeviceImage> img;  // this partition's device: resident members + tables + reference names
   K1Ctx k1;
   hipStream_t st = nullptr, copy_st = nullptr;
@@ -633,7 +643,8 @@ struct BamExecState {
 
   BamExecState(const Plan& pl, int partition, uint32_t bs, bool host)
       : plan(pl), p(*pl.prov), batch_size(bs), to_host(host),
-        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device) {
+        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device),
+        ramp(host && !pl.prov->chunk_members) {
     satisfiable = build_terms(plan, &terms);
     items = build_work(plan, partition, terms.size());
     if (!satisfiable) items.clear();
@@ -692,7 +703,7 @@ struct BamExecState {
     StageTimer t(st);
     bioscan_scan_stats s{};
     // ---- members of this chunk; the item ends with the member that holds stop_rel ----
-    const uint32_t m0 = next_member, m1 = std::min<uint32_t>(w.range.b_hi, m0 + chunk_members);
+    const uint32_t m0 = next_member, m1 = std::min<uint32_t>(w.range.b_hi, m0 + chunk_len(chunks_done));
     const uint64_t range_u0 = p.blk_uoff[w.range.b_lo];
     const uint64_t chunk_bytes = p.blk_uoff[m1] - p.blk_uoff[m0];
     const bool last = m1 == w.range.b_hi || consumed + chunk_bytes >= w.range.stop_rel;
@@ -866,12 +877,13 @@ struct BamExecState {
     } else {
       const uint64_t c = L - end_of_records;
       const int nxt = cur ^ 1;
-      const uint64_t next_bytes = p.blk_uoff[std::min<uint32_t>(w.range.b_hi, m1 + chunk_members)] - p.blk_uoff[m1];
+      const uint64_t next_bytes = p.blk_uoff[std::min<uint32_t>(w.range.b_hi, m1 + chunk_len(chunks_done + 1))] - p.blk_uoff[m1];
       if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
       if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
       carry_len = c;
       cur = nxt;
     }
+    chunks_done++;
     // every kernel that reads this chunk's scratch (record table, keys, row list) has to be done before the scratch
     // is released at the end of this scope; the Arrow buffers live on in `res`
     HIP_CHECK(hipStreamSynchronize(st));
