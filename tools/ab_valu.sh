@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev tool: SQ_INSTS_VALU / SQ_BUSY_CYCLES of K1 per phase -- the ablation builds of ab_ablate.sh under a --pmc pass
+# dev tool: SQ_INSTS_VALU / SQ_BUSY_CYCLES of K1 per phase -- the ablation builds (see ab_cfg.sh) under a --pmc pass
 # (16384 members; outputs of the ablated builds are wrong on purpose, only the counters are meaningful)
 R=$GRAFT_REPO_ROOT
 make -C $R/tools >/dev/null 2>&1
