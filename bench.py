@@ -7,8 +7,11 @@ in HBM, for `SELECT *` (the 12 core columns).  The compressed file is resident i
 timed region starts; nothing is cached between steps (every step re-inflates and re-extracts).
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B]
-N > 1 is launched by torch.distributed.run (one rank per GPU); ranks scan independent files
-(weak scaling: BAI/BGZF block ranges shard with no collective on the data path).
+N > 1: one rank per GPU.  Started by a launcher (torch.distributed.run sets WORLD_SIZE) the process is one rank; started
+bare (`python bench.py --gpus N`) it spawns the N ranks as child processes itself, before any GPU call, and relays
+rank 0's line.  Default workload at N > 1 is config 5: ONE file of N x --blocks members whose BAI plan is
+sharded in order over the ranks, every rank uploading and inflating only its run (weak scaling, no collective on the
+data path); `--mode shards` gives every rank its own independent file instead.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -275,6 +278,21 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n, argv):
+    """Start `n` ranks of this script under torch.distributed.run as a child process tree and return its exit status.
+    Called before torch is imported: the parent never initialises the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,15 +314,33 @@ def main():
                     help="indexed mode: partitions of a rank executed concurrently from this many threads, the way DataFusion drives "
                          "execute(partition); 1 (default) = one after another, which keeps stage_ms and the roofline's launch time "
                          "free of overlap -- with more threads they are sums of overlapping stream times")
-    ap.add_argument("--mode", default="sequential", choices=["sequential", "indexed"],
-                    help="sequential: each rank scans its own file as one partition (weak scaling, default). "
-                         "indexed: every rank opens the SAME file, the BAI plan (target_partitions = 8 x ranks) is "
-                         "sharded in order across ranks and each rank inflates only its partitions' members (strong scaling)")
+    ap.add_argument("--mode", default=None, choices=["sequential", "indexed", "shards"],
+                    help="sequential (default at N = 1): the rank scans its file as one partition. "
+                         "indexed (default at N > 1; config 5 / SURVEY 8e): every rank opens the SAME file of --blocks x N members, the "
+                         "BAI plan (target_partitions = 8 x ranks) is sharded in order across ranks "
+                         "(bio-format-core/src/range_planning.rs:147-195) and each rank uploads and inflates only its partitions' "
+                         "members -- per-GPU work stays that of config 2, so the scaling is weak. "
+                         "shards: N > 1 with one independent file of --blocks members per rank (seed 42 + rank), each one partition")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL over xGMI for
+        # the bench's own barrier / MAX / SUM) before this process has imported torch or made any HIP call -- a process that
+        # has touched the GPU must never exec or fork into another GPU program -- relay their output (rank 0 prints the JSON
+        # line) and exit with their status.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1 and args.mode is None:
+        args.mode = "indexed"   # ONE file, its BAI plan sharded in order over the ranks
+    if args.mode is None:
+        args.mode = "sequential"
 
     import torch
     import torch.distributed as dist
@@ -334,31 +370,41 @@ def main():
     synth = os.path.join(ROOT, "tools", "_build", "synth_bam")
     if not os.path.exists(synth):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
-    # the synthetic file (~26 KB per member) goes to /dev/shm when every local rank's file fits there with room to
-    # spare, else to /tmp; if neither has the space the member count per rank is reduced and reported as such
-    need = int(args.blocks * 27000 * 1.15) * max(1, world)
-    shm = None
-    for cand in ("/dev/shm", "/tmp"):
-        try:
-            if os.path.isdir(cand) and os.access(cand, os.W_OK):
-                vfs = os.statvfs(cand)
-                if vfs.f_bavail * vfs.f_frsize > need:
-                    shm = cand
-                    break
-        except OSError:
-            pass
-    if shm is None:
-        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-        vfs = os.statvfs(shm)
-        fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / max(1, world) / (27000 * 1.15))
-        args.blocks = max(4096, min(args.blocks, fit))
-    path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.bam")
+    # indexed mode at N > 1 (config 5): ONE file of --blocks x N members, written by rank 0 and opened by every rank;
+    # otherwise every rank writes its own file of --blocks members.
+    # The file (~26 KB per member) goes to /dev/shm when it fits there with room to spare, else to /tmp; if neither has the
+    # space the member count is reduced and reported as such.
+    shared = world > 1 and args.mode == "indexed"
     ncpu = os.cpu_count() or 1
-    gen_threads = max(1, min(16, ncpu // max(1, world if world > 1 else 1)))
-    t0 = time.time()
-    seed = 42 if args.mode == "indexed" else 42 + rank
-    meta = json.loads(subprocess.check_output([synth, path, str(args.blocks), str(seed), str(gen_threads)]).decode())
-    t_gen = time.time() - t0
+    path, meta, t_gen = None, None, 0.0
+    if rank == 0 or not shared:
+        need = int(args.blocks * 27000 * 1.15) * max(1, world)
+        shm = None
+        for cand in ("/dev/shm", "/tmp"):
+            try:
+                if os.path.isdir(cand) and os.access(cand, os.W_OK):
+                    vfs = os.statvfs(cand)
+                    if vfs.f_bavail * vfs.f_frsize > need:
+                        shm = cand
+                        break
+            except OSError:
+                pass
+        if shm is None:
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+            vfs = os.statvfs(shm)
+            fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / max(1, world) / (27000 * 1.15))
+            args.blocks = max(4096, min(args.blocks, fit))
+        path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.bam")
+        file_blocks = args.blocks * (world if shared else 1)
+        gen_threads = max(1, min(16 * world, ncpu)) if shared else max(1, min(16, ncpu // max(1, world)))
+        t0 = time.time()
+        seed = 42 if args.mode == "indexed" else 42 + rank
+        meta = json.loads(subprocess.check_output([synth, path, str(file_blocks), str(seed), str(gen_threads)]).decode())
+        t_gen = time.time() - t0
+    if shared:
+        box = [path, meta, args.blocks]
+        dist.broadcast_object_list(box, src=0, device=torch.device(COLL_DEVICE if COLL_DEVICE == "cpu" else f"cuda:{local_rank}"))
+        path, meta, args.blocks = box
 
     # ---- CPU baseline sample (rank 0, N == 1 only): read now, timed after the GPU steps ----
     cpu = None
@@ -376,12 +422,16 @@ def main():
     if args.mode != "indexed":
         prov.make_resident()  # (indexed mode: each rank uploads only what its partitions inflate, below)
     t_load = time.time() - t0
-    if not args.keep_file:
-        for p in (path, path + ".bai"):
-            try:
-                os.unlink(p)
-            except OSError:
-                pass
+
+    def unlink_input():
+        if not args.keep_file:
+            for p in (path, path + ".bai"):
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+    if not shared:
+        unlink_input()
     if args.projection == "*":
         projection = None
     elif args.projection == "count":
@@ -397,6 +447,10 @@ def main():
         plan.make_resident(my_parts)   # only the compressed byte range this rank's partitions cover
         t_load += time.time() - t0
         res_lo, res_hi = prov.resident_range(local_rank)
+        if shared:
+            dist.barrier()             # every rank has mapped the file and uploaded its range
+            if rank == 0:
+                unlink_input()
     else:
         plan = prov.scan(projection=projection, target_partitions=1)
         assert plan.num_partitions() == 1
@@ -445,7 +499,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     # full-size property: every record the generator wrote comes back (and K2 has checked the CRC32 of every member)
-    if (args.mode == "sequential" or world == 1) and int(stats["n_rows"]) != int(meta["n_records"]):
+    if not shared and int(stats["n_rows"]) != int(meta["n_records"]):
         raise SystemExit(f"rank {rank}: the scan returned {stats['n_rows']} rows, the generator wrote {meta['n_records']} records")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=COLL_DEVICE)
@@ -455,6 +509,8 @@ def main():
                             float(stats["arrow_bytes"])], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_rows, tot_u, tot_c, tot_a = [float(x) for x in cnt.tolist()]
+        if shared and int(tot_rows) != int(meta["n_records"]):   # the ranks' runs of the plan together return every record once
+            raise SystemExit(f"the {world} ranks returned {int(tot_rows)} rows, the generator wrote {meta['n_records']} records")
     else:
         tot_rows, tot_u, tot_c, tot_a = (float(stats["n_rows"]), float(stats["inflated_bytes"]),
                                          float(stats["compressed_bytes"]), float(stats["arrow_bytes"]))
@@ -537,26 +593,33 @@ def main():
         per_step = elapsed / args.steps
         gb = meta["compressed_bytes"] / 1e9
         if world == 1:
-            workload = "BGZF-BAM full-table scan (config 2), synthetic 150bp paired reads, seed 42"
-        elif args.mode == "indexed":
-            workload = (f"BGZF-BAM scan of ONE {gb:.1f} GB file (config-2 generator, seed 42) by {world} GPUs: the BAI plan of "
-                        f"{8 * world} partitions sharded in order, every rank inflates only its partitions' members")
+            workload = "BGZF-BAM full-table scan (config 2), synthetic 150bp paired reads, seed 42" + \
+                       (", as the BAI plan of 8 partitions" if args.mode == "indexed" else "")
+        elif shared:
+            workload = (f"config 5: ONE BGZF-BAM of {meta['n_blocks']} members ({gb:.1f} GB compressed; config-2 generator, seed 42, "
+                        f"{args.blocks} members per GPU) scanned by {world} GPUs: the BAI plan of {8 * world} partitions sharded in "
+                        "order over the ranks (range_planning.rs:147-195), every rank uploads and inflates only its partitions' members")
         else:
-            workload = (f"config-5 style shards: {world} GPUs x {meta['n_blocks']} BGZF members ({gb:.1f} GB compressed each, "
-                        f"{gb * world:.1f} GB in total; config 5 names ~200 GB), config-2 generator with seed 42 + rank, "
-                        "one independent block-range shard per GPU")
+            workload = (f"independent shards: {world} GPUs x {meta['n_blocks']} BGZF members ({gb:.1f} GB compressed each, "
+                        f"{gb * world:.1f} GB in total), config-2 generator with seed 42 + rank, one block-range shard per GPU")
         avg_infl = sum(infl_ms) / len(infl_ms)
         c, u = float(stats["compressed_bytes"]), float(stats["inflated_bytes"])
         achieved = (c + u) / (avg_infl * 1e-3) / 1e9  # GB/s, algorithmic bytes of K1 = C read + U written
         out = {
             "metric": "bgzf_bam_full_scan_records_per_sec", "value": round(tot_rows / per_step / 1e6, 3), "unit": "Mrec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong" if args.mode == "indexed" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload,
-                       "n_blocks_per_gpu": meta["n_blocks"], "compressed_bytes_per_gpu": meta["compressed_bytes"],
-                       "inflated_bytes_per_gpu": meta["inflated_bytes"], "records_per_gpu": meta["n_records"],
+                       "n_blocks_per_gpu": meta["n_blocks"] // (world if shared else 1),
+                       "compressed_bytes_per_gpu": meta["compressed_bytes"] // (world if shared else 1),
+                       "inflated_bytes_per_gpu": meta["inflated_bytes"] // (world if shared else 1),
+                       "records_per_gpu": meta["n_records"] // (world if shared else 1),
+                       **({"file_blocks": meta["n_blocks"], "file_compressed_bytes": meta["compressed_bytes"],
+                           "file_records": meta["n_records"], "plan_partitions": 8 * world,
+                           "rank0_partitions": len(my_parts), "rank0_resident_bytes": int(res_hi - res_lo)} if shared else {}),
                        "projection": args.projection, "batch_size": args.batch_size, "mode": args.mode, "deflate_level": meta["level"],
-                       "deflater": meta["deflate"], "parallelism": f"{world} independent block-range shard(s), no collective",
+                       "deflater": meta["deflate"], "parallelism": (f"{world} ranks, contiguous runs of one BAI plan, no collective on the data path" if shared
+                                       else f"{world} independent block-range shard(s), no collective"),
                        **({"partition_threads": args.partition_threads,
                            "stage_ms_note": "partitions run concurrently: stage_ms and roofline.avg_launch_ms are sums of overlapping stream times"}
                           if pool is not None else {})},

@@ -65,6 +65,13 @@ def full_size_blocks(full: int, fallback: int, bytes_per_block: int = 27000) -> 
     return fallback
 
 
+def report_size(test, **sizes):
+    """Large-input tests pick their size from the box (scratch space, cores); a UserWarning survives `pytest -q` and lands
+    in the driver's record, so the record says which size a run actually covered."""
+    import warnings
+    warnings.warn("%s ran with %s" % (test, ", ".join("%s=%s" % kv for kv in sizes.items())), UserWarning, stacklevel=2)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

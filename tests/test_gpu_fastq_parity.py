@@ -240,6 +240,9 @@ def test_large_file_properties(pkg):
         prov = pkg.FastqTableProvider(path)
         plan = prov.scan(target_partitions=1)
         first = plan.execute_device(0, 8192)
+        from conftest import report_size
+        report_size("test_large_file_properties[fastq]", members=meta["n_blocks"], reads=meta["n_records"],
+                    inflated_GB=round(meta["inflated_bytes"] / 1e9, 2))
         assert first["n_rows"] == meta["n_records"]
         assert first["inflated_bytes"] == meta["inflated_bytes"]
         again = plan.execute_device(0, 8192)

@@ -109,6 +109,9 @@ def test_large_file_properties(pkg):
         prov.make_resident()
         plan = prov.scan(target_partitions=1)
         first = plan.execute_device(0, 8192)
+        from conftest import report_size
+        report_size("test_large_file_properties[bam]", members=meta["n_blocks"], records=meta["n_records"],
+                    compressed_GB=round(meta["compressed_bytes"] / 1e9, 2), inflated_GB=round(meta["inflated_bytes"] / 1e9, 2))
         assert first["n_rows"] == first["n_records"] == meta["n_records"]
         assert first["inflated_bytes"] >= meta["inflated_bytes"]          # + the header member(s)
         assert first["compressed_bytes"] == meta["compressed_bytes"]

@@ -633,6 +633,9 @@ def test_large_file_properties(pkg, tmp_path):
         seq = pkg.VcfTableProvider(path, index_path="")
         plan = seq.scan(target_partitions=1)
         first = plan.execute_device(0, 8192)
+        from conftest import report_size
+        report_size("test_large_file_properties[vcf]", lines=n_lines, members=first["n_blocks"],
+                    inflated_GB=round(first["inflated_bytes"] / 1e9, 2), multisample_lines=max(2000, n_lines // 200), samples=500)
         assert first["n_rows"] == n_lines
         again = plan.execute_device(0, 8192)
         for k in ("n_rows", "n_blocks", "inflated_bytes", "arrow_bytes"):
