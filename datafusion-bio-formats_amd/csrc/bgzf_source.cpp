@@ -188,42 +188,59 @@ std::shared_ptr<DeviceImage> BgzfSource::build_image(int dev, uint32_t m_lo, uin
   return img;
 }
 
-void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members) {
+void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members, bool oneshot) {
   HIP_CHECK(hipSetDevice(img.device));
   c.device = img.device;
   if (!c.stream) HIP_CHECK(hipStreamCreate(&c.stream));
   c.grid = std::min<uint32_t>(img.grid_max, std::max<uint32_t>(max_members, 1));
   if (!c.ctr.p) c.ctr.alloc(32);
-  const size_t need = ((size_t)c.grid + 8) * img.scratch_stride;
+  size_t need = ((size_t)c.grid + 8) * img.scratch_stride;
+  if (oneshot) {
+    // twice what the device holds at once: a wave finds a free stride within a few probes
+    c.n_slots = (uint32_t)((uint64_t)img.grid_max * (uint64_t)std::max(105, env_knobs().k1_slots_pct) / 100u);
+    need = (size_t)c.n_slots * img.scratch_stride;
+    if (c.slots.n < c.n_slots) c.slots.alloc(c.n_slots);
+    HIP_CHECK(hipMemsetAsync(c.slots.p, 0, (size_t)c.n_slots * 4, c.stream));
+  }
   if (c.scratch.n < need) c.scratch.alloc(need);
   if (c.status.n < max_members) c.status.alloc(std::max<uint32_t>(max_members, 1));
 }
 
-void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0) {
+void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status) {
   if (b0 < img.m_lo || b0 + nb > img.m_hi) throw Error("internal: members outside the resident range of the device image");
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
-  launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, c.status.p, c.ctr.p, c.scratch.p, c.grid,
-                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream);
+  if (c.n_slots) HIP_CHECK(hipMemsetAsync(status, 0xFF, (size_t)nb * 4, c.stream));  // a member no bounded wave took reads as an error
+  launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
+                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,
+                         (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw);
+}
+void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0) {
+  launch_inflate_to(c, img, dst, nb, b0, c.status.p);
 }
 
+void BgzfSource::launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st) {
+  launch_bgzf_crc32(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, dst - blk_uoff[b0], nb, status, st);
+}
 void BgzfSource::launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0) {
-  launch_bgzf_crc32(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, dst - blk_uoff[b0], nb, c.status.p, c.stream);
+  launch_crc_on(img, dst, nb, b0, c.status.p, c.stream);
 }
 
-void BgzfSource::check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb) {
+void BgzfSource::check_inflate_status_on(uint32_t* status, hipStream_t st, uint32_t b0, uint32_t nb) {
   DevBuf<uint32_t> res(1);
-  launch_first_bad_status(c.status.p, nb, res.p, c.stream);
+  launch_first_bad_status(status, nb, res.p, st);
   uint32_t i = 0xFFFFFFFFu;
-  HIP_CHECK(hipMemcpyAsync(&i, res.p, 4, hipMemcpyDeviceToHost, c.stream));
-  HIP_CHECK(hipStreamSynchronize(c.stream));
+  HIP_CHECK(hipMemcpyAsync(&i, res.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
   if (i != 0xFFFFFFFFu) {
-    uint32_t st = 0;
-    HIP_CHECK(hipMemcpy(&st, c.status.p + i, 4, hipMemcpyDeviceToHost));
+    uint32_t stv = 0;
+    HIP_CHECK(hipMemcpyAsync(&stv, status + i, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
     throw Error(std::string(what) + " read error: BGZF block " + std::to_string(b0 + i) + " at offset " +
-                std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(st & 0xFF) + " (code " + std::to_string(st) + ")");
+                std::to_string(blk_coff[b0 + i]) + ": " + inflate_status_str(stv & 0xFF) + " (code " + std::to_string(stv) + ")");
   }
 }
+void BgzfSource::check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb) { check_inflate_status_on(c.status.p, c.stream, b0, nb); }
 
 void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
   launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);

@@ -27,6 +27,10 @@ struct K1Ctx {
   DevBuf<unsigned long long> scratch;
   DevBuf<uint32_t> status;  // status[i] = member b0 + i of the last launch
   uint32_t grid = 0;
+  // one-shot launches (a wave per member, see inflate_v3.hip): scratch strides are borrowed through these flags, so
+  // several launches of one context may be in flight at once
+  DevBuf<uint32_t> slots;
+  uint32_t n_slots = 0;
   K1Ctx() = default;
   K1Ctx(const K1Ctx&) = delete;
   K1Ctx& operator=(const K1Ctx&) = delete;
@@ -88,10 +92,15 @@ struct BgzfSource {
   std::shared_ptr<DeviceImage> image_for(int dev, uint32_t m_lo, uint32_t m_hi);
   std::shared_ptr<DeviceImage> image_of(int dev);      // the current image of a device, or null
   std::shared_ptr<DeviceImage> build_image(int dev, uint32_t m_lo, uint32_t m_hi);
-  void init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members);
+  void init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members, bool oneshot = false);
   void launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0);
   void launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0);
   void check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb);
+  // the same three steps with the status slots and the stream named by the caller (look-ahead inflate: K1 of the next
+  // chunk runs on the context's stream while CRC and the status check of this chunk run on the execute's own stream)
+  void launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status);
+  void launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st);
+  void check_inflate_status_on(uint32_t* status, hipStream_t st, uint32_t b0, uint32_t nb);
   // Inflate blocks [0, b1) into a temporary device buffer and copy to the host (header / sampling).
   std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1);
 };

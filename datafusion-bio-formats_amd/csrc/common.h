@@ -63,7 +63,8 @@ void set_last_error(const std::string& msg);
 //   BIOSCAN_K1_WAVES_PER_CU=n  persistent-grid size of K1 (default: the occupancy API's answer)
 //   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 64)
 //   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 16384)
-//   BIOSCAN_CHUNK_MEMBERS_DEVICE=n  the same for bioscan_execute_device (default 1048576)
+//   BIOSCAN_CHUNK_MEMBERS_DEVICE=n  the same for bioscan_execute_device (default 1048576; 65536 with BIOSCAN_LOOKAHEAD=1)
+//   BIOSCAN_LOOKAHEAD / BIOSCAN_K1_ONESHOT / BIOSCAN_LA_PRIORITY / BIOSCAN_LA_HEAD  the look-ahead inflate (engine.cpp: BamExecState)
 struct EnvKnobs {
   bool debug = false, laps = false;
   int k1_waves_per_cu = 0;
@@ -71,6 +72,15 @@ struct EnvKnobs {
   double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
   uint32_t chunk_members = 16384;          // BGZF members per pipeline chunk of a host stream (~1.3 GB of Arrow buffers for short reads)
   uint32_t chunk_members_device = 1u << 20;  // device-resident execution keeps every chunk in HBM anyway: large chunks, short K1 tails
+  bool chunk_members_device_set = false;
+  uint32_t chunk_members_lookahead = 65536;  // ... with the look-ahead inflate on: small enough to pipeline
+  int lookahead = 0;      // BIOSCAN_LOOKAHEAD=1: inflate of chunk c + 1 overlapped with the other stages of chunk c (measured: no gain)
+  int k1_oneshot = 1;     // BIOSCAN_K1_ONESHOT=0: look-ahead launches keep K1's persistent grid
+  int k1_bounded_wpw = 4; // BIOSCAN_K1_BOUNDED_WPW=1: one-wave workgroups in bounded launches
+  int k1_slots_pct = 200; // BIOSCAN_K1_SLOTS_PCT: scratch strides of a bounded context, percent of what the device holds at once
+  int k1_per_wave = 1;    // BIOSCAN_K1_PER_WAVE: members a wave of a bounded K1 launch decodes before it retires
+  int la_priority = 1;    // BIOSCAN_LA_PRIORITY=0: K1's stream and the stage stream at equal priority
+  uint64_t la_head = 1u << 20;  // BIOSCAN_LA_HEAD: bytes in front of a look-ahead chunk for the record cut by the previous chunk
 };
 const EnvKnobs& env_knobs();
 

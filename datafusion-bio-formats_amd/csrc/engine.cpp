@@ -40,7 +40,14 @@ const EnvKnobs& env_knobs() {
     if (const char* e = getenv("BIOSCAN_HOST_POOL_GB")) v.host_pool_gb = atof(e);
     if (const char* e = getenv("BIOSCAN_DEV_POOL_GB")) v.dev_pool_gb = atof(e);
     if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS")) v.chunk_members = (uint32_t)std::max(1, atoi(e));
-    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS_DEVICE")) v.chunk_members_device = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("BIOSCAN_CHUNK_MEMBERS_DEVICE")) { v.chunk_members_device = (uint32_t)std::max(1, atoi(e)); v.chunk_members_device_set = true; }
+    if (const char* e = getenv("BIOSCAN_LOOKAHEAD")) v.lookahead = atoi(e);
+    if (const char* e = getenv("BIOSCAN_K1_ONESHOT")) v.k1_oneshot = atoi(e);
+    if (const char* e = getenv("BIOSCAN_K1_PER_WAVE")) v.k1_per_wave = atoi(e);
+    if (const char* e = getenv("BIOSCAN_K1_BOUNDED_WPW")) v.k1_bounded_wpw = atoi(e);
+    if (const char* e = getenv("BIOSCAN_K1_SLOTS_PCT")) v.k1_slots_pct = atoi(e);
+    if (const char* e = getenv("BIOSCAN_LA_PRIORITY")) v.la_priority = atoi(e);
+    if (const char* e = getenv("BIOSCAN_LA_HEAD")) v.la_head = (uint64_t)std::max(0ll, atoll(e));
     return v;
   }();
   return k;
@@ -622,6 +629,15 @@ struct BamExecState {
   std::shared_ptr<DeviceImage> img;  // this partition's device: resident members + tables + reference names
   K1Ctx k1;
   hipStream_t st = nullptr, copy_st = nullptr;
+  // Look-ahead inflate: K1 (vector-issue bound) of chunk c + 1 runs on the context's own low-priority stream while the
+  // HBM-bound stages of chunk c (CRC32, record chain, row selection, extract) run on `st`; K1 is launched one wave per
+  // member (one-shot) so that retiring waves leave room on every CU for those stages.  The inflate destination of a buffer
+  // starts `la_head` bytes in: the record cut by the previous chunk's end is copied in front of it afterwards.
+  const bool la;
+  bool own_st = false;
+  struct Pending { bool valid = false; uint32_t m0 = 0, m1 = 0; hipEvent_t t0 = nullptr, t1 = nullptr; } pend[2];
+  DevBuf<uint32_t> la_status[2];
+  uint64_t data_off[2] = {0, 0};  // where the inflated chunk starts inside ubuf[k]
   std::vector<WorkItem> items;
   size_t item = 0;
   // position inside the current item
@@ -643,8 +659,9 @@ struct BamExecState {
 
   BamExecState(const Plan& pl, int partition, uint32_t bs, bool host)
       : plan(pl), p(*pl.prov), batch_size(bs), to_host(host),
-        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device),
-        ramp(host && !pl.prov->chunk_members) {
+        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members
+                      : (env_knobs().lookahead && !env_knobs().chunk_members_device_set) ? env_knobs().chunk_members_lookahead : env_knobs().chunk_members_device),
+        ramp(host && !pl.prov->chunk_members), la(env_knobs().lookahead != 0) {
     satisfiable = build_terms(plan, &terms);
     items = build_work(plan, partition, terms.size());
     if (!satisfiable) items.clear();
@@ -652,8 +669,18 @@ struct BamExecState {
     work_span(items, &m_lo, &m_hi);
     img = p.device_image(plan.device_of(partition), m_lo, m_hi);
     HIP_CHECK(hipSetDevice(img->device));
-    p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(m_hi - m_lo, 1)));
-    st = k1.stream;
+    if (la) {
+      int least = 0, greatest = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      const bool prio = env_knobs().la_priority != 0;
+      HIP_CHECK(hipStreamCreateWithPriority(&k1.stream, hipStreamNonBlocking, prio ? least : 0));
+      HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio ? greatest : 0));
+      own_st = true;
+      for (auto& q : pend) { HIP_CHECK(hipEventCreate(&q.t0)); HIP_CHECK(hipEventCreate(&q.t1)); }
+    }
+    p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(m_hi - m_lo, 1)), la && env_knobs().k1_oneshot != 0);
+    if (!la) st = k1.stream;
+    else HIP_CHECK(hipStreamSynchronize(k1.stream));  // (the slot flags are zeroed on K1's stream)
     if (to_host) HIP_CHECK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
     d_terms.alloc(std::max<size_t>(terms.size(), 1));
     if (!terms.empty()) HIP_CHECK(hipMemcpyAsync(d_terms.p, terms.data(), terms.size() * sizeof(FilterTerm), hipMemcpyHostToDevice, st));
@@ -667,19 +694,50 @@ struct BamExecState {
     HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above go out of scope
   }
   ~BamExecState() {
+    // every stream of this execute is idle before any of its buffers (members declared after `k1` are destroyed first)
+    // goes back to the shared pool -- also when an exception ended a chunk between a launch and its sync
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (img) (void)hipSetDevice(img->device);
+    if (k1.stream) (void)hipStreamSynchronize(k1.stream);
+    if (st && st != k1.stream) (void)hipStreamSynchronize(st);
     if (copy_st) {
-      int prev = 0;
-      (void)hipGetDevice(&prev);
-      (void)hipSetDevice(img->device);
       (void)hipStreamSynchronize(copy_st);
       (void)hipStreamDestroy(copy_st);
-      (void)hipSetDevice(prev);
     }
+    if (own_st && st) (void)hipStreamDestroy(st);
+    for (auto& q : pend) {
+      if (q.t0) (void)hipEventDestroy(q.t0);
+      if (q.t1) (void)hipEventDestroy(q.t1);
+    }
+    (void)hipSetDevice(prev);
+  }
+  bool dead = false;  // an error ended a chunk: the stream must not be polled again
+
+  // look-ahead: K1 of members [m0, m1) into buffer k (on K1's stream; returns at once)
+  void launch_ahead(int k, uint32_t m0, uint32_t m1) {
+    const uint64_t bytes = p.blk_uoff[m1] - p.blk_uoff[m0];
+    const uint64_t head = env_knobs().la_head;
+    if (ubuf[k].n < head + bytes + 64) ubuf[k].alloc(head + bytes + 64);
+    data_off[k] = head;
+    if (la_status[k].n < m1 - m0) la_status[k].alloc(std::max<uint32_t>(m1 - m0, 1));
+    Pending& q = pend[k];
+    HIP_CHECK(hipEventRecord(q.t0, k1.stream));
+    p.launch_inflate_to(k1, *img, ubuf[k].p + head, m1 - m0, m0, la_status[k].p);
+    HIP_CHECK(hipEventRecord(q.t1, k1.stream));
+    q.valid = true; q.m0 = m0; q.m1 = m1;
   }
 
   // Next chunk of rows of the partition (never an empty one), or nullptr when the partition is exhausted.
   std::shared_ptr<Result> next_chunk() {
+    if (dead) throw Error("the stream ended with an error");
     HIP_CHECK(hipSetDevice(img->device));
+    struct Guard { bool* d; bool ok = false; ~Guard() { if (!ok) *d = true; } } guard{&dead};
+    auto r = next_chunk_impl();
+    guard.ok = true;
+    return r;
+  }
+  std::shared_ptr<Result> next_chunk_impl() {
     for (;;) {
       if (!item_open) {
         if (item >= items.size()) return nullptr;
@@ -709,25 +767,50 @@ struct BamExecState {
     const bool last = m1 == w.range.b_hi || consumed + chunk_bytes >= w.range.stop_rel;
     const uint64_t take = last ? w.range.stop_rel - consumed : chunk_bytes;  // bytes of the chunk inside the record window
     uint8_t* u = ubuf[cur].p;
-    if (ubuf[cur].n < carry_len + chunk_bytes + 64) {
-      DevBuf<uint8_t> g(carry_len + chunk_bytes + 64);
-      if (carry_len) HIP_CHECK(hipMemcpyAsync(g.p, ubuf[cur].p, carry_len, hipMemcpyDeviceToDevice, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      ubuf[cur] = std::move(g);
-      u = ubuf[cur].p;
-    }
     s.n_blocks = m1 - m0;
     s.compressed_bytes = p.blk_coff[m1] - p.blk_coff[m0];
     s.inflated_bytes = chunk_bytes;
-    t.start();
-    p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
-    s.ms_inflate = t.stop();
-    p.report_k1_debug(k1.ctr.p, m1 - m0);
-    // CRC32 validation (noodles-bgzf checks every block)
-    t.start();
-    p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
-    s.ms_crc = t.stop();
-    p.check_inflate_status(k1, m0, m1 - m0);
+    if (!la) {
+      if (ubuf[cur].n < carry_len + chunk_bytes + 64) {
+        DevBuf<uint8_t> g(carry_len + chunk_bytes + 64);
+        if (carry_len) HIP_CHECK(hipMemcpyAsync(g.p, ubuf[cur].p, carry_len, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        ubuf[cur] = std::move(g);
+        u = ubuf[cur].p;
+      }
+      t.start();
+      p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
+      s.ms_inflate = t.stop();
+      p.report_k1_debug(k1.ctr.p, m1 - m0);
+      // CRC32 validation (noodles-bgzf checks every block)
+      t.start();
+      p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
+      s.ms_crc = t.stop();
+      p.check_inflate_status(k1, m0, m1 - m0);
+    } else {
+      // this chunk's inflate is in flight since the previous chunk (or starts now: first chunk of an item); the next
+      // chunk's is queued behind it before this chunk's other stages begin
+      if (!(pend[cur].valid && pend[cur].m0 == m0 && pend[cur].m1 == m1)) {
+        if (pend[cur].valid) { HIP_CHECK(hipStreamSynchronize(k1.stream)); pend[cur].valid = false; }
+        if (carry_len) throw Error("internal: a carried record without a look-ahead buffer");
+        launch_ahead(cur, m0, m1);
+      }
+      if (!last) {
+        const uint32_t m2 = std::min<uint32_t>(w.range.b_hi, m1 + chunk_len(chunks_done + 1));
+        launch_ahead(cur ^ 1, m1, m2);
+      }
+      HIP_CHECK(hipStreamWaitEvent(st, pend[cur].t1, 0));
+      u = ubuf[cur].p + data_off[cur] - carry_len;
+      t.start();
+      p.launch_crc_on(*img, u + carry_len, m1 - m0, m0, la_status[cur].p, st);
+      s.ms_crc = t.stop();   // (waits for this chunk's inflate as well: the events of K1's stream are complete now)
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, pend[cur].t0, pend[cur].t1));
+      s.ms_inflate = ms;
+      pend[cur].valid = false;
+      p.report_k1_debug(k1.ctr.p, m1 - m0);
+      p.check_inflate_status_on(la_status[cur].p, st, m0, m1 - m0);
+    }
     (void)range_u0;
 
     // ---- record chain over [0, L): records starting in [first_rec, L); a record cut by L is carried ----
@@ -874,12 +957,30 @@ struct BamExecState {
     if (stop_item) {
       item_open = false;
       carry_len = 0;
+      if (la && pend[cur ^ 1].valid) {   // (a tail item ended before its range did: the look-ahead is not needed)
+        HIP_CHECK(hipStreamSynchronize(k1.stream));
+        pend[cur ^ 1].valid = false;
+      }
     } else {
       const uint64_t c = L - end_of_records;
       const int nxt = cur ^ 1;
       const uint64_t next_bytes = p.blk_uoff[std::min<uint32_t>(w.range.b_hi, m1 + chunk_len(chunks_done + 1))] - p.blk_uoff[m1];
-      if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
-      if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
+      if (!la) {
+        if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
+        if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
+      } else if (c <= data_off[nxt]) {
+        if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p + data_off[nxt] - c, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
+      } else {
+        // the cut record is longer than the head room in front of the next chunk's bytes: wait for that inflate and move
+        // both into a buffer that holds them
+        HIP_CHECK(hipStreamSynchronize(k1.stream));
+        DevBuf<uint8_t> g(c + next_bytes + 64);
+        HIP_CHECK(hipMemcpyAsync(g.p, u + end_of_records, c, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(g.p + c, ubuf[nxt].p + data_off[nxt], next_bytes, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        ubuf[nxt] = std::move(g);
+        data_off[nxt] = c;
+      }
       carry_len = c;
       cur = nxt;
     }

@@ -90,7 +90,10 @@ constexpr uint32_t F_EOB = 1, F_BAD = 2;
 // Every synchronisation is therefore wave-local: LDS operations of one wave execute in order, so a compiler +
 // counter fence is all a "barrier" has to be.
 #ifndef V3_WAVES_PER_WG
-#define V3_WAVES_PER_WG 1
+#define V3_WAVES_PER_WG 1     // persistent launches
+#endif
+#ifndef V3_BOUNDED_WPW
+#define V3_BOUNDED_WPW 4      // bounded launches (look-ahead inflate): a retiring workgroup frees room for a 256-thread workgroup
 #endif
 #define V3_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
@@ -112,6 +115,7 @@ struct __attribute__((aligned(16))) V3Lds {
   uint32_t be_lut[64];  // [0..31] length symbols 257.., [32..63] distance symbols: base value
   uint16_t null_slot[7];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v3_pass)
   uint16_t eob_fix;       // bits a lane over-consumed when it followed the end-of-block pointer (see E_EOB)
+  uint32_t bnd_slot, bnd_budget;  // bounded launches: the scratch stride this wave borrowed, members it may still take
 #ifdef V3_PAD_LDS
   uint32_t pad_lds[V3_PAD_LDS / 4];  // occupancy experiment only
 #endif
@@ -126,15 +130,17 @@ __device__ __forceinline__ uint32_t uni2(uint32_t v) { return __builtin_amdgcn_r
 __device__ __forceinline__ uint32_t bitrev2(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
 // ---- uniform register-staged bit reader (as v1) ---------------------------------------------------
+// (address space 1: see V3_SRC)
+typedef const __attribute__((address_space(1))) uint32_t* v3_gsrc_t;
 struct UBits {
-  const uint32_t* base;
+  v3_gsrc_t base;
   uint32_t cur, nxt, cidx, wpos;
   uint64_t bb;
   int bc;
 };
 // start reading at bit `bitpos` counted from the 4-byte aligned pointer `base`
 __device__ __forceinline__ void ub_init(UBits& s, const uint32_t* base, uint64_t bitpos, int lane) {
-  s.base = base;
+  s.base = (v3_gsrc_t)base;
   uint32_t w = (uint32_t)(bitpos >> 5);
   s.cidx = w >> 6;
   s.cur = base[(size_t)s.cidx * 64 + lane];
@@ -222,7 +228,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uin
 // code per lane (groups by comparing root prefixes of neighbours, sizes by a suffix scan -- sub-tables are handed out
 // from the END of the sub-table space, so a group's place is known from the groups to its right alone), root entries one
 // symbol per lane.
-__device__ int v3_build(V3Lds& L, const uint8_t* lens, int n, uint16_t* fast, uint32_t abs_off, int root_bits, int sub_cap,
+__device__ __forceinline__ int v3_build(V3Lds& L, const uint8_t* lens, int n, uint16_t* fast, uint32_t abs_off, int root_bits, int sub_cap,
                         uint16_t* sorted, bool is_dist, int lane) {
   V3_SYNC();
   for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = (uint16_t)E_BAD;  // bit patterns no code maps to
@@ -357,6 +363,10 @@ __device__ int v3_build(V3Lds& L, const uint8_t* lens, int n, uint16_t* fast, ui
 // lane to the distance table, a stopped lane follows its self-pointer for ever: lanes in different states share the same
 // instructions, so a wave never pays for a path only one lane needs, and there is no loop-carried predicate (each costs
 // four scalar instructions per step to merge; K1 is bound by VALU + SALU issue).
+// The compressed input is read through an address-space-1 pointer: `base32` is made from an integer (alignment of the payload
+// pointer), which hides from the compiler that it points to global memory, and a generic pointer is read with FLAT loads.
+// A FLAT load counts in lgkmcnt as well as in vmcnt, so the `s_waitcnt lgkmcnt(0)` behind the table lookup of the NEXT
+// decode step waited for the bit-window prefetch to come back from L2 / HBM -- the prefetch hid nothing.
 #ifdef V3_GUARD
 #define V3_SRC(i) (V3_G((i) > ((limit + 64u) >> 5) + 3u, 1, (i)) ? 0u : gsrc[i])
 #else
@@ -372,7 +382,7 @@ static_assert((uint32_t)V3_CK_MAX * V3_CK_ROW == V3_CK_DWORDS, "kernels.h sizes 
 // instructions), and because every lane then starts its count pass at its own first symbol, the checkpoint rows of all
 // lanes are aligned to the same steps.  Garbage contains END-OF-BLOCK and unassigned codes: such a stop says nothing about
 // the block, the lane carries on from the literal/length root.
-__device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t count_from, uint32_t limit, const uint32_t* __restrict__ gsrc) {
+__device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t count_from, uint32_t limit, v3_gsrc_t gsrc) {
   uint32_t pos = start;
   const bool run0 = pos < count_from;  // a lane that starts exactly on its boundary (lane 0: the round's first bit) is there already
   uint32_t wp = pos >> 5;
@@ -429,7 +439,7 @@ __device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t c
 __device__ unsigned long long v3_util[4];  // dev diagnostic: loop iterations / lane-steps of the first count pass, of the fix passes
 #endif
 __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, uint32_t limit,
-                                         const uint32_t* __restrict__ gsrc, uint32_t* __restrict__ ck, int lane,
+                                         v3_gsrc_t gsrc, uint32_t* __restrict__ ck, int lane,
                                          uint32_t& end_out, uint32_t& acc_out, uint32_t& flags, uint32_t& ck_n, int kind = 0) {
   static_assert(offsetof(V3Lds, null_slot) - offsetof(V3Lds, lit_fast) == V3_NULL_BASE, "null slots must sit at V3_NULL_BASE");
   uint32_t pos = start;
@@ -528,7 +538,7 @@ template <int MODE>
 __device__ __forceinline__ uint32_t v3_write(V3Lds& L, bool active, uint32_t pos, uint32_t tb0, uint32_t mb0, uint32_t mlen,
                                              uint32_t limit, uint32_t stop_any, uint8_t* out, uint32_t opos,
                                              unsigned long long* mlist, uint32_t mpos, uint32_t win_base,
-                                             const uint32_t* __restrict__ gsrc) {
+                                             v3_gsrc_t gsrc) {
   const bool run0 = active && pos < stop_any;
   uint32_t wp = pos >> 5;
   const uint32_t wp0 = run0 ? wp : 0u;
@@ -600,7 +610,7 @@ __device__ __forceinline__ void st4(uint8_t* p, uint32_t v) { ((u32p*)p)->v = v;
 __device__ __forceinline__ void st2(uint8_t* p, uint16_t v) { ((u16p*)p)->v = v; }
 
 // dependency-ordered copy of <= 64 matches (one per lane)
-__device__ void v3_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
+__device__ __forceinline__ void v3_resolve_batch(uint8_t* out, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
   bool valid = lane < nm;
   if (valid && V3_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u, 4, m_dst + m_len)) valid = false;
   const uint32_t src_lo = m_dst - m_dist;
@@ -719,7 +729,7 @@ __device__ __forceinline__ void v3_far_finish(uint8_t* win, const uint8_t* out, 
 }
 
 // dependency-ordered copy of the in-window part of <= 64 matches (one per lane, sorted by destination)
-__device__ void v3_near_batch(uint8_t* win, uint32_t R, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
+__device__ __forceinline__ void v3_near_batch(uint8_t* win, uint32_t R, int lane, int nm, uint32_t m_dst, uint32_t m_len, uint32_t m_dist) {
   bool valid = lane < nm;
   if (valid && V3_G(m_dst + m_len > 65536u || m_dist > m_dst || m_len > 258u || m_dst < R || m_dst + m_len - R > (uint32_t)V3_WIN, 5, m_dst + m_len)) valid = false;
   const uint32_t src_lo = m_dst - m_dist;
@@ -841,17 +851,48 @@ __device__ __forceinline__ void v3_resolve(V3Lds& L, uint8_t* out, unsigned long
 #ifndef V3_WAVES_PER_EU
 #define V3_WAVES_PER_EU 5
 #endif
-__global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgzf_inflate_v3(const uint8_t* __restrict__ comp,
+template <int WPW, bool BOUNDED>
+__global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3(const uint8_t* __restrict__ comp,
                                                            const uint64_t* __restrict__ blk_coff,
                                                            const uint64_t* __restrict__ blk_uoff, uint8_t* out_all,
                                                            uint32_t n_blocks, uint32_t* __restrict__ status,
                                                            uint32_t* counter, unsigned long long* scratch,
-                                                           uint32_t scratch_stride, uint32_t* dbg) {
-  __shared__ V3Lds L_all[V3_WAVES_PER_WG];
+                                                           uint32_t scratch_stride, uint32_t* dbg, uint32_t* slots, uint32_t n_slots,
+                                                           uint32_t per_wave) {
+  __shared__ V3Lds L_all[WPW];
   V3Lds& L = L_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
+  // Two launch shapes.  PERSISTENT (slots == nullptr): the grid is what the device holds at once, every wave owns scratch
+  // stride blockIdx and pulls members from the atomic counter until none is left.  BOUNDED (slots != nullptr): workgroups
+  // of WPW waves, every wave pulls at most `per_wave` members and retires, so a workgroup lives a few milliseconds and
+  // then frees WPW wave slots + its LDS in one piece -- room in which the 256-thread workgroups of the HBM-bound stages
+  // of the previous chunk (other stream, higher priority) fit while a long inflate runs.  (With one-wave workgroups a
+  // freed slot is always taken by the next inflate wave: a 4-wave workgroup of another kernel never finds room.)
+  // A bounded wave borrows one of n_slots scratch strides for its lifetime: lane 0 claims a free flag by compare-and-swap,
+  // starting at a hashed position; n_slots is twice what the device can hold, so a few probes find one.
+  // (The kernel runs at the edge of its register budget: the bounded shape keeps its loop state -- members left, the
+  // borrowed stride -- in LDS and is a separate instantiation, so the persistent one compiles to what it was.)
+  uint32_t slot = blockIdx.x * WPW + (threadIdx.x >> 6);
+  if constexpr (BOUNDED) {
+    uint32_t h = 0;
+    if (lane == 0) {
+      h = (slot * 0x9E3779B1u) % n_slots;
+      // every resident wave holds at most one stride and there are more strides than resident waves, so a free one turns
+      // up within a few probes; the probe count is bounded anyway: a wave that finds none takes no member and retires (the
+      // members it would have taken are decoded by the waves that follow)
+      uint32_t tries = 0;
+      while (atomicCAS(&slots[h], 0u, 1u) != 0u) {
+        h = h + 1u == n_slots ? 0u : h + 1u;
+        if (++tries > (1u << 22)) { h = 0xFFFFFFFFu; break; }
+      }
+      L.bnd_slot = h;
+      L.bnd_budget = h == 0xFFFFFFFFu ? 0u : per_wave;
+    }
+    slot = uni2(h);
+    if (slot == 0xFFFFFFFFu) slot = 0;  // (no member will be taken: the scratch pointer is never used)
+  }
   // per-wave scratch (L2-resident): the match list of a mini-round, then the checkpoint rows of a round
-  unsigned long long* mlist = scratch + ((size_t)blockIdx.x * V3_WAVES_PER_WG + (threadIdx.x >> 6)) * scratch_stride;
+  unsigned long long* mlist = scratch + (size_t)slot * scratch_stride;
   uint32_t* ck = (uint32_t*)(mlist + V3_ML_ENTRIES);
   uint32_t dbg_rounds = 0, dbg_passes = 0, dbg_matches = 0, dbg_near = 0, dbg_minis = 0, dbg_idle = 0, dbg_hbm = 0;
   uint64_t pred_bits = V3_FIRST_BLOCK_BITS;  // expected length of the next DEFLATE block body (the previous block's)
@@ -873,6 +914,13 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
   V3_SYNC();
 
   for (;;) {
+    if constexpr (BOUNDED) {
+      V3_SYNC();
+      const uint32_t left = uni2(L.bnd_budget);
+      if (left == 0u) break;
+      V3_SYNC();
+      if (lane == 0) L.bnd_budget = left - 1u;
+    }
     uint32_t b = 0;
     if (lane == 0) b = atomicAdd(counter, 1u);
     b = uni2(b);
@@ -896,6 +944,8 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
     const uint32_t* base32 = (const uint32_t*)((uintptr_t)payload & ~(uintptr_t)3);
     const uint64_t skew = (uint64_t)((uintptr_t)payload & 3) * 8;
     const uint64_t end_bits = skew + payload_len * 8;
+    // a bounded wave lives for a few members: the block length is predicted from the member itself (a BGZF member is usually one block)
+    if constexpr (BOUNDED) pred_bits = payload_len * 8 < 2048 ? 2048 : payload_len * 8;
     uint64_t P = skew;
     uint32_t opos = 0;
     bool first_block = true;
@@ -1052,7 +1102,7 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
         if (ovb < (uint32_t)V3_OV_MIN) ovb = V3_OV_MIN;
         if (ovb > (uint32_t)V3_OV_MAX) ovb = V3_OV_MAX;
         const uint64_t wb = P >> 5;
-        const uint32_t* gsrc = base32 + wb;
+        v3_gsrc_t gsrc = (v3_gsrc_t)(base32 + wb);
         TOCK(1);
         const uint32_t rel0 = (uint32_t)(P & 31);
         const uint32_t bnd = rel0 + (uint32_t)lane * subb;
@@ -1199,6 +1249,10 @@ __global__ __launch_bounds__(WAVE * V3_WAVES_PER_WG, V3_WAVES_PER_EU) void k_bgz
 #endif
     if (lane == 0) status[b] = st;
   }
+  if constexpr (BOUNDED) {
+    V3_SYNC();
+    if (lane == 0 && L.bnd_slot != 0xFFFFFFFFu) atomicExch(&slots[L.bnd_slot], 0u);  // (the scratch carries nothing from one owner to the next)
+  }
   if (dbg && lane == 0) {
     atomicAdd(&dbg[0], dbg_rounds);
     atomicAdd(&dbg[1], dbg_passes);
@@ -1226,18 +1280,32 @@ void v3_guard_report() {
 int v3_resident_wg_per_cu() {
   int n = 0;
   // resident WAVES per CU (= members decoded concurrently per CU)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v3, WAVE * V3_WAVES_PER_WG, 0) != hipSuccess || n < 1) n = 8;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v3<V3_WAVES_PER_WG, false>, WAVE * V3_WAVES_PER_WG, 0) != hipSuccess || n < 1) n = 8;
   return n * V3_WAVES_PER_WG;
 }
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
-                            uint32_t grid, uint32_t* dbg, hipStream_t st) {
+                            uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots, uint32_t n_slots, uint32_t per_wave, uint32_t wpw) {
   if (!n_blocks) return;
+  if (wpw != 1) wpw = V3_BOUNDED_WPW;
   (void)hipMemsetAsync(counter, 0, 4, st);
-  uint32_t g = grid < n_blocks ? grid : n_blocks;
-  g = (g + V3_WAVES_PER_WG - 1) / V3_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V3_WAVES_PER_WG strides
-  hipLaunchKernelGGL(k_bgzf_inflate_v3, dim3(g), dim3(WAVE * V3_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks, status, counter,
-                     scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg);
+  if (slots) {
+    // bounded: workgroups of `wpw` waves, `per_wave` members each; scratch strides handed out through `slots`
+    if (!per_wave) per_wave = 1;
+    const uint32_t per_wg = wpw * per_wave;
+    const uint32_t g = (n_blocks + per_wg - 1) / per_wg;
+    if (wpw == 1)
+      hipLaunchKernelGGL((k_bgzf_inflate_v3<1, true>), dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave);
+    else
+      hipLaunchKernelGGL((k_bgzf_inflate_v3<V3_BOUNDED_WPW, true>), dim3(g), dim3(WAVE * V3_BOUNDED_WPW), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave);
+  } else {
+    uint32_t g = grid < n_blocks ? grid : n_blocks;
+    g = (g + V3_WAVES_PER_WG - 1) / V3_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V3_WAVES_PER_WG strides
+    hipLaunchKernelGGL((k_bgzf_inflate_v3<V3_WAVES_PER_WG, false>), dim3(g), dim3(WAVE * V3_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                       status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, nullptr, 0u, 0u);
+  }
 #ifdef V3_GUARD
   v3_guard_report();
 #endif

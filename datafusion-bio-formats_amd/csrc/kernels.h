@@ -28,7 +28,8 @@ constexpr uint32_t V3_SCRATCH_STRIDE = V3_ML_ENTRIES + V3_CK_DWORDS / 2;
 int v3_resident_wg_per_cu();
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
-                            uint32_t grid, uint32_t* dbg, hipStream_t st);
+                            uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots = nullptr, uint32_t n_slots = 0,
+                            uint32_t per_wave = 0, uint32_t wpw = 0);
 // K2: CRC32 of each inflated block vs the BGZF trailer (validation mode).
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
                        const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
