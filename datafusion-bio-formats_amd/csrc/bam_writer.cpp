@@ -176,10 +176,42 @@ static void up_var(const ArrowArray* a, DevCol* d, hipStream_t st) {
   d->values.alloc(bytes + 16);
   if (bytes) HIP_CHECK(hipMemcpyAsync(d->values.p, a->buffers[2], bytes, hipMemcpyHostToDevice, st));
 }
-static void up_fixed(const ArrowArray* a, DevCol* d, hipStream_t st) {
-  const size_t bytes = (size_t)(a->offset + a->length) * 4;
+// The core columns are uploaded REBASED: rows [eff, eff + n) of the Arrow array (eff = the array's own offset + the offset of
+// the struct array the batch came as) become rows [0, n) on the device, so columns sliced differently -- and sliced
+// batches -- need nothing from the kernels.  A validity bitmap whose first bit is not at a byte boundary is repacked on the
+// host; `keep` owns such staging blocks until the batch's copies have been waited for.
+static const uint8_t* up_valid_at(const ArrowArray* a, int64_t eff, int64_t n, DevCol* d, std::vector<std::vector<uint8_t>>* keep, hipStream_t st) {
+  if (a->null_count == 0 || !a->buffers[0]) return nullptr;
+  const uint8_t* v = (const uint8_t*)a->buffers[0];
+  const size_t bytes = (size_t)((n + 7) / 8);
+  d->valid.alloc(bytes + 1);
+  if ((eff & 7) == 0) {
+    HIP_CHECK(hipMemcpyAsync(d->valid.p, v + (eff >> 3), bytes, hipMemcpyHostToDevice, st));
+  } else {
+    keep->emplace_back(bytes + 1, 0);
+    std::vector<uint8_t>& t = keep->back();
+    const int sh = (int)(eff & 7);
+    const size_t b0 = (size_t)(eff >> 3), last = (size_t)((eff + n - 1) >> 3);
+    for (size_t k = 0; k < bytes; k++) {
+      const uint32_t lo = v[b0 + k], hi = b0 + k + 1 <= last ? v[b0 + k + 1] : 0u;
+      t[k] = (uint8_t)((lo >> sh) | (hi << (8 - sh)));
+    }
+    HIP_CHECK(hipMemcpyAsync(d->valid.p, t.data(), bytes, hipMemcpyHostToDevice, st));
+  }
+  return d->valid.p;
+}
+static void up_var_at(const ArrowArray* a, int64_t eff, int64_t n, DevCol* d, hipStream_t st) {
+  const int32_t* off = (const int32_t*)a->buffers[1] + eff;   // the offsets stay absolute: the value bytes are uploaded from byte 0
+  d->off.alloc((size_t)n + 1);
+  HIP_CHECK(hipMemcpyAsync(d->off.p, off, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
+  const size_t bytes = (size_t)off[n];
+  d->values.alloc(bytes + 16);
+  if (bytes) HIP_CHECK(hipMemcpyAsync(d->values.p, a->buffers[2], bytes, hipMemcpyHostToDevice, st));
+}
+static void up_fixed_at(const ArrowArray* a, int64_t eff, int64_t n, DevCol* d, hipStream_t st) {
+  const size_t bytes = (size_t)n * 4;
   d->values.alloc(bytes + 4);
-  if (bytes) HIP_CHECK(hipMemcpyAsync(d->values.p, a->buffers[1], bytes, hipMemcpyHostToDevice, st));
+  if (bytes) HIP_CHECK(hipMemcpyAsync(d->values.p, (const uint8_t*)a->buffers[1] + (size_t)eff * 4, bytes, hipMemcpyHostToDevice, st));
 }
 
 // ---- tag columns ---------------------------------------------------------------------------------------------------
@@ -288,12 +320,13 @@ struct TagPlan {            // one tag column: what the device needs + what the 
   const ArrowSchema* f = nullptr;
   DevCol dev;
   DevBuf<uint8_t> evalid;
+  int64_t row0 = 0;   // index of the batch's row 0 in the column (its own offset + the struct array's)
 };
 [[noreturn]] static void throw_tag_err(const std::vector<std::unique_ptr<TagPlan>>& plans, unsigned long long key) {
   const int64_t row = (int64_t)(key >> 16);
   const uint32_t ci = (uint32_t)((key >> 8) & 0xFFu), code = (uint32_t)(key & 0xFFu);
   const TagPlan& t = *plans.at(ci);
-  const int64_t j = row + t.a->offset;
+  const int64_t j = row + t.row0;
   auto str_at = [&]() {
     const int32_t* off = (const int32_t*)t.a->buffers[1];
     return std::string((const char*)t.a->buffers[2] + off[j], (size_t)(off[j + 1] - off[j]));
@@ -337,6 +370,224 @@ static void throw_ser_err(uint32_t e) {
 
 }  // namespace
 
+// ---- SAM header from Arrow schema metadata (bio-format-bam/src/header_builder.rs:42-195) -------------------------------
+// A reader for the JSON the provider writes into schema metadata (arrays of flat objects: strings, numbers, null, and one
+// nested string map "other_fields"; serde's output for ReferenceSequenceMetadata / ReadGroupMetadata / ProgramMetadata,
+// bio-format-core/src/metadata.rs:249-300).  Anything that does not parse makes the key count as absent, like
+// from_json_string returning None.
+struct JVal {
+  enum Kind { NUL, STR, NUM, OBJ, ARR, BOOL } kind = NUL;
+  std::string s;                                       // STR: the text; NUM: the literal
+  std::vector<std::pair<std::string, JVal>> obj;       // OBJ, in document order
+  std::vector<JVal> arr;
+  const JVal* get(const char* k) const {
+    for (auto& kv : obj) if (kv.first == k) return &kv.second;
+    return nullptr;
+  }
+};
+struct JParser {
+  const char* p; const char* e; bool ok = true;
+  void ws() { while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+  static void put_utf8(std::string& o, uint32_t c) {
+    if (c < 0x80) o.push_back((char)c);
+    else if (c < 0x800) { o.push_back((char)(0xC0 | (c >> 6))); o.push_back((char)(0x80 | (c & 63))); }
+    else if (c < 0x10000) { o.push_back((char)(0xE0 | (c >> 12))); o.push_back((char)(0x80 | ((c >> 6) & 63))); o.push_back((char)(0x80 | (c & 63))); }
+    else { o.push_back((char)(0xF0 | (c >> 18))); o.push_back((char)(0x80 | ((c >> 12) & 63))); o.push_back((char)(0x80 | ((c >> 6) & 63))); o.push_back((char)(0x80 | (c & 63))); }
+  }
+  bool hex4(uint32_t* v) {
+    if (e - p < 4) return false;
+    uint32_t x = 0;
+    for (int i = 0; i < 4; i++) {
+      const char c = p[i];
+      x <<= 4;
+      if (c >= '0' && c <= '9') x |= (uint32_t)(c - '0');
+      else if (c >= 'a' && c <= 'f') x |= (uint32_t)(c - 'a' + 10);
+      else if (c >= 'A' && c <= 'F') x |= (uint32_t)(c - 'A' + 10);
+      else return false;
+    }
+    p += 4; *v = x;
+    return true;
+  }
+  std::string str() {
+    std::string o;
+    if (p >= e || *p != '"') { ok = false; return o; }
+    p++;
+    while (p < e && *p != '"') {
+      if (*p == '\\') {
+        if (++p >= e) { ok = false; return o; }
+        const char c = *p++;
+        switch (c) {
+          case 'n': o.push_back('\n'); break; case 't': o.push_back('\t'); break; case 'r': o.push_back('\r'); break;
+          case 'b': o.push_back('\b'); break; case 'f': o.push_back('\f'); break;
+          case 'u': {
+            uint32_t c1 = 0;
+            if (!hex4(&c1)) { ok = false; return o; }
+            if (c1 >= 0xD800 && c1 < 0xDC00 && e - p >= 6 && p[0] == '\\' && p[1] == 'u') {
+              p += 2;
+              uint32_t c2 = 0;
+              if (!hex4(&c2)) { ok = false; return o; }
+              c1 = 0x10000 + ((c1 - 0xD800) << 10) + (c2 - 0xDC00);
+            }
+            put_utf8(o, c1);
+            break;
+          }
+          default: o.push_back(c);  // \" \\ \/
+        }
+      } else {
+        o.push_back(*p++);
+      }
+    }
+    if (p >= e) { ok = false; return o; }
+    p++;
+    return o;
+  }
+  JVal val(int depth = 0) {
+    JVal v;
+    ws();
+    if (p >= e || depth > 8) { ok = false; return v; }
+    if (*p == '"') { v.kind = JVal::STR; v.s = str(); }
+    else if (*p == '{') {
+      v.kind = JVal::OBJ; p++; ws();
+      if (p < e && *p == '}') { p++; return v; }
+      while (ok) {
+        ws();
+        std::string k = str();
+        ws();
+        if (!ok || p >= e || *p != ':') { ok = false; break; }
+        p++;
+        JVal c = val(depth + 1);
+        v.obj.emplace_back(std::move(k), std::move(c));
+        ws();
+        if (p < e && *p == ',') { p++; continue; }
+        if (p < e && *p == '}') { p++; break; }
+        ok = false;
+      }
+    } else if (*p == '[') {
+      v.kind = JVal::ARR; p++; ws();
+      if (p < e && *p == ']') { p++; return v; }
+      while (ok) {
+        v.arr.push_back(val(depth + 1));
+        ws();
+        if (p < e && *p == ',') { p++; continue; }
+        if (p < e && *p == ']') { p++; break; }
+        ok = false;
+      }
+    } else if (e - p >= 4 && !strncmp(p, "null", 4)) { p += 4; }
+    else if (e - p >= 4 && !strncmp(p, "true", 4)) { p += 4; v.kind = JVal::BOOL; v.s = "true"; }
+    else if (e - p >= 5 && !strncmp(p, "false", 5)) { p += 5; v.kind = JVal::BOOL; v.s = "false"; }
+    else {
+      v.kind = JVal::NUM;
+      while (p < e && (isdigit((unsigned char)*p) || *p == '-' || *p == '+' || *p == '.' || *p == 'e' || *p == 'E')) v.s.push_back(*p++);
+      if (v.s.empty()) ok = false;
+    }
+    return v;
+  }
+};
+static bool parse_json(const std::string& text, JVal* out) {
+  JParser jp{text.data(), text.data() + text.size()};
+  *out = jp.val();
+  jp.ws();
+  return jp.ok && jp.p == jp.e;
+}
+
+struct BuiltHeader {
+  std::string text;
+  std::vector<std::string> ref_names;
+  std::vector<int64_t> ref_lengths;
+};
+// Optional fields of a header line that noodles keeps ("other_fields" whose key is one of the standard tags of that record
+// kind; header_builder.rs:192-250).  serde writes other_fields from a HashMap, so their order in the reference is that
+// map's iteration order -- unspecified; here they follow in key order.
+static void append_other(std::string& line, const JVal* other, const char* const* allowed) {
+  if (!other || other->kind != JVal::OBJ) return;
+  std::vector<std::pair<std::string, std::string>> kv;
+  for (auto& f : other->obj) {
+    bool ok = false;
+    for (const char* const* a = allowed; *a; a++) ok = ok || f.first == *a;
+    if (ok && f.second.kind == JVal::STR) kv.emplace_back(f.first, f.second.s);
+  }
+  std::sort(kv.begin(), kv.end());
+  for (auto& f : kv) line += "\t" + f.first + ":" + f.second;
+}
+static BuiltHeader build_bam_header(const std::unordered_map<std::string, std::string>& md) {
+  BuiltHeader h;
+  auto get = [&](const char* k) -> const std::string* { auto it = md.find(k); return it == md.end() ? nullptr : &it->second; };
+  // @HD: VN from bio.bam.file_format_version when it parses as major.minor, else 1.6; SO / GO / SS when present
+  std::string vn = "1.6";
+  if (const std::string* v = get("bio.bam.file_format_version")) {
+    const size_t dot = v->find('.');
+    auto digits = [](const std::string& t) { return !t.empty() && t.find_first_not_of("0123456789") == std::string::npos; };
+    if (dot != std::string::npos && digits(v->substr(0, dot)) && digits(v->substr(dot + 1)))
+      vn = std::to_string(strtoul(v->substr(0, dot).c_str(), nullptr, 10)) + "." + std::to_string(strtoul(v->substr(dot + 1).c_str(), nullptr, 10));
+  }
+  h.text = "@HD\tVN:" + vn;
+  if (const std::string* v = get("bio.bam.sort_order")) h.text += "\tSO:" + *v;
+  if (const std::string* v = get("bio.bam.group_order")) h.text += "\tGO:" + *v;
+  if (const std::string* v = get("bio.bam.subsort_order")) h.text += "\tSS:" + *v;
+  h.text += "\n";
+  JVal j;
+  if (const std::string* v = get("bio.bam.reference_sequences"); v && parse_json(*v, &j) && j.kind == JVal::ARR) {
+    bool shape = true;
+    for (auto& r : j.arr) {
+      const JVal* nm = r.get("name"); const JVal* ln = r.get("length");
+      shape = shape && r.kind == JVal::OBJ && nm && nm->kind == JVal::STR && ln && ln->kind == JVal::NUM && ln->s.find_first_not_of("0123456789") == std::string::npos;
+    }
+    if (shape) {
+      static const char* const SQ[] = {"AH", "AN", "AS", "DS", "M5", "SP", "TP", "UR", nullptr};
+      for (auto& r : j.arr) {
+        const unsigned long long len = strtoull(r.get("length")->s.c_str(), nullptr, 10);
+        if (len == 0) throw Error("Reference sequence length cannot be zero");
+        std::string line = "@SQ\tSN:" + r.get("name")->s + "\tLN:" + std::to_string(len);
+        append_other(line, r.get("other_fields"), SQ);
+        h.text += line + "\n";
+        h.ref_names.push_back(r.get("name")->s);
+        h.ref_lengths.push_back((int64_t)len);
+      }
+    }
+  }
+  auto opt = [](const JVal& r, const char* k) -> const std::string* {
+    const JVal* v = r.get(k);
+    return v && v->kind == JVal::STR ? &v->s : nullptr;
+  };
+  if (const std::string* v = get("bio.bam.read_groups"); v && parse_json(*v, &j) && j.kind == JVal::ARR) {
+    bool shape = true;
+    for (auto& r : j.arr) shape = shape && r.kind == JVal::OBJ && opt(r, "id");
+    if (shape) {
+      static const char* const RG[] = {"BC", "CN", "DT", "FO", "KS", "PG", "PI", "PM", "PU", nullptr};
+      for (auto& r : j.arr) {
+        std::string line = "@RG\tID:" + *opt(r, "id");
+        if (auto x = opt(r, "sample")) line += "\tSM:" + *x;
+        if (auto x = opt(r, "platform")) line += "\tPL:" + *x;
+        if (auto x = opt(r, "library")) line += "\tLB:" + *x;
+        if (auto x = opt(r, "description")) line += "\tDS:" + *x;
+        append_other(line, r.get("other_fields"), RG);
+        h.text += line + "\n";
+      }
+    }
+  }
+  if (const std::string* v = get("bio.bam.program_info"); v && parse_json(*v, &j) && j.kind == JVal::ARR) {
+    bool shape = true;
+    for (auto& r : j.arr) shape = shape && r.kind == JVal::OBJ && opt(r, "id");
+    if (shape) {
+      static const char* const PG[] = {"PP", "DS", nullptr};
+      for (auto& r : j.arr) {
+        std::string line = "@PG\tID:" + *opt(r, "id");
+        if (auto x = opt(r, "name")) line += "\tPN:" + *x;
+        if (auto x = opt(r, "version")) line += "\tVN:" + *x;
+        if (auto x = opt(r, "command_line")) line += "\tCL:" + *x;
+        append_other(line, r.get("other_fields"), PG);
+        h.text += line + "\n";
+      }
+    }
+  }
+  if (const std::string* v = get("bio.bam.comments"); v && parse_json(*v, &j) && j.kind == JVal::ARR) {
+    bool shape = true;
+    for (auto& c : j.arr) shape = shape && c.kind == JVal::STR;
+    if (shape) for (auto& c : j.arr) h.text += "@CO\t" + c.s + "\n";
+  }
+  return h;
+}
+
 struct bioscan_bam_writer { Writer w; };
 
 #define W_BEGIN try {
@@ -353,6 +604,15 @@ extern "C" {
 int bioscan_bam_writer_open(const char* path, const char* header_text, const char* const* ref_names, const int64_t* ref_lengths,
                             int32_t n_ref, int32_t coordinate_system_zero_based, int32_t device_id, bioscan_bam_writer** out) {
   W_BEGIN
+  {
+    // BamCompressionType::from_path (bio-format-bam/src/writer.rs:27-43): a path ending in .sam selects the plain SAM text
+    // writer in the reference.  This library writes BGZF BAM only (SAM text is not on the scan path) and
+    // says so instead of writing BAM bytes into a .sam file.
+    std::string low = path ? path : "";
+    for (auto& ch : low) ch = (char)tolower((unsigned char)ch);
+    if (low.size() >= 4 && low.compare(low.size() - 4, 4, ".sam") == 0)
+      throw Error("Failed to create output file: '.sam' selects the plain SAM text writer, which this library does not provide (BGZF BAM only): " + std::string(path));
+  }
   char nm[8];
   if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(bioscan_last_error());
   std::unique_ptr<bioscan_bam_writer> bw(new bioscan_bam_writer);
@@ -383,13 +643,51 @@ int bioscan_bam_writer_open(const char* path, const char* header_text, const cha
   W_END
 }
 
+// schema-level metadata of the struct schema a RecordBatch is exported as, with the overrides of insert_into applied
+static std::unordered_map<std::string, std::string> effective_metadata(const struct ArrowSchema* schema, int32_t sort_on_write) {
+  auto md = field_metadata(schema);
+  // table_provider.rs:1156-1164: the provider's sort_on_write flag decides @HD SO, whatever the schema says
+  if (sort_on_write >= 0) md["bio.bam.sort_order"] = sort_on_write ? "coordinate" : "unsorted";
+  return md;
+}
+
+int bioscan_bam_header_from_schema(const struct ArrowSchema* schema, int32_t sort_on_write, char** header_text) {
+  W_BEGIN
+  const BuiltHeader h = build_bam_header(effective_metadata(schema, sort_on_write));
+  char* o = (char*)malloc(h.text.size() + 1);
+  if (!o) throw Error("out of host memory");
+  memcpy(o, h.text.c_str(), h.text.size() + 1);
+  *header_text = o;
+  W_END
+}
+
+int bioscan_bam_writer_open_schema(const char* path, const struct ArrowSchema* schema, int32_t sort_on_write, int32_t device_id,
+                                   bioscan_bam_writer** out) {
+  W_BEGIN
+  const auto md = effective_metadata(schema, sort_on_write);
+  const BuiltHeader h = build_bam_header(md);
+  // table_provider.rs:1131-1135: the coordinate system of the rows is the schema's, 0-based when it does not say
+  bool zero_based = true;
+  if (auto it = md.find("bio.coordinate_system_zero_based"); it != md.end()) {
+    if (it->second == "true") zero_based = true;
+    else if (it->second == "false") zero_based = false;
+  }
+  std::vector<const char*> names;
+  for (auto& n : h.ref_names) names.push_back(n.c_str());
+  if (names.empty()) names.push_back("");
+  if (bioscan_bam_writer_open(path, h.text.c_str(), names.data(), h.ref_lengths.empty() ? nullptr : h.ref_lengths.data(),
+                              (int32_t)h.ref_names.size(), zero_based ? 1 : 0, device_id, out))
+    throw Error(bioscan_last_error());
+  W_END
+}
+
 int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* batch, const struct ArrowSchema* schema) {
   W_BEGIN
   Writer& w = bw->w;
   if (w.finished) throw Error("BAM writer is finished");
   const int64_t n = batch->length;
   if (n == 0) return 0;
-  if (batch->offset != 0) throw Error("Failed to write BAM records: sliced struct arrays are not supported");
+  const int64_t boff = batch->offset;   // a sliced struct array: its offset adds to every child's own
   hipStream_t st = w.comp->st;
   HIP_CHECK(hipSetDevice(w.comp->device));
   const Col name = find_col(batch, schema, "name", true), chrom = find_col(batch, schema, "chrom", true),
@@ -408,19 +706,19 @@ int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* ba
   if (!cigar_binary && cigar.format != "u") throw Error("Column 'cigar' must be String or Binary type");
   const ArrowArray* all[] = {name.a, chrom.a, start.a, flags.a, cigar.a, mapq.a, mchrom.a, mstart.a, seq.a, qual.a, tlen.a};
   for (auto* a : all)
-    if (a->length != n || a->offset != name.a->offset) throw Error("Failed to write BAM records: columns differ in length or offset");
+    if (a->length < boff + n) throw Error("Failed to write BAM records: columns differ in length");
   // chrom / mate_chrom -> reference ids (sam_record_serializer.rs:145-151, 176-186)
   std::vector<int32_t> refid((size_t)n), mrefid((size_t)n);
   {
-    auto is_valid = [](const ArrowArray* a, int64_t i) {
+    auto is_valid = [boff](const ArrowArray* a, int64_t i) {
       const uint8_t* v = (const uint8_t*)a->buffers[0];
-      const int64_t j = i + a->offset;
+      const int64_t j = i + a->offset + boff;
       return a->null_count == 0 || !v || ((v[j >> 3] >> (j & 7)) & 1);
     };
-    auto str_at = [](const ArrowArray* a, int64_t i) {
+    auto str_at = [boff](const ArrowArray* a, int64_t i) {
       const int32_t* off = (const int32_t*)a->buffers[1];
       const char* d = (const char*)a->buffers[2];
-      const int64_t j = i + a->offset;
+      const int64_t j = i + a->offset + boff;
       return std::string(d + off[j], (size_t)(off[j + 1] - off[j]));
     };
     std::string last_c, last_m;
@@ -447,18 +745,20 @@ int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* ba
   DevCol d_name, d_cigar, d_seq, d_qual, d_start, d_flags, d_mapq, d_mstart, d_tlen;
   DevBuf<int32_t> d_refid((size_t)n), d_mrefid((size_t)n);
   SerCols c{};
-  c.offset = name.a->offset;
+  c.offset = 0;   // (rebased uploads, see up_valid_at)
   c.zero_based = w.zero_based ? 1 : 0;
   c.cigar_binary = cigar_binary ? 1 : 0;
-  c.name_valid = up_valid(name.a, &d_name, st); up_var(name.a, &d_name, st); c.name_off = d_name.off.p; c.name = d_name.values.p;
-  up_var(cigar.a, &d_cigar, st); c.cigar_off = d_cigar.off.p; c.cigar = d_cigar.values.p;
-  up_var(seq.a, &d_seq, st); c.seq_off = d_seq.off.p; c.seq = d_seq.values.p;
-  up_var(qual.a, &d_qual, st); c.qual_off = d_qual.off.p; c.qual = d_qual.values.p;
-  c.start_valid = up_valid(start.a, &d_start, st); up_fixed(start.a, &d_start, st); c.start = (const uint32_t*)d_start.values.p;
-  up_fixed(flags.a, &d_flags, st); c.flags = (const uint32_t*)d_flags.values.p;
-  up_fixed(mapq.a, &d_mapq, st); c.mapq = (const uint32_t*)d_mapq.values.p;
-  c.mate_start_valid = up_valid(mstart.a, &d_mstart, st); up_fixed(mstart.a, &d_mstart, st); c.mate_start = (const uint32_t*)d_mstart.values.p;
-  up_fixed(tlen.a, &d_tlen, st); c.tlen = (const int32_t*)d_tlen.values.p;
+  std::vector<std::vector<uint8_t>> keep;
+  auto eff = [boff](const ArrowArray* a) { return a->offset + boff; };
+  c.name_valid = up_valid_at(name.a, eff(name.a), n, &d_name, &keep, st); up_var_at(name.a, eff(name.a), n, &d_name, st); c.name_off = d_name.off.p; c.name = d_name.values.p;
+  up_var_at(cigar.a, eff(cigar.a), n, &d_cigar, st); c.cigar_off = d_cigar.off.p; c.cigar = d_cigar.values.p;
+  up_var_at(seq.a, eff(seq.a), n, &d_seq, st); c.seq_off = d_seq.off.p; c.seq = d_seq.values.p;
+  up_var_at(qual.a, eff(qual.a), n, &d_qual, st); c.qual_off = d_qual.off.p; c.qual = d_qual.values.p;
+  c.start_valid = up_valid_at(start.a, eff(start.a), n, &d_start, &keep, st); up_fixed_at(start.a, eff(start.a), n, &d_start, st); c.start = (const uint32_t*)d_start.values.p;
+  up_fixed_at(flags.a, eff(flags.a), n, &d_flags, st); c.flags = (const uint32_t*)d_flags.values.p;
+  up_fixed_at(mapq.a, eff(mapq.a), n, &d_mapq, st); c.mapq = (const uint32_t*)d_mapq.values.p;
+  c.mate_start_valid = up_valid_at(mstart.a, eff(mstart.a), n, &d_mstart, &keep, st); up_fixed_at(mstart.a, eff(mstart.a), n, &d_mstart, st); c.mate_start = (const uint32_t*)d_mstart.values.p;
+  up_fixed_at(tlen.a, eff(tlen.a), n, &d_tlen, st); c.tlen = (const int32_t*)d_tlen.values.p;
   HIP_CHECK(hipMemcpyAsync(d_refid.p, refid.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(d_mrefid.p, mrefid.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   c.refid = d_refid.p; c.mate_refid = d_mrefid.p;
@@ -471,7 +771,7 @@ int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* ba
     if (!md.count("bio.bam.tag.tag")) continue;
     const std::string tname = f->name ? f->name : "";
     const ArrowArray* a = batch->children[ci];
-    if (a->length != n) throw Error("Failed to write BAM records: columns differ in length or offset");
+    if (a->length < boff + n) throw Error("Failed to write BAM records: columns differ in length");
     if (a->null_count == a->length && a->length > 0) continue;   // nothing to write; the reference never looks at the type
     if (tname.size() != 2) continue;                             // sam_tag_io.rs:135-138
     std::string spec = "Z";
@@ -498,7 +798,7 @@ int bioscan_bam_writer_write(bioscan_bam_writer* bw, const struct ArrowArray* ba
     std::unique_ptr<TagPlan> t(new TagPlan);
     t->a = a; t->f = f;
     t->d.tag[0] = (uint8_t)tname[0]; t->d.tag[1] = (uint8_t)tname[1];
-    t->d.kind = kind; t->d.offset = a->offset;
+    t->d.kind = kind; t->d.offset = a->offset + boff; t->row0 = a->offset + boff;
     if (strchr("icsCSI", sam_type)) {
       if (!kind_is_int(kind)) throw Error("Tag value type mismatch for integer: " + tn);
     } else if (sam_type == 'f') {

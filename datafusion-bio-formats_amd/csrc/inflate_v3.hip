@@ -39,9 +39,6 @@ namespace bioscan {
 #ifndef V3_CK_STEPS
 #define V3_CK_STEPS 24        // decode steps between two checkpoints = longest segment of the write phase
 #endif
-#ifndef V3_CK_MAX
-#define V3_CK_MAX 24          // checkpoints per lane and pass; a pass that needs more restarts its round with short sub-streams
-#endif
 #ifndef V3_FIRST_BLOCK_BITS
 #define V3_FIRST_BLOCK_BITS (12u * 1024u * 8u)   // size guess for the first block a wave ever sees
 #endif
@@ -116,6 +113,7 @@ struct __attribute__((aligned(16))) V3Lds {
   uint16_t null_slot[7];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v3_pass)
   uint16_t eob_fix;       // bits a lane over-consumed when it followed the end-of-block pointer (see E_EOB)
   uint32_t bnd_slot, bnd_budget;  // bounded launches: the scratch stride this wave borrowed, members it may still take
+  uint32_t blk_final;             // BFINAL of the block being decoded (kept here, not in a register: the kernel is at its SGPR limit)
 #ifdef V3_PAD_LDS
   uint32_t pad_lds[V3_PAD_LDS / 4];  // occupancy experiment only
 #endif
@@ -957,6 +955,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
       ub_refill(in, lane);
       const uint32_t bfinal = ub_take(in, 1);
       const uint32_t btype = ub_take(in, 2);
+      if (lane == 0) L.blk_final = bfinal;
       if (btype == 3) { st = INF_BAD_BTYPE; break; }
       if (btype == 0) {
         ub_take(in, in.bc & 7);
@@ -1093,6 +1092,19 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
         uint64_t want = pred_bits > used + pred_bits / 8 ? pred_bits - used : pred_bits / 8;
         want += want / 16 + 64;
         if (want > rem_bits) want = rem_bits;
+#ifndef V3_NO_EXACT_FINAL
+        // A member's FINAL block ends with its payload (at most 7 bits of padding behind the END-OF-BLOCK), so its length
+        // needs no prediction: the rounds that are left share the remaining bits evenly and the last one ends with the
+        // block.  (A BGZF member is usually one block.  Predicted from the previous member's block, 6 % of slack did not
+        // cover the variation between members: config 2 ran 2.97 rounds per member -- a third, short round whose
+        // sub-streams are too short for their pre-roll -- and one fix pass per round.)
+        if (uni2(L.blk_final)) {
+          const uint32_t round_max = 64u * 32u * (uint32_t)V3_MAX_SUB_DW;   // (a payload is < 2^19 bits)
+          const uint32_t rb = (uint32_t)rem_bits;
+          const uint32_t rounds_left = (rb + round_max - 1u) / round_max;
+          want = rounds_left > 1u ? (rb + rounds_left - 1u) / rounds_left : rb;
+        }
+#endif
         uint32_t sub_dw = (uint32_t)((want + 64ull * 32 - 1) / (64ull * 32));
         if (sub_dw > (uint32_t)V3_MAX_SUB_DW) sub_dw = V3_MAX_SUB_DW;
         if (sub_dw < 5) sub_dw = 5;

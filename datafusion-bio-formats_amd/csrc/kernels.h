@@ -23,7 +23,10 @@ enum InflateStatus : uint32_t {
 // K1 (inflate_v3.hip): long sub-streams, checkpointed count passes, segment mini-rounds.  Per-wave scratch stride in
 // u64: the match list of one mini-round (V3_ML_ENTRIES) followed by the checkpoint rows of one round.
 constexpr uint32_t V3_ML_ENTRIES = 1536;
-constexpr uint32_t V3_CK_DWORDS = 24 * 3 * 64;  // V3_CK_MAX rows x (pos, acc, state) x 64 lanes
+#ifndef V3_CK_MAX
+#define V3_CK_MAX 24          // checkpoints per lane and pass; a pass that needs more restarts its round with short sub-streams
+#endif
+constexpr uint32_t V3_CK_DWORDS = V3_CK_MAX * 3 * 64;  // V3_CK_MAX rows x (pos, acc, state) x 64 lanes
 constexpr uint32_t V3_SCRATCH_STRIDE = V3_ML_ENTRIES + V3_CK_DWORDS / 2;
 int v3_resident_wg_per_cu();
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,

@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
     "bioscan_scan_devices", "bioscan_plan_partition_device", "bioscan_plan_make_resident", "bioscan_provider_resident_range",
     "bioscan_debug_shard_partitions", "bioscan_debug_extract_regions",
-    "bioscan_bam_writer_open", "bioscan_bam_writer_write", "bioscan_bam_writer_finish", "bioscan_bam_writer_close", "bioscan_bgzf_deflate",
+    "bioscan_bam_writer_open", "bioscan_bam_writer_open_schema", "bioscan_bam_header_from_schema", "bioscan_bam_writer_write", "bioscan_bam_writer_finish", "bioscan_bam_writer_close", "bioscan_bgzf_deflate",
 ]
 
 
@@ -147,6 +147,8 @@ def load_library():
     lib.bioscan_provider_resident_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.bioscan_bam_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32,
                                             C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_bam_writer_open_schema.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.bioscan_bam_header_from_schema.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
     lib.bioscan_bam_writer_write.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.bioscan_bam_writer_finish.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.bioscan_bam_writer_close.argtypes = [C.c_void_p]
@@ -696,6 +698,22 @@ class BamWriter:
         _check(lib.bioscan_bam_writer_open(path.encode(), header_text.encode(), names, lens, len(ref_names),
                                            1 if coordinate_system_zero_based else 0, device_id, C.byref(self._h)))
 
+    @classmethod
+    def for_insert(cls, path: str, schema: pa.Schema, sort_on_write: bool = False, device_id: int = 0) -> "BamWriter":
+        """The writer of an INSERT OVERWRITE (BamTableProvider::new_for_write + insert_into, table_provider.rs:639-662,
+        1117-1178): header, @SQ dictionary and coordinate system all come from the Arrow schema's metadata."""
+        lib = load_library()
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        sch = _ArrowSchema()
+        schema._export_to_c(C.addressof(sch))
+        try:
+            _check(lib.bioscan_bam_writer_open_schema(path.encode(), C.addressof(sch), 1 if sort_on_write else 0, device_id, C.byref(self._h)))
+        finally:
+            if sch.release:
+                C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))
+        return self
+
     def write_records(self, batch: pa.RecordBatch):
         arr, sch = _ArrowArray(), _ArrowSchema()
         pa.StructArray.from_arrays(batch.columns, fields=list(batch.schema))._export_to_c(C.addressof(arr), C.addressof(sch))
@@ -718,3 +736,20 @@ class BamWriter:
         if h:
             load_library().bioscan_bam_writer_close(h)
             self._h = None
+
+
+def bam_header_from_schema(schema: pa.Schema, sort_on_write: Optional[bool] = None) -> str:
+    """build_bam_header (bio-format-bam/src/header_builder.rs:42-195) + noodles' SAM header text, from schema metadata.
+    sort_on_write None keeps the schema's own bio.bam.sort_order; True / False apply insert_into's override."""
+    lib = load_library()
+    sch = _ArrowSchema()
+    schema._export_to_c(C.addressof(sch))
+    out = C.c_void_p()
+    try:
+        _check(lib.bioscan_bam_header_from_schema(C.addressof(sch), -1 if sort_on_write is None else (1 if sort_on_write else 0), C.byref(out)))
+        return C.string_at(out).decode()
+    finally:
+        if out:
+            lib.bioscan_free(out)
+        if sch.release:
+            C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))

@@ -250,6 +250,17 @@ int bioscan_execute_device(const bioscan_plan* plan, int32_t partition, int32_t 
 typedef struct bioscan_bam_writer bioscan_bam_writer;
 int bioscan_bam_writer_open(const char* path, const char* header_text, const char* const* ref_names, const int64_t* ref_lengths,
                             int32_t n_ref, int32_t coordinate_system_zero_based, int32_t device_id, bioscan_bam_writer** out);
+/* The writer of an INSERT OVERWRITE (TableProvider::insert_into + BamWriteExec, bio-format-bam/src/table_provider.rs:1117-1178,
+ * write_exec.rs:72-170, 281-336): everything comes from the Arrow schema of the rows -- the SAM header from its "bio.bam.*"
+ * metadata (build_bam_header, bio-format-bam/src/header_builder.rs:42-195: @HD VN default 1.6, SO / GO / SS, @SQ / @RG / @PG
+ * from their JSON arrays, @CO), the coordinate system from "bio.coordinate_system_zero_based" (0-based when absent).
+ * sort_on_write: 1 -> @HD SO:coordinate, 0 -> SO:unsorted (the provider's override of the schema's value; the sort itself is
+ * DataFusion's SortExec above the write plan), -1 -> the schema's own value.  A path ending in ".sam" selects the plain SAM
+ * writer in the reference (BamCompressionType::from_path, writer.rs:27-43) and is refused here.
+ * bioscan_bam_header_from_schema returns the header text alone (malloc'd, bioscan_free). */
+int bioscan_bam_writer_open_schema(const char* path, const struct ArrowSchema* schema, int32_t sort_on_write, int32_t device_id,
+                                   bioscan_bam_writer** out);
+int bioscan_bam_header_from_schema(const struct ArrowSchema* schema, int32_t sort_on_write, char** header_text);
 int bioscan_bam_writer_write(bioscan_bam_writer* w, const struct ArrowArray* batch, const struct ArrowSchema* schema);
 int bioscan_bam_writer_finish(bioscan_bam_writer* w, uint64_t* n_records, uint64_t* n_members, uint64_t* n_bytes);
 void bioscan_bam_writer_close(bioscan_bam_writer* w);

@@ -1102,6 +1102,67 @@ def evaluate_record_filters(fields: dict, filters, string_fields=("chrom",),
 
 # =======================================================================================
 # Table provider / exec mirror (names follow the reference)
+def build_bam_header(metadata: dict, sort_on_write=None) -> str:
+    """bio-format-bam/src/header_builder.rs:42-195 (build_bam_header) + the text noodles-sam's header writer produces for it,
+    with the sort-order override of insert_into (table_provider.rs:1156-1164) when sort_on_write is True / False.
+    `metadata`: the Arrow schema's metadata as str -> str.  Optional fields kept from other_fields: the standard tags
+    header_builder.rs:192-250 maps; serde emits other_fields from a HashMap (unspecified order), here in key order."""
+    md = dict(metadata)
+    if sort_on_write is not None:
+        md["bio.bam.sort_order"] = "coordinate" if sort_on_write else "unsorted"
+    vn = "1.6"
+    v = md.get("bio.bam.file_format_version")
+    if v is not None:
+        a, dot, b = v.partition(".")
+        if dot and a.isascii() and b.isascii() and a.isdigit() and b.isdigit():
+            vn = "%d.%d" % (int(a), int(b))
+    out = "@HD\tVN:" + vn
+    for key, tag in (("bio.bam.sort_order", "SO"), ("bio.bam.group_order", "GO"), ("bio.bam.subsort_order", "SS")):
+        if key in md:
+            out += "\t%s:%s" % (tag, md[key])
+    out += "\n"
+
+    def load(key, need):
+        try:
+            j = json.loads(md[key])
+        except (KeyError, ValueError):
+            return None
+        if not isinstance(j, list) or not all(need(r) for r in j):
+            return None
+        return j
+
+    def others(r, allowed):
+        o = r.get("other_fields") if isinstance(r, dict) else None
+        if not isinstance(o, dict):
+            return ""
+        return "".join("\t%s:%s" % (k, o[k]) for k in sorted(o) if k in allowed and isinstance(o[k], str))
+
+    sq = load("bio.bam.reference_sequences", lambda r: isinstance(r, dict) and isinstance(r.get("name"), str)
+              and isinstance(r.get("length"), int) and not isinstance(r.get("length"), bool) and r["length"] >= 0)
+    for r in sq or []:
+        if r["length"] == 0:
+            raise ValueError("Reference sequence length cannot be zero")
+        out += "@SQ\tSN:%s\tLN:%d%s\n" % (r["name"], r["length"], others(r, ("AH", "AN", "AS", "DS", "M5", "SP", "TP", "UR")))
+    rg = load("bio.bam.read_groups", lambda r: isinstance(r, dict) and isinstance(r.get("id"), str))
+    for r in rg or []:
+        line = "@RG\tID:" + r["id"]
+        for k, tag in (("sample", "SM"), ("platform", "PL"), ("library", "LB"), ("description", "DS")):
+            if isinstance(r.get(k), str):
+                line += "\t%s:%s" % (tag, r[k])
+        out += line + others(r, ("BC", "CN", "DT", "FO", "KS", "PG", "PI", "PM", "PU")) + "\n"
+    pg = load("bio.bam.program_info", lambda r: isinstance(r, dict) and isinstance(r.get("id"), str))
+    for r in pg or []:
+        line = "@PG\tID:" + r["id"]
+        for k, tag in (("name", "PN"), ("version", "VN"), ("command_line", "CL")):
+            if isinstance(r.get(k), str):
+                line += "\t%s:%s" % (tag, r[k])
+        out += line + others(r, ("PP", "DS")) + "\n"
+    co = load("bio.bam.comments", lambda c: isinstance(c, str))
+    for c in co or []:
+        out += "@CO\t%s\n" % c
+    return out
+
+
 # =======================================================================================
 class BamOracle:
     """Mirror of BamTableProvider::new + scan + BamExec::execute on the CPU."""
