@@ -48,6 +48,8 @@ typedef struct {
 typedef void* (*ld_allocd_t)(void);
 typedef int (*ld_decomp_t)(void*, const void*, size_t, void*, size_t, size_t*);
 typedef void (*ld_freed_t)(void*);
+typedef uint32_t (*ld_crc32_t)(uint32_t, const void*, size_t);
+static ld_crc32_t ld_crc32;   /* libdeflate's CRC32 (what noodles-bgzf's libdeflate backend uses), zlib's otherwise */
 static ld_allocd_t ld_allocd;
 static ld_decomp_t ld_decomp;
 static ld_freed_t ld_freed;
@@ -62,9 +64,13 @@ static void load_libdeflate(void) {
     ld_allocd = (ld_allocd_t)dlsym(h, "libdeflate_alloc_decompressor");
     ld_decomp = (ld_decomp_t)dlsym(h, "libdeflate_deflate_decompress");
     ld_freed = (ld_freed_t)dlsym(h, "libdeflate_free_decompressor");
-    if (ld_allocd && ld_decomp && ld_freed) return;
+    if (ld_allocd && ld_decomp && ld_freed) { ld_crc32 = (ld_crc32_t)dlsym(h, "libdeflate_crc32"); return; }
     ld_allocd = NULL;
   }
+}
+
+static inline uint32_t crc_of(const uint8_t* p, size_t n) {
+  return ld_crc32 ? ld_crc32(0, p, n) : (uint32_t)crc32(crc32(0, NULL, 0), p, (uInt)n);
 }
 
 static double now_s(void) {
@@ -110,7 +116,7 @@ static void* inflate_worker(void* arg) {
       inflateEnd(&zs);
       if ((rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && isize == 0)) || got != isize) { j->err = 1; break; }
     }
-    if ((uint32_t)crc32(crc32(0, NULL, 0), dst, isize) != crc) { j->err = 2; break; }
+    if (crc_of(dst, isize) != crc) { j->err = 2; break; }
   }
   if (d) ld_freed(d);
   return NULL;
@@ -397,6 +403,320 @@ int oracle_bam_scan(const char* path, int zero_based, int threads, uint64_t max_
   fclose(f);
   int rc = got == (size_t)sz ? oracle_bam_scan_mem(d, (uint64_t)sz, zero_based, threads, max_blocks, n_tags, tags, tag_kinds, build_columns, out) : 1;
   free(d);
+  return rc;
+}
+
+/* =================================================================================================
+ * Streaming form of the BAM scan: the shape of the reference's executor, used as the CPU baseline.
+ *
+ * The reference runs one OS thread per partition (bio-format-core/src/sync_stream.rs:19-29); a partition's thread owns a
+ * BGZF reader positioned at a record-aligned virtual offset from the index, inflates ONE member at a time, decodes the
+ * records in it, appends to its own column builders and hands a RecordBatch over every `batch_rows` rows
+ * (bio-format-bam/src/physical_exec.rs:408-573, 857-862) -- nothing is shared between partitions and nothing is as large
+ * as the file.  oracle_bam_scan_mem above materialises whole columns (for parity checks) and pays for that with phases no
+ * partition thread of the reference has: one serial walk of the record chain over the whole inflated file, serial prefix
+ * sums of six offset columns, first-touch of file-sized arrays.  It stopped scaling at 8 threads, which understated the CPU.
+ *
+ * oracle_bam_stream_plan plays the index: it returns, for T partitions of the first `max_blocks` members, the virtual
+ * offset (compressed offset of a member, offset inside its payload) of the first record that starts in each partition's
+ * member range.  It is not timed (an index is built before a scan).  oracle_bam_scan_stream then runs the T partitions.
+ * ================================================================================================= */
+typedef struct {
+  uint64_t n_rows, n_batches, n_blocks, compressed_bytes, inflated_bytes, arrow_bytes;
+  uint64_t col_bytes[12];      /* value bytes per core column (4 x rows for the fixed ones) */
+  uint64_t col_sum[12];        /* sum of all value bytes per core column (order-independent checksum) */
+  uint64_t n_valid[12];        /* non-NULL rows per column */
+  double seconds_total;        /* wall time of the parallel region */
+  double seconds_inflate_avg, seconds_inflate_max;   /* per-thread time in inflate + CRC32 */
+  double seconds_build_avg, seconds_build_max;       /* per-thread time decoding records into builders */
+  int threads, used_libdeflate;
+  char error[256];
+} oracle_stream_result;
+
+int oracle_bam_stream_plan(const uint8_t* file, uint64_t file_len, uint64_t max_blocks, int threads, uint64_t* start_coff,
+                           uint64_t* start_within, uint64_t* n_blocks_out, char* err, int err_cap) {
+  oracle_result r;
+  /* members + record chain through the materialising scan (columns off): untimed planning */
+  if (oracle_bam_scan_mem(file, file_len, 1, threads > 16 ? 16 : threads, max_blocks, 0, "", NULL, 0, &r)) { snprintf(err, (size_t)err_cap, "%s", r.error); return 1; }
+  /* redo the framing + chain here to get at the offsets (cheap next to the inflate above, and untimed) */
+  uint64_t cap = r.n_blocks + 1, nb = 0, o = 0, uo = 0;
+  uint64_t* coff = (uint64_t*)malloc((cap + 1) * 8);
+  uint64_t* uoff = (uint64_t*)malloc((cap + 1) * 8);
+  while (nb < r.n_blocks) {
+    uint32_t xlen = rd16(file + o + 10);
+    int64_t bsize = -1;
+    for (uint64_t p = o + 12; p + 4 <= o + 12 + xlen;) {
+      uint32_t slen = rd16(file + p + 2);
+      if (file[p] == 66 && file[p + 1] == 67 && slen == 2) bsize = (int64_t)rd16(file + p + 4) + 1;
+      p += 4 + slen;
+    }
+    coff[nb] = o; uoff[nb] = uo;
+    uo += rd32(file + o + bsize - 4);
+    o += (uint64_t)bsize;
+    nb++;
+  }
+  coff[nb] = o; uoff[nb] = uo;
+  uint8_t* u = (uint8_t*)malloc(uo + 64);
+  inflate_job ij = {file, coff, uoff, u, 0, nb, 0};
+  inflate_worker(&ij);
+  if (ij.err) { snprintf(err, (size_t)err_cap, "inflate failed"); return 1; }
+  uint64_t p = 8 + (uint64_t)rdi32(u + 4);
+  int n_ref = rdi32(u + p); p += 4;
+  for (int k = 0; k < n_ref; k++) p += 8 + (uint64_t)rdi32(u + p);
+  /* partition t owns members [nb t / T, nb (t + 1) / T): its first record is the first one starting at / after uoff of its first member */
+  int t = 0;
+  uint64_t b = 0;
+  for (t = 0; t < threads; t++) { start_coff[t] = coff[nb]; start_within[t] = 0; }
+  t = 0;
+  while (p + 4 <= uo && t < threads) {
+    const uint64_t lo = uoff[nb * (uint64_t)t / (uint64_t)threads];
+    if (p >= lo) {
+      while (uoff[b + 1] <= p) b++;
+      start_coff[t] = coff[b]; start_within[t] = p - uoff[b];
+      t++;
+      continue;
+    }
+    uint32_t bs = rd32(u + p);
+    if (bs < 32 || p + 4 + bs > uo) break;
+    p += 4 + bs;
+  }
+  *n_blocks_out = nb;
+  free(u); free(coff); free(uoff);
+  oracle_free(&r);
+  return 0;
+}
+
+typedef struct { uint8_t* p; size_t n, cap; } sbuf;
+static inline uint8_t* sb_room(sbuf* g, size_t k) {
+  if (g->n + k > g->cap) { g->cap = (g->n + k) * 2 + 4096; g->p = (uint8_t*)realloc(g->p, g->cap); }
+  uint8_t* d = g->p + g->n;
+  g->n += k;
+  return d;
+}
+typedef struct {
+  const uint8_t* file;
+  uint64_t file_len, c_lo, w_lo, c_hi, w_hi;   /* [start, end) as virtual offsets (member coff, offset in payload) */
+  int zero_based;
+  uint32_t batch_rows;
+  oracle_stream_result acc;                      /* this thread's share */
+  double t_inflate, t_build;
+  int err;
+} stream_job;
+
+/* a batch is handed over: account for its buffers, fold the order-independent checksums, empty the builders for reuse */
+static void stream_hand_over(stream_job* j, sbuf* vdata, sbuf* voff, sbuf* fdata, sbuf* valid, uint32_t rows, uint64_t* arrow_bytes) {
+  static const int VAR[6] = {0, 1, 5, 7, 9, 10}, FIX[6] = {2, 3, 4, 6, 8, 11};
+  for (int c = 0; c < 6; c++) {
+    uint64_t sm = 0;
+    for (size_t k = 0; k < vdata[c].n; k++) sm += vdata[c].p[k];
+    j->acc.col_bytes[VAR[c]] += vdata[c].n; j->acc.col_sum[VAR[c]] += sm;
+    *arrow_bytes += vdata[c].n + ((uint64_t)rows + 1) * 4;
+    vdata[c].n = 0; voff[c].n = 0;
+    sm = 0;
+    for (size_t k = 0; k < fdata[c].n; k++) sm += fdata[c].p[k];
+    j->acc.col_bytes[FIX[c]] += fdata[c].n; j->acc.col_sum[FIX[c]] += sm;
+    *arrow_bytes += fdata[c].n;
+    fdata[c].n = 0;
+  }
+  for (int c = 0; c < 12; c++) {
+    if (valid[c].n) {
+      uint64_t nv = 0;
+      for (size_t k = 0; k < valid[c].n; k++) nv += valid[c].p[k];
+      j->acc.n_valid[c] += nv;
+      *arrow_bytes += (valid[c].n + 7) / 8;
+      valid[c].n = 0;
+    } else {
+      j->acc.n_valid[c] += rows;   /* columns without NULLs */
+    }
+  }
+  j->acc.n_rows += rows;
+  j->acc.n_batches++;
+}
+
+static void* stream_worker(void* arg) {
+  stream_job* j = (stream_job*)arg;
+  static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+  static const char OPS[] = "MIDNSHP=X???????";
+  void* d = ld_allocd ? ld_allocd() : NULL;
+  /* builders of one batch: 6 var-len columns (offsets + bytes), 6 fixed, validity as one byte per row (packed at hand-over) */
+  sbuf vdata[6] = {{0}}, voff[6] = {{0}}, fdata[6] = {{0}}, valid[12] = {{0}};
+  uint32_t rows = 0;
+  size_t ucap = 1 << 18, have = 0;
+  uint8_t* u = (uint8_t*)malloc(ucap);
+  uint64_t pos_c = j->c_lo;
+  size_t off = 0;          /* parse position in u */
+  int first = 1;
+  /* reference names are needed for chrom / mate_chrom: the header is read by partition 0 of the reference's provider at
+     open; here every partition decodes the leading members once (outside its timers would hide real work of nobody: it
+     is part of open, not of the scan) */
+  const char** ref_names = NULL; uint32_t* ref_len = NULL; int n_ref = 0;
+  uint8_t* hdrbuf = NULL;
+  {
+    size_t hcap = 1 << 20, hh = 0;
+    hdrbuf = (uint8_t*)malloc(hcap);
+    uint64_t c = 0;
+    for (;;) {
+      const uint8_t* m = j->file + c;
+      uint32_t xlen = rd16(m + 10);
+      int64_t bsize = -1;
+      for (uint64_t q = 12; q + 4 <= 12 + (uint64_t)xlen;) { uint32_t slen = rd16(m + q + 2); if (m[q] == 66 && m[q + 1] == 67 && slen == 2) bsize = (int64_t)rd16(m + q + 4) + 1; q += 4 + slen; }
+      uint32_t isize = rd32(m + bsize - 4);
+      if (hh + isize > hcap) { hcap = (hh + isize) * 2; hdrbuf = (uint8_t*)realloc(hdrbuf, hcap); }
+      size_t got = 0;
+      if (d) { if (ld_decomp(d, m + 12 + xlen, (size_t)(bsize - 12 - xlen - 8), hdrbuf + hh, isize, &got) != 0) { j->err = 1; return NULL; } }
+      else { uLongf dl = isize; z_stream zs; memset(&zs, 0, sizeof zs); inflateInit2(&zs, -15); zs.next_in = (Bytef*)(m + 12 + xlen); zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = hdrbuf + hh; zs.avail_out = isize; inflate(&zs, Z_FINISH); inflateEnd(&zs); (void)dl; }
+      hh += isize; c += (uint64_t)bsize;
+      if (hh >= 12) {
+        uint64_t q = 8 + (uint64_t)rdi32(hdrbuf + 4);
+        if (q + 4 <= hh) {
+          int nr = rdi32(hdrbuf + q); uint64_t e = q + 4; int ok = 1;
+          for (int k = 0; k < nr; k++) { if (e + 4 > hh) { ok = 0; break; } e += 8 + (uint64_t)rdi32(hdrbuf + e); if (e > hh) { ok = 0; break; } }
+          if (ok) {
+            n_ref = nr; ref_names = (const char**)malloc(sizeof(char*) * (size_t)(nr + 1)); ref_len = (uint32_t*)malloc(4 * (size_t)(nr + 1));
+            e = q + 4;
+            for (int k = 0; k < nr; k++) { int32_t ln = rdi32(hdrbuf + e); ref_names[k] = (const char*)hdrbuf + e + 4; ref_len[k] = (uint32_t)ln - 1; e += 8 + (uint64_t)ln; }
+            break;
+          }
+        }
+      }
+      if (c >= j->file_len) { j->err = 3; return NULL; }
+    }
+  }
+  uint64_t arrow_bytes = 0;
+  uint64_t head_c = j->c_lo, head_w = j->w_lo;   /* virtual offset of the carried (cut) record at u[0] */
+  size_t data_start = 0;                          /* where the current member's payload begins in u */
+  uint64_t cur_c = 0;                             /* compressed offset of the current member */
+  for (;;) {
+    /* ---- next member: needed while a record of this partition is incomplete, or the next member starts before the end ---- */
+    const int pending = off < have;
+    if (!pending && !first && (pos_c > j->c_hi || (pos_c == j->c_hi && j->w_hi == 0))) break;
+    if (first && (pos_c > j->c_hi || (pos_c == j->c_hi && j->w_lo >= j->w_hi))) break;   /* an empty partition */
+    if (pos_c + 28 > j->file_len) break;
+    double t0 = now_s();
+    const uint8_t* m = j->file + pos_c;
+    uint32_t xlen = rd16(m + 10);
+    int64_t bsize = -1;
+    for (uint64_t q = 12; q + 4 <= 12 + (uint64_t)xlen;) { uint32_t slen = rd16(m + q + 2); if (m[q] == 66 && m[q + 1] == 67 && slen == 2) bsize = (int64_t)rd16(m + q + 4) + 1; q += 4 + slen; }
+    if (bsize < 0 || pos_c + (uint64_t)bsize > j->file_len) break;   /* the sample ends inside a member */
+    uint32_t isize = rd32(m + bsize - 4), crc = rd32(m + bsize - 8);
+    /* keep the unparsed tail (a record cut by the member's end) at the front, drop what has been decoded */
+    if (off) {
+      if (off >= data_start) { head_c = cur_c; head_w = off - data_start; }
+      memmove(u, u + off, have - off);
+      have -= off; off = 0;
+    }
+    data_start = have;
+    if (have + isize > ucap) { ucap = (have + isize) * 2; u = (uint8_t*)realloc(u, ucap); }
+    size_t got = 0;
+    if (d) { if (ld_decomp(d, m + 12 + xlen, (size_t)(bsize - 12 - xlen - 8), u + have, isize, &got) != 0 || got != isize) { j->err = 1; break; } }
+    else {
+      z_stream zs; memset(&zs, 0, sizeof zs); inflateInit2(&zs, -15);
+      zs.next_in = (Bytef*)(m + 12 + xlen); zs.avail_in = (uInt)(bsize - 12 - xlen - 8); zs.next_out = u + have; zs.avail_out = isize;
+      int rc = inflate(&zs, Z_FINISH); got = zs.total_out; inflateEnd(&zs);
+      if ((rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && isize == 0)) || got != isize) { j->err = 1; break; }
+    }
+    if (crc_of(u + have, isize) != crc) { j->err = 2; break; }   /* noodles-bgzf checks every block */
+    have += isize;
+    j->acc.n_blocks++; j->acc.compressed_bytes += (uint64_t)bsize; j->acc.inflated_bytes += isize;
+    cur_c = pos_c;
+    pos_c += (uint64_t)bsize;
+    if (first) { off = (size_t)j->w_lo; first = 0; }
+    double t1 = now_s();
+    j->t_inflate += t1 - t0;
+    /* ---- records that are complete in the buffer ---- */
+    int done = 0;
+    while (off + 4 <= have) {
+      /* a record belongs to this partition when it STARTS before the partition's end (virtual offsets) */
+      const uint64_t rc_ = off >= data_start ? cur_c : head_c, rw_ = off >= data_start ? (uint64_t)(off - data_start) : head_w;
+      if (rc_ > j->c_hi || (rc_ == j->c_hi && rw_ >= j->w_hi)) { done = 1; break; }
+      const uint8_t* r = u + off;
+      const uint32_t bs = rd32(r);
+      if (bs < 32) { j->err = 4; done = 1; break; }
+      if (off + 4 + bs > have) break;   /* cut by the member's end: carried */
+      int32_t refid = rdi32(r + 4), pos = rdi32(r + 8);
+      uint32_t lrn = r[12], mapq = r[13], ncig = rd16(r + 16), flag = rd16(r + 18);
+      int32_t lseq = rdi32(r + 20), nref = rdi32(r + 24), npos = rdi32(r + 28), tlen = rdi32(r + 32);
+      const uint8_t* cg = r + 36 + lrn;
+      const uint8_t* sq = cg + 4 * ncig;
+      const uint8_t* ql = sq + (lseq + 1) / 2;
+      if (refid >= n_ref || nref >= n_ref || lseq < 0 || 32u + lrn + 4u * ncig + (uint32_t)((lseq + 1) / 2) + (uint32_t)lseq > bs) { j->err = 5; done = 1; break; }
+      /* name */
+      { const uint32_t n = lrn ? lrn - 1 : 0; memcpy(sb_room(&vdata[0], n), r + 36, n); }
+      /* chrom / mate_chrom */
+      if (refid >= 0) memcpy(sb_room(&vdata[1], ref_len[refid]), ref_names[refid], ref_len[refid]);
+      if (nref >= 0) memcpy(sb_room(&vdata[3], ref_len[nref]), ref_names[nref], ref_len[nref]);
+      /* cigar + reference span */
+      uint32_t span = 0;
+      for (uint32_t k = 0; k < ncig; k++) {
+        uint32_t v = rd32(cg + 4 * k), n = v >> 4, nd = ndigits(n);
+        if ((0x18Du >> (v & 15)) & 1u) span += n;
+        uint8_t* dd = sb_room(&vdata[2], nd + 1);
+        for (int q = (int)nd - 1; q >= 0; q--) { dd[q] = (uint8_t)('0' + n % 10); n /= 10; }
+        dd[nd] = (uint8_t)OPS[v & 15];
+      }
+      /* sequence, qualities */
+      { uint8_t* dd = sb_room(&vdata[4], (size_t)lseq); for (int32_t k = 0; k < lseq; k++) { uint8_t b = sq[k >> 1]; dd[k] = (uint8_t)SEQ[(k & 1) ? (b & 15) : (b >> 4)]; } }
+      {
+        uint8_t* dd = sb_room(&vdata[5], 2 * (size_t)lseq);
+        size_t w = 0;
+        for (int32_t k = 0; k < lseq; k++) {
+          uint32_t ch = ((uint32_t)ql[k] + 33u) & 0xFFu;
+          if (ch < 128u) dd[w++] = (uint8_t)ch;
+          else { dd[w++] = (uint8_t)(0xC0u | (ch >> 6)); dd[w++] = (uint8_t)(0x80u | (ch & 0x3Fu)); }
+        }
+        vdata[5].n -= 2 * (size_t)lseq - w;
+      }
+      for (int c = 0; c < 6; c++) { uint32_t e = (uint32_t)vdata[c].n; memcpy(sb_room(&voff[c], 4), &e, 4); }
+      const uint32_t end1 = pos >= 0 ? (uint32_t)pos + span : 0;
+      const uint32_t fx[6] = {pos >= 0 ? (uint32_t)(j->zero_based ? pos : pos + 1) : 0, end1, flag, mapq,
+                              npos >= 0 ? (uint32_t)(j->zero_based ? npos : npos + 1) : 0, (uint32_t)tlen};
+      for (int c = 0; c < 6; c++) memcpy(sb_room(&fdata[c], 4), &fx[c], 4);
+      *sb_room(&valid[1], 1) = refid >= 0; *sb_room(&valid[2], 1) = pos >= 0; *sb_room(&valid[3], 1) = end1 != 0;
+      *sb_room(&valid[7], 1) = nref >= 0; *sb_room(&valid[8], 1) = npos >= 0;
+      rows++;
+      off += 4 + (size_t)bs;
+      if (rows == j->batch_rows) { stream_hand_over(j, vdata, voff, fdata, valid, rows, &arrow_bytes); rows = 0; }
+    }
+    j->t_build += now_s() - t1;
+    if (done) break;
+  }
+  if (rows) stream_hand_over(j, vdata, voff, fdata, valid, rows, &arrow_bytes);   /* the short last batch */
+  j->acc.arrow_bytes = arrow_bytes;
+  for (int c = 0; c < 6; c++) { free(vdata[c].p); free(voff[c].p); free(fdata[c].p); }
+  for (int c = 0; c < 12; c++) free(valid[c].p);
+  free(u); free(hdrbuf); free(ref_names); free(ref_len);
+  if (d) ld_freed(d);
+  return NULL;
+}
+
+int oracle_bam_scan_stream(const uint8_t* file, uint64_t file_len, int zero_based, int threads, const uint64_t* start_coff,
+                           const uint64_t* start_within, uint64_t end_coff, uint32_t batch_rows, oracle_stream_result* out) {
+  memset(out, 0, sizeof *out);
+  load_libdeflate();
+  out->used_libdeflate = ld_allocd != NULL;
+  out->threads = threads;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  stream_job* sj = (stream_job*)calloc((size_t)threads, sizeof(stream_job));
+  const double t0 = now_s();
+  for (int t = 0; t < threads; t++) {
+    sj[t].file = file; sj[t].file_len = file_len; sj[t].zero_based = zero_based; sj[t].batch_rows = batch_rows ? batch_rows : 8192;
+    sj[t].c_lo = start_coff[t]; sj[t].w_lo = start_within[t];
+    sj[t].c_hi = t + 1 < threads ? start_coff[t + 1] : end_coff; sj[t].w_hi = t + 1 < threads ? start_within[t + 1] : 0;
+    pthread_create(&th[t], NULL, stream_worker, &sj[t]);
+  }
+  for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+  out->seconds_total = now_s() - t0;
+  int rc = 0;
+  for (int t = 0; t < threads; t++) {
+    if (sj[t].err) { snprintf(out->error, sizeof out->error, "partition %d: error %d", t, sj[t].err); rc = 1; }
+    out->n_rows += sj[t].acc.n_rows; out->n_batches += sj[t].acc.n_batches; out->n_blocks += sj[t].acc.n_blocks;
+    out->compressed_bytes += sj[t].acc.compressed_bytes; out->inflated_bytes += sj[t].acc.inflated_bytes; out->arrow_bytes += sj[t].acc.arrow_bytes;
+    for (int c = 0; c < 12; c++) { out->col_bytes[c] += sj[t].acc.col_bytes[c]; out->col_sum[c] += sj[t].acc.col_sum[c]; out->n_valid[c] += sj[t].acc.n_valid[c]; }
+    out->seconds_inflate_avg += sj[t].t_inflate / threads; out->seconds_build_avg += sj[t].t_build / threads;
+    if (sj[t].t_inflate > out->seconds_inflate_max) out->seconds_inflate_max = sj[t].t_inflate;
+    if (sj[t].t_build > out->seconds_build_max) out->seconds_build_max = sj[t].t_build;
+  }
+  free(th); free(sj);
   return rc;
 }
 

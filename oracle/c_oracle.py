@@ -1,6 +1,9 @@
 """ctypes wrapper of oracle/bioscan_oracle.c (TEST INFRASTRUCTURE ONLY -- see that file's header)."""
 import ctypes as C
 import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import pyarrow as pa
 
@@ -66,6 +69,86 @@ def scan(data: bytes, zero_based=True, threads=1, max_blocks=0, tags=(), tag_kin
                 cols[name] = pa.Array.from_buffers(pa.uint32() if kind == "u" else pa.int32(), n, [vb, db])
     lib().oracle_free(C.byref(res))
     return stats, cols
+
+
+class _StreamResult(C.Structure):
+    _fields_ = [("n_rows", C.c_uint64), ("n_batches", C.c_uint64), ("n_blocks", C.c_uint64), ("compressed_bytes", C.c_uint64),
+                ("inflated_bytes", C.c_uint64), ("arrow_bytes", C.c_uint64), ("col_bytes", C.c_uint64 * 12), ("col_sum", C.c_uint64 * 12),
+                ("n_valid", C.c_uint64 * 12), ("seconds_total", C.c_double), ("seconds_inflate_avg", C.c_double),
+                ("seconds_inflate_max", C.c_double), ("seconds_build_avg", C.c_double), ("seconds_build_max", C.c_double),
+                ("threads", C.c_int), ("used_libdeflate", C.c_int), ("error", C.c_char * 256)]
+
+
+def stream_plan(data: bytes, threads: int, max_blocks: int = 0):
+    """The "index" of the streaming baseline: record-aligned virtual offsets of `threads` partitions over the first
+    max_blocks members (untimed).  Returns (start_coff[], start_within[], end_coff, n_blocks)."""
+    L = lib()
+    L.oracle_bam_stream_plan.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
+    sc, sw = (C.c_uint64 * threads)(), (C.c_uint64 * threads)()
+    nb = C.c_uint64()
+    err = C.create_string_buffer(256)
+    if L.oracle_bam_stream_plan(data, len(data), max_blocks, threads, sc, sw, C.byref(nb), err, 256):
+        raise RuntimeError(err.value.decode())
+    # end of the last complete member of the sample
+    import struct
+    o = 0
+    for _ in range(nb.value):
+        o += struct.unpack_from("<H", data, o + 16)[0] + 1
+    return list(sc), list(sw), o, nb.value
+
+
+def stream_plan_bai(data: bytes, bai_bytes: bytes, threads: int, max_blocks: int = 0):
+    """The same plan from the file's BAI, the way the reference gets its partitions' record-aligned starts (every chunk
+    begin and every linear-index entry of a BAI is the virtual offset of a record start): partition t begins at the first
+    indexed record start in or behind member n_blocks * t / threads.  Costs no inflate."""
+    import bisect
+    import struct
+    import bam_oracle
+    coffs, o = [], 0
+    while o + 28 <= len(data) and (max_blocks == 0 or len(coffs) < max_blocks):
+        bs = struct.unpack_from("<H", data, o + 16)[0] + 1
+        if o + bs > len(data):
+            break
+        coffs.append(o)
+        o += bs
+    end_coff, nb = o, len(coffs)
+    bai = bam_oracle.parse_bai(bai_bytes)
+    vo = set()
+    for r in bai.refs:
+        for chunks in r.bins.values():
+            vo.update(c[0] for c in chunks)
+        vo.update(v for v in r.intervals if v)
+    vo = sorted(v for v in vo if (v >> 16) < end_coff)
+    sc, sw = [], []
+    for t in range(threads):
+        lo = coffs[nb * t // threads] << 16 if t else 0
+        k = bisect.bisect_left(vo, lo)
+        v = vo[k] if k < len(vo) else (end_coff << 16)
+        sc.append(v >> 16)
+        sw.append(v & 0xFFFF)
+    return sc, sw, end_coff, nb
+
+
+def stream_scan(data: bytes, plan, zero_based=True, batch_rows=8192) -> dict:
+    """oracle_bam_scan_stream: one thread per partition of `plan`, member by member, per-batch builders (the reference's
+    executor shape).  Returns counts, order-independent column checksums and the per-thread time split."""
+    L = lib()
+    sc, sw, end_coff, _ = plan
+    T = len(sc)
+    L.oracle_bam_scan_stream.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                         C.c_uint64, C.c_uint32, C.POINTER(_StreamResult)]
+    res = _StreamResult()
+    rc = L.oracle_bam_scan_stream(data, end_coff, 1 if zero_based else 0, T, (C.c_uint64 * T)(*sc), (C.c_uint64 * T)(*sw), end_coff,
+                                  batch_rows, C.byref(res))
+    if rc:
+        raise RuntimeError(res.error.decode())
+    out = {k: getattr(res, k) for k, _ in _StreamResult._fields_ if k not in ("col_bytes", "col_sum", "n_valid", "error")}
+    names = [n for n, _, _ in CORE]
+    out["col_bytes"] = dict(zip(names, list(res.col_bytes)))
+    out["col_sum"] = dict(zip(names, list(res.col_sum)))
+    out["n_valid"] = dict(zip(names, list(res.n_valid)))
+    return out
 
 
 class _VcfResult(C.Structure):

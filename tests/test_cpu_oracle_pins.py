@@ -144,3 +144,44 @@ def test_c_oracle_equals_python_oracle(oracle):
                 if pa.types.is_large_string(got.type):
                     got = got.cast(pa.utf8())
                 assert got.equals(t.column(name).combine_chunks()), (f, name)
+
+
+def _col_digest(arr):
+    """(value bytes, sum of value bytes, non-NULL rows) of one column, the order-independent digest the streaming C
+    baseline folds per batch."""
+    arr = arr.combine_chunks() if isinstance(arr, pa.ChunkedArray) else arr
+    n_valid = len(arr) - arr.null_count
+    if pa.types.is_string(arr.type) or pa.types.is_large_string(arr.type):
+        off_t = "q" if pa.types.is_large_string(arr.type) else "i"
+        import struct
+        offs = arr.buffers()[1]
+        w = 8 if off_t == "q" else 4
+        lo = struct.unpack_from("<" + off_t, offs, arr.offset * w)[0]
+        hi = struct.unpack_from("<" + off_t, offs, (arr.offset + len(arr)) * w)[0]
+        data = arr.buffers()[2].to_pybytes()[lo:hi] if arr.buffers()[2] is not None else b""
+        return len(data), sum(data), n_valid
+    data = arr.buffers()[1].to_pybytes()[arr.offset * 4:(arr.offset + len(arr)) * 4]
+    # NULL slots hold 0 in both implementations
+    return len(data), sum(data), n_valid
+
+
+@pytest.mark.parametrize("threads", [1, 2, 3, 7])
+def test_streaming_c_baseline_equals_materialising_oracle(oracle, threads):
+    """oracle_bam_scan_stream (bench.py's cpu_baseline: one thread per partition, member by member, per-batch builders --
+    the reference's executor shape) returns the rows the materialising C oracle and the Python oracle return: same row
+    count, and per column the same value bytes, byte sum and NULL count, for any partition count and batch size."""
+    import sys
+    sys.path.insert(0, os.path.dirname(oracle.__file__))
+    import c_oracle
+    for f in ("multi_chrom.bam", "multi_chrom_large.bam", "nanopore_custom_tags.bam", "no_coor_only.bam", "10x_pbmc_tags.bam"):
+        data = open(os.path.join(G, f), "rb").read()
+        for zb, bs in ((True, 8192), (False, 100), (True, 1)):
+            _, cols = c_oracle.scan(data, zb, 2)
+            plan = c_oracle.stream_plan(data, threads)
+            r = c_oracle.stream_scan(data, plan, zb, bs)
+            n = len(cols["name"])
+            assert r["n_rows"] == n, (f, threads, r["n_rows"], n)
+            assert r["n_batches"] >= (n + bs - 1) // bs and r["n_batches"] <= (n + bs - 1) // bs + threads
+            for name, arr in cols.items():
+                nb, sm, nv = _col_digest(arr)
+                assert (r["col_bytes"][name], r["col_sum"][name], r["n_valid"][name]) == (nb, sm, nv), (f, threads, zb, bs, name)
