@@ -579,6 +579,19 @@ def main():
         except AttributeError:
             nproc = ncpu
         cores = min(16, nproc)  # a one-GPU box's CPU share; the all-cores run of SURVEY 8(d) is threads_sweep[str(nproc)]
+        # the CPU time the box actually grants (cgroup v2 cpu.max / v1 cfs quota): `nproc` may list cores the quota never schedules
+        quota = None
+        for qf, pf in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+            try:
+                if pf is None:
+                    a, b = open(qf).read().split()[:2]
+                    quota = None if a == "max" else round(int(a) / int(b), 2)
+                else:
+                    a, b = int(open(qf).read()), int(open(pf).read())
+                    quota = None if a <= 0 else round(a / b, 2)
+                break
+            except (OSError, ValueError):
+                continue
 
         def leg(threads, blocks):
             blocks = min(blocks, sample_blocks)
@@ -604,7 +617,7 @@ def main():
         st = main_leg
         cpu = {
             "value": round(st["n_rows"] / st["seconds_total"] / 1e6, 3), "unit": "Mrec/s", "cores": cores, "kind": "port",
-            "nproc": nproc, "os_cpu_count": ncpu,
+            "nproc": nproc, "os_cpu_count": ncpu, "cgroup_cpu_quota_cores": quota,
             "sample": f"first {st['n_blocks']} BGZF blocks of the same file ({st['inflated_bytes'] / 1e9:.2f} GB inflated, "
                       f"{st['n_rows']} records), SELECT * core columns in batches of {args.batch_size}, "
                       f"{'libdeflate' if st['used_libdeflate'] else 'zlib'} inflate + CRC32, {cores} threads = {cores} BAI partitions, each streaming "
@@ -614,6 +627,8 @@ def main():
             "seconds_inflate": round(st["seconds_inflate_avg"], 3), "seconds_build": round(st["seconds_build_avg"], 3),
             "seconds_note": "per-thread averages: inflate + CRC32 of the members / record decode into the batch builders; there is no serial phase",
             "parallel_efficiency": round(st["n_rows"] / st["seconds_total"] / cores / rate1, 3),
+            "parallel_efficiency_note": "rate per thread relative to the 1-thread leg; a leg with more threads than cgroup_cpu_quota_cores "
+                                        "(or than the physical cores behind nproc) time-slices and cannot scale -- per-thread seconds grow with the thread count there",
             "threads_sweep": sweep,
         }
 
