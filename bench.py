@@ -310,10 +310,11 @@ def main():
     ap.add_argument("--format", default="bam", choices=["bam", "fastq", "vcf-sites", "vcf-samples"],
                     help="bam (default, BASELINE.json config 2) or fastq (BGZF-FASTQ + GZI full scan: the only scan the "
                          "reference publishes numbers for, openspec/.../design.md:29-36)")
-    ap.add_argument("--partition-threads", type=int, default=1,
+    ap.add_argument("--partition-threads", type=int, default=0,
                     help="indexed mode: partitions of a rank executed concurrently from this many threads, the way DataFusion drives "
-                         "execute(partition); 1 (default) = one after another, which keeps stage_ms and the roofline's launch time "
-                         "free of overlap -- with more threads they are sums of overlapping stream times")
+                         "execute(partition) from its worker pool; 1 = one after another, which keeps stage_ms and the roofline's launch "
+                         "time free of overlap -- with more threads they are sums of overlapping stream times.  0 (default) = 1 at "
+                         "N = 1, min(8, partitions of the rank) at N > 1")
     ap.add_argument("--mode", default=None, choices=["sequential", "indexed", "shards"],
                     help="sequential (default at N = 1): the rank scans its file as one partition. "
                          "indexed (default at N > 1; config 5 / SURVEY 8e): every rank opens the SAME file of --blocks x N members, the "
@@ -341,6 +342,8 @@ def main():
         args.mode = "indexed"   # ONE file, its BAI plan sharded in order over the ranks
     if args.mode is None:
         args.mode = "sequential"
+    if args.partition_threads <= 0:
+        args.partition_threads = 8 if (world > 1 and args.mode == "indexed") else 1
 
     import torch
     import torch.distributed as dist

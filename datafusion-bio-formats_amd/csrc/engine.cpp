@@ -6,8 +6,12 @@
 // decode path in this library: every inflate / record walk / field extract runs on the GPU and
 // the library refuses to open a file when no HIP device is usable.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
+#include <thread>
+#include <deque>
+#include <condition_variable>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -52,28 +56,77 @@ const EnvKnobs& env_knobs() {
   }();
   return k;
 }
+// Cached (idle) device blocks, keyed by (device, size class).  Most sizes of a scan are data dependent (records of a chunk,
+// column totals, selected rows), so blocks are handed out by SIZE CLASS (<= 25 % slack below 64 MiB, <= 6 % above), not by exact
+// size: a partition's buffers are reused by the next partition and the next step although no two sizes repeat.  The cap
+// is per device (BIOSCAN_DEV_POOL_GB, at most 60 % of the device's memory); a block that does not fit evicts the least
+// recently cached blocks of ITS device first, and an allocation the driver refuses gives that device's idle blocks back
+// and is tried again -- other devices' caches, and the executes running on them, are left alone.
 static std::mutex g_pool_mu;
-static std::multimap<std::pair<int, size_t>, void*> g_pool;  // (device, bytes) -> cached block
-static size_t g_pool_bytes = 0;
-static size_t dev_pool_limit() { return (size_t)(env_knobs().dev_pool_gb * (double)(1ull << 30)); }
-constexpr size_t POOL_MIN = 1;  // every block is cached: hipFree of even a tiny block synchronises the device
+struct PoolBlock { void* p; uint64_t seq; };
+static std::multimap<std::pair<int, size_t>, PoolBlock> g_pool;                  // (device, class bytes) -> idle block
+static std::map<int, std::map<uint64_t, std::multimap<std::pair<int, size_t>, PoolBlock>::iterator>> g_pool_lru;  // device -> age order
+static std::map<int, size_t> g_pool_bytes, g_pool_cap;
+static uint64_t g_pool_seq = 0;
 static int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+static size_t dev_class(size_t bytes) {
+  if (bytes <= 256) return 256;
+  const size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));  // highest power of two <= bytes
+  const size_t step = bytes >= ((size_t)64 << 20) ? top >> 4 : top >> 2;
+  return (bytes + step - 1) / step * step;
+}
+static size_t dev_pool_cap(int device) {  // g_pool_mu held
+  auto it = g_pool_cap.find(device);
+  if (it != g_pool_cap.end()) return it->second;
+  size_t cap = (size_t)(env_knobs().dev_pool_gb * (double)(1ull << 30));
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  size_t fr = 0, total = 0;
+  if (hipSetDevice(device) == hipSuccess && hipMemGetInfo(&fr, &total) == hipSuccess && total) cap = std::min(cap, total / 10 * 6);
+  (void)hipSetDevice(prev);
+  g_pool_cap[device] = cap;
+  return cap;
+}
+static void pool_evict_oldest(int device, size_t need_room) {  // g_pool_mu held: frees idle blocks of `device` until `need_room` fits
+  auto& lru = g_pool_lru[device];
+  const size_t cap = dev_pool_cap(device);
+  while (!lru.empty() && g_pool_bytes[device] + need_room > cap) {
+    auto it = lru.begin()->second;
+    g_pool_bytes[device] -= it->first.second;
+    (void)hipFree(it->second.p);  // (waits for the device; only when the cache is over its cap)
+    g_pool.erase(it);
+    lru.erase(lru.begin());
+  }
+}
+static void pool_trim_device(int device) {  // g_pool_mu held
+  auto& lru = g_pool_lru[device];
+  for (auto& kv : lru) { (void)hipFree(kv.second->second.p); g_pool.erase(kv.second); }
+  lru.clear();
+  g_pool_bytes[device] = 0;
+}
 void* dev_pool_alloc(size_t bytes) {
-  if (bytes >= POOL_MIN) {
+  const size_t cls = dev_class(bytes);
+  const int dev = cur_device();
+  {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto it = g_pool.find({cur_device(), bytes});
+    auto it = g_pool.find({dev, cls});
     if (it != g_pool.end()) {
-      void* p = it->second;
+      void* p = it->second.p;
+      g_pool_lru[dev].erase(it->second.seq);
       g_pool.erase(it);
-      g_pool_bytes -= bytes;
+      g_pool_bytes[dev] -= cls;
       return p;
     }
   }
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess && bytes >= POOL_MIN) {  // out of memory: give cached blocks back and retry once
-    dev_pool_trim();
-    e = hipMalloc(&p, bytes);
+  hipError_t e = hipMalloc(&p, cls);
+  if (e != hipSuccess) {  // out of memory: give this device's idle blocks back and retry once
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      pool_trim_device(dev);
+    }
+    e = hipMalloc(&p, cls);
   }
   HIP_CHECK(e);
   return p;
@@ -83,22 +136,26 @@ void dev_pool_free(void* p, size_t bytes, int device) {
   // callbacks and destructors on threads whose current device may be anything.
   // device < 0: released while an exception unwinds -- kernels that read the block may still be in flight, so it goes
   // back to the driver (hipFree waits for the device) instead of into the cache where another stream could pick it up
-  if (bytes >= POOL_MIN && device >= 0) {
+  const size_t cls = dev_class(bytes);
+  if (device >= 0) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool_bytes + bytes <= dev_pool_limit()) {
-      g_pool.emplace(std::make_pair(device, bytes), p);
-      g_pool_bytes += bytes;
+    if (cls <= dev_pool_cap(device)) {
+      pool_evict_oldest(device, cls);
+      auto it = g_pool.emplace(std::make_pair(device, cls), PoolBlock{p, ++g_pool_seq});
+      g_pool_lru[device][it->second.seq] = it;
+      g_pool_bytes[device] += cls;
       return;
     }
   }
-  (void)hipFree(p);  // over the cap (or unwinding): back to the driver
+  (void)hipFree(p);  // larger than the whole cap (or unwinding): back to the driver
 }
 int dev_pool_device() { return cur_device(); }
 void dev_pool_trim() {
   std::lock_guard<std::mutex> lk(g_pool_mu);
-  for (auto& kv : g_pool) (void)hipFree(kv.second);  // hipFree takes a pointer of any device
+  for (auto& kv : g_pool) (void)hipFree(kv.second.p);  // hipFree takes a pointer of any device
   g_pool.clear();
-  g_pool_bytes = 0;
+  g_pool_lru.clear();
+  g_pool_bytes.clear();
 }
 // ---- host block cache ----
 static std::mutex g_hpool_mu;
@@ -305,7 +362,10 @@ struct Column {
   uint64_t total_bytes = 0;   // var: bytes; list: elements
   // host
   HostBuf h_values, h_off32, h_valid;
-  std::vector<uint64_t> h_batch_base;  // per batch: first byte / element
+  HostBuf h_batch_base_buf;            // per batch: first byte / element -- PINNED: a D2H copy into pageable memory blocks the
+                                       // calling thread until everything queued before it on the copy stream is done, which
+                                       // serialised a chunk's kernels behind the previous chunk's whole transfer
+  const uint64_t* h_batch_base = nullptr;
   bool is_var() const { return fd.kind == AK_UTF8 || fd.kind == AK_BINARY; }
   bool is_list() const { return fd.kind >= AK_LIST_INT8; }
   uint32_t list_elem_bytes() const {
@@ -575,8 +635,9 @@ static void start_copy_to_host(Result& res, hipStream_t st, hipStream_t copy_st)
       uint64_t bytes = nb * ((uint64_t)batch_size + 1) * 4;
       col.h_off32.alloc(bytes, true, true);
       HIP_CHECK(hipMemcpyAsync(col.h_off32.p, col.d_off32.p, bytes, hipMemcpyDeviceToHost, copy_st));
-      col.h_batch_base.resize(nb);
-      HIP_CHECK(hipMemcpyAsync(col.h_batch_base.data(), col.d_base.p, nb * 8, hipMemcpyDeviceToHost, copy_st));
+      col.h_batch_base_buf.alloc(std::max<uint64_t>(nb, 1) * 8, true, true);
+      col.h_batch_base = (const uint64_t*)col.h_batch_base_buf.p;
+      HIP_CHECK(hipMemcpyAsync(col.h_batch_base_buf.p, col.d_base.p, nb * 8, hipMemcpyDeviceToHost, copy_st));
     }
     if (col.d_valid.p && n) {
       col.h_valid.alloc(nwords * 8 + 8, true, true);
@@ -681,6 +742,9 @@ struct BamExecState {
     p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(m_hi - m_lo, 1)), la && env_knobs().k1_oneshot != 0);
     if (!la) st = k1.stream;
     else HIP_CHECK(hipStreamSynchronize(k1.stream));  // (the slot flags are zeroed on K1's stream)
+    // (the D2H copies of a chunk are blit kernels on this ROCm -- no SDMA transfer shows in a memory-copy trace -- with a tiny
+    // footprint: they run beside K1's persistent grid at the full link rate; stream priorities and a smaller K1 grid were
+    // measured and change nothing)
     if (to_host) HIP_CHECK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
     d_terms.alloc(std::max<size_t>(terms.size(), 1));
     if (!terms.empty()) HIP_CHECK(hipMemcpyAsync(d_terms.p, terms.data(), terms.size() * sizeof(FilterTerm), hipMemcpyHostToDevice, st));
@@ -875,7 +939,30 @@ struct BamExecState {
     const uint64_t* rows = rec_off.p;
     uint64_t n_rows = n_rec;
     bool stop_item = last;
-    if (w.sel.mode != 0 && n_rec) {
+    if ((w.sel.mode == 1 || w.sel.mode == 3) && n_rec) {
+      // region / no-coor items: one pass over the records decides every region of the decode (no key table)
+      std::vector<RowSelect> sels;
+      sels.push_back(w.sel);
+      for (auto& extra : w.more) sels.push_back(extra);
+      DevBuf<RowSelect> d_sels(sels.size());
+      HIP_CHECK(hipMemcpyAsync(d_sels.p, sels.data(), sels.size() * sizeof(RowSelect), hipMemcpyHostToDevice, st));
+      DevBuf<uint32_t> kerr(1), keep(n_rec);
+      DevBuf<uint64_t> kscan(n_rec + 1), tmp(scan_tmp_elems(n_rec));
+      HIP_CHECK(hipMemsetAsync(kerr.p, 0, 4, st));
+      launch_row_flags_rec(u, rec_off.p, n_rec, d_sels.p, (int)sels.size(), d_terms.p, keep.p, kerr.p, st);
+      launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n_rec, tmp.p, st);
+      uint64_t tsel = 0;
+      uint32_t e8 = 0;
+      HIP_CHECK(hipMemcpyAsync(&tsel, kscan.p + n_rec, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(&e8, kerr.p, 4, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));   // (the staging vector `sels` is done with as well)
+      throw_extract_err(e8);
+      n_rows = tsel;
+      rows_owned.alloc(std::max<uint64_t>(n_rows, 1));
+      if (n_rows) launch_compact_rows(rec_off.p, keep.p, kscan.p, n_rec, rows_owned.p, 0, st);
+      HIP_CHECK(hipStreamSynchronize(st));  // keep / kscan are released at the end of this scope
+      rows = rows_owned.p;
+    } else if (w.sel.mode != 0 && n_rec) {
       DevBuf<int32_t> k_refid(n_rec), k_pos(n_rec), k_end1(n_rec);
       DevBuf<uint32_t> k_fm(n_rec);
       RecKeys rk{k_refid.p, k_pos.p, k_end1.p, k_fm.p};
@@ -1610,21 +1697,77 @@ static void export_pieces(const std::vector<Piece>& pieces, ArrowArray* out) {
 struct Stream {
   Provider* prov = nullptr;
   std::unique_ptr<BamExecState> exec;   // BAM: chunk producer; null for a FASTQ stream (one result) or once exhausted
-  std::shared_ptr<Result> cur, ahead;
-  bool started = false, on_host = true;
+  std::shared_ptr<Result> cur;
+  bool on_host = true;
   uint64_t cur_batch = 0;
   std::vector<Piece> pending;           // whole device batches that do not fill a batch yet
   uint64_t pending_rows = 0;
   std::vector<std::shared_ptr<Result>> device_results;  // execute_device: the chunks stay in HBM until the stream is closed
   bioscan_scan_stats stats{};
+  // The producer runs on its own thread (the reference: one OS thread per partition feeding a bounded channel,
+  // bio-format-core/src/sync_stream.rs:19-29): chunk k + 2 is computed while chunk k + 1 is on the link and chunk k is
+  // being handed out as batches.  Driven from the consumer's calls instead, a chunk's kernels only started once the
+  // consumer came back for more -- after the previous chunk's copy had finished and its batches had been exported -- and
+  // the link idled for the kernels of every chunk (41 of ~55 GB/s on a config-2 stream).
+  static constexpr size_t QUEUE_DEPTH = 2;
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<Result>> ready;
+  bool producer_done = false, stop = false;
+  std::exception_ptr producer_error;
+
+  void start_producer() {
+    worker = std::thread([this] {
+      try {
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [this] { return stop || ready.size() < QUEUE_DEPTH; });
+            if (stop) break;
+          }
+          auto r = exec->next_chunk();   // (kernels + the start of its D2H; returns with the copy in flight)
+          std::lock_guard<std::mutex> lk(mu);
+          if (!r) { producer_done = true; cv.notify_all(); break; }
+          ready.push_back(std::move(r));
+          cv.notify_all();
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        producer_error = std::current_exception();
+        producer_done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  ~Stream() {
+    if (worker.joinable()) {
+      { std::lock_guard<std::mutex> lk(mu); stop = true; }
+      cv.notify_all();
+      worker.join();
+    }
+    // chunks that were never handed out: their copies finish before their buffers go (finish_copy waits for the event)
+    for (auto& r : ready) if (r) { try { finish_copy(*r); } catch (...) {} }
+    ready.clear();
+    cur.reset();
+    pending.clear();
+    exec.reset();
+  }
 
   bool fetch() {
     if (!exec) return false;
-    if (!started) { ahead = exec->next_chunk(); started = true; }
-    if (!ahead) { exec.reset(); return false; }
-    cur = ahead;
+    if (!worker.joinable() && !producer_done) start_producer();
+    std::shared_ptr<Result> r;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this] { return !ready.empty() || producer_done; });
+      if (!ready.empty()) { r = std::move(ready.front()); ready.pop_front(); cv.notify_all(); }
+      else if (producer_error) { auto e = producer_error; producer_error = nullptr; lk.unlock(); std::rethrow_exception(e); }
+    }
+    if (!r) return false;   // end of the partition
+    cur = std::move(r);
     cur_batch = 0;
-    ahead = exec->next_chunk();  // the next chunk's kernels run while `cur` is still being copied to the host
+    HIP_CHECK(hipSetDevice(cur->device));
     finish_copy(*cur);
     return true;
   }
@@ -1814,7 +1957,13 @@ static std::vector<int32_t> shard_in_order(const std::vector<uint64_t>& weights,
 // =================================================================================================
 // C ABI
 // =================================================================================================
-struct bioscan_provider { Provider p; std::unique_ptr<VcfProviderI> vcf; };
+static std::atomic<int> g_live_providers{0};
+struct bioscan_provider {
+  Provider p;
+  std::unique_ptr<VcfProviderI> vcf;
+  bioscan_provider() { g_live_providers.fetch_add(1); }
+  ~bioscan_provider() { g_live_providers.fetch_sub(1); }
+};
 struct bioscan_plan { Plan pl; std::unique_ptr<VcfPlanI> vcf; };
 struct bioscan_stream { Stream s; std::unique_ptr<VcfStreamI> vcf; };
 
@@ -2237,9 +2386,14 @@ int bioscan_next(bioscan_stream* s, struct ArrowArray* out, int32_t* has_batch) 
 void bioscan_stream_close(bioscan_stream* s) { delete s; }
 void bioscan_plan_close(bioscan_plan* p) { delete p; }
 void bioscan_provider_close(bioscan_provider* p) {
+  if (!p) return;
   delete p;
-  dev_pool_trim();
-  host_pool_trim();
+  // the caches are shared by every provider of the process: they are given back when the LAST one closes, never under a
+  // provider that is still executing
+  if (g_live_providers.load() == 0) {
+    dev_pool_trim();
+    host_pool_trim();
+  }
 }
 
 int bioscan_provider_make_resident(bioscan_provider* p) {

@@ -92,6 +92,8 @@ struct RowSelect {
   int32_t n_terms;
 };
 void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st);
+void launch_row_flags_rec(const uint8_t* u, const uint64_t* rec_off, uint64_t n, const RowSelect* sels_dev, int n_sel, const FilterTerm* terms_dev,
+                          uint32_t* keep, uint32_t* err, hipStream_t st);
 void launch_compact_rows(const uint64_t* rec_off, const uint32_t* keep, const uint64_t* keep_scan, uint64_t n,
                          uint64_t* rows, uint64_t row_base, hipStream_t st);
 // tail run finder: first index >= i0 with refid==ref  /  first index > a with refid != ref

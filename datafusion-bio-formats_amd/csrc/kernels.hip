@@ -441,6 +441,67 @@ __global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTe
   if (accumulate) { if (kp) keep[i] = 1u; }   // a further region of the same decode (regions are disjoint)
   else keep[i] = kp ? 1u : 0u;
 }
+// One record's verdict for one selection (shared by the key-table form above and the fused form below)
+__device__ __forceinline__ bool row_verdict(const RowSelect& sel, uint64_t i, int32_t refid, int32_t pos, uint32_t end1, uint32_t fm,
+                                            const FilterTerm* __restrict__ terms) {
+  bool kp = false;
+  bool has_chrom = false, has_start = false, has_end = false;
+  int32_t chrom_ref = -1;
+  uint32_t start_out = 0;
+  if (sel.mode == 0) {
+    kp = true;
+  } else if (sel.mode == 1) {
+    if (refid == sel.ref && pos >= 0 && end1 != 0) {
+      const int64_t s1 = (int64_t)pos + 1;
+      const bool inter = sel.q_start1 <= (int64_t)end1 && s1 <= sel.end1;
+      const bool dedup = s1 >= sel.start1 && s1 <= sel.end1;
+      kp = inter && dedup;
+      has_chrom = true; chrom_ref = refid;
+      has_start = true; start_out = sel.zero_based ? (uint32_t)pos : (uint32_t)pos + 1u;
+      has_end = true;
+    }
+  } else if (sel.mode == 2) {
+    kp = i >= sel.i_lo && i < sel.i_hi && refid == sel.ref && pos < 0;
+    has_chrom = true; chrom_ref = sel.ref;
+  } else {
+    kp = refid < 0 && pos < 0;
+  }
+  if (kp && sel.n_terms)
+    kp = eval_terms(terms, sel.n_terms, has_chrom, chrom_ref, has_start, start_out, has_end, end1, fm >> 16, fm & 0xFFFFu);
+  return kp;
+}
+
+// Fused form for region and no-coor items: the record's keys (reference, position, end from the CIGAR, flag, mapq) stay in
+// registers and every region of the decode is tried at once (regions are disjoint: OR).  It replaces k_rec_keys + one
+// k_row_flags per region + the 16-byte-per-record key table between them (config 2 as a BAI plan: 9.4 + 13.2 ms).
+__global__ void k_row_flags_rec(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n, const RowSelect* __restrict__ sels,
+                                int n_sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep, uint32_t* err) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* r = u + rec_off[i];
+  const uint32_t bs = ld_u32(r), lrn = r[12], ncig = ld_u16(r + 16);
+  const int32_t lseq = ld_i32(r + 20);
+  if (lrn == 0 || lseq < 0 || 32ull + lrn + 4ull * ncig + (((uint64_t)(uint32_t)lseq + 1) >> 1) + (uint64_t)(uint32_t)lseq > (uint64_t)bs) {
+    atomicExch(err, 8u);
+    keep[i] = 0u;
+    return;
+  }
+  const int32_t refid = ld_i32(r + 4), pos = ld_i32(r + 8);
+  const uint32_t fm = ld_u16(r + 18) | ((uint32_t)r[13] << 16);
+  // the end needs the CIGAR: only records on a reference some region asks for pay for it
+  bool want_end = false;
+  for (int k = 0; k < n_sel; k++) want_end = want_end || (sels[k].mode == 1 && sels[k].ref == refid);
+  const uint32_t end1 = want_end ? rec_end1(r) : 0u;
+  bool kp = false;
+  for (int k = 0; k < n_sel && !kp; k++) kp = row_verdict(sels[k], i, refid, pos, end1, fm, terms);
+  keep[i] = kp ? 1u : 0u;
+}
+void launch_row_flags_rec(const uint8_t* u, const uint64_t* rec_off, uint64_t n, const RowSelect* sels_dev, int n_sel, const FilterTerm* terms_dev,
+                          uint32_t* keep, uint32_t* err, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_row_flags_rec, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, sels_dev, n_sel, terms_dev, keep, err);
+}
+
 void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st) {
   if (!n) return;
   hipLaunchKernelGGL(k_row_flags, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, k, n, sel, terms_dev, keep, accumulate);
