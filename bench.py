@@ -565,9 +565,21 @@ def main():
                "link_GB_s": round(float(stats["arrow_bytes"]) / r["seconds"] / 1e9, 3),
                "ms_to_first_batch": round(r["seconds_to_first_batch"] * 1e3, 2), "n_batches": r["n_batches"],
                "first_run_seconds": round(runs[0]["seconds"], 3),
+               "projections": {},
                "what": "bioscan_execute + bioscan_next until end of stream, every batch released at once; compressed file resident in "
                        "HBM, chunks of 2048 doubling to %d BGZF members, Arrow buffers copied D2H into recycled pinned blocks "
                        "(BIOSCAN_HOST_POOL_GB=%s)" % (int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384)), os.environ.get("BIOSCAN_HOST_POOL_GB", "64"))}
+
+    if e2e is not None and args.projection == "*":
+        # the same stream for the narrow projections (what `SELECT chrom, start` and `COUNT(*)` consumers get)
+        names = prov.schema().names
+        for label, proj in (("chrom,start", [names.index("chrom"), names.index("start")]), ("count", [])):
+            pl2 = prov.scan(projection=proj, target_partitions=1)
+            r2 = [pl2.execute_drain(0, args.batch_size) for _ in range(2)][-1]
+            if int(r2["n_rows"]) != int(meta["n_records"]):
+                raise SystemExit(f"end-to-end stream ({label}) returned {r2['n_rows']} rows, the generator wrote {meta['n_records']} records")
+            e2e["projections"][label] = {"Mrec_s": round(r2["n_rows"] / r2["seconds"] / 1e6, 3), "seconds": round(r2["seconds"], 3),
+                                         "ms_to_first_batch": round(r2["seconds_to_first_batch"] * 1e3, 2)}
 
     if cpu_sample is not None:
         # The C oracle's STREAMING scan (oracle/bioscan_oracle.c: oracle_bam_scan_stream) on a bounded sample of the same file,

@@ -1,12 +1,15 @@
-//! `BamTableProvider` (bio-format-bam/src/table_provider.rs:381-529, 927-1178) over `bioscan_bam_open`.
+//! `BamTableProvider` (bio-format-bam/src/table_provider.rs:381-529, 639-662, 927-1178) over `bioscan_bam_open` (read side)
+//! and `bioscan_bam_writer_open_schema` (write side, through `write::BamWriteExec`).
 use crate::ObjectStorageOptions;
 use crate::exec::{BioscanExec, import_schema, pushdown};
 use crate::ffi;
 use crate::handles::{ProviderHandle, check, cstring};
+use crate::write::BamWriteExec;
 use arrow::datatypes::SchemaRef;
 use async_trait::async_trait;
 use datafusion::catalog::{Session, TableProvider};
 use datafusion::datasource::TableType;
+use datafusion::logical_expr::dml::InsertOp;
 use datafusion::logical_expr::{Expr, TableProviderFilterPushDown};
 use datafusion::physical_plan::ExecutionPlan;
 use datafusion::physical_plan::execution_plan::EmissionType;
@@ -33,9 +36,14 @@ impl Default for BamOptions {
 }
 
 pub struct BamTableProvider {
-    provider: Arc<ProviderHandle>,
+    /// `None` for a provider made by `new_for_write`: there is no file to scan yet.
+    provider: Option<Arc<ProviderHandle>>,
     schema: SchemaRef,
     options: BamOptions,
+    /// write side (`new_for_write`, table_provider.rs:639-662)
+    output_path: Option<String>,
+    write_tag_fields: Option<Vec<String>>,
+    sort_on_write: bool,
 }
 
 impl std::fmt::Debug for BamTableProvider {
@@ -101,7 +109,25 @@ impl BamTableProvider {
         check(unsafe { ffi::bioscan_bam_open(path.as_ptr(), &o, &mut raw) })?;
         let provider = Arc::new(ProviderHandle(raw));
         let schema = import_schema(|s| unsafe { ffi::bioscan_schema(provider.0, s) })?;
-        Ok(Self { provider, schema, options })
+        Ok(Self { provider: Some(provider), schema, options, output_path: None, write_tag_fields: None, sort_on_write: false })
+    }
+
+    /// The reference's write constructor, argument for argument (table_provider.rs:639-662).  `coordinate_system_zero_based`
+    /// is accepted and -- as in the reference's `insert_into`, which reads the schema's
+    /// `bio.coordinate_system_zero_based` instead (:1131-1135) -- not used.
+    pub fn new_for_write(
+        output_path: String,
+        schema: SchemaRef,
+        tag_fields: Option<Vec<String>>,
+        coordinate_system_zero_based: bool,
+        sort_on_write: bool,
+    ) -> Self {
+        let _ = coordinate_system_zero_based;
+        Self { provider: None, schema, options: BamOptions::default(), output_path: Some(output_path), write_tag_fields: tag_fields, sort_on_write }
+    }
+
+    fn read_side(&self) -> datafusion::common::Result<&Arc<ProviderHandle>> {
+        self.provider.as_ref().ok_or_else(|| datafusion::common::DataFusionError::Execution("this BamTableProvider was created for writing: nothing to scan".to_string()))
     }
 }
 
@@ -117,7 +143,7 @@ impl TableProvider for BamTableProvider {
         TableType::Base
     }
     fn supports_filters_pushdown(&self, filters: &[&Expr]) -> datafusion::common::Result<Vec<TableProviderFilterPushDown>> {
-        pushdown(&self.provider, filters)
+        pushdown(self.read_side()?, filters)
     }
     async fn scan(
         &self,
@@ -126,7 +152,33 @@ impl TableProvider for BamTableProvider {
         filters: &[Expr],
         limit: Option<usize>,
     ) -> datafusion::common::Result<Arc<dyn ExecutionPlan>> {
-        BioscanExec::plan("BamExec", &self.provider, projection, filters, limit, state.config().target_partitions(),
+        BioscanExec::plan("BamExec", self.read_side()?, projection, filters, limit, state.config().target_partitions(),
                           &self.options.device_ids, EmissionType::Final)
+    }
+
+    /// `INSERT OVERWRITE` (table_provider.rs:1117-1178): the tag columns are the schema's fields that carry
+    /// `bio.bam.tag.tag` metadata plus the names given to `new_for_write`; the header's sort order follows `sort_on_write`.
+    async fn insert_into(
+        &self,
+        _state: &dyn Session,
+        input: Arc<dyn ExecutionPlan>,
+        insert_op: InsertOp,
+    ) -> datafusion::common::Result<Arc<dyn ExecutionPlan>> {
+        if insert_op != InsertOp::Overwrite {
+            return Err(datafusion::common::DataFusionError::NotImplemented("BAM insert_into only supports OVERWRITE mode".to_string()));
+        }
+        let path = match &self.output_path {
+            Some(p) => p.clone(),
+            None => return Err(datafusion::common::DataFusionError::Execution("this BamTableProvider was opened for reading: use new_for_write".to_string())),
+        };
+        let mut tag_fields: Vec<String> = self.schema.fields().iter().filter(|f| f.metadata().contains_key("bio.bam.tag.tag")).map(|f| f.name().clone()).collect();
+        if let Some(explicit) = &self.write_tag_fields {
+            for t in explicit {
+                if !tag_fields.contains(t) {
+                    tag_fields.push(t.clone());
+                }
+            }
+        }
+        Ok(Arc::new(BamWriteExec::new(input, path, tag_fields, self.sort_on_write, *self.options.device_ids.first().unwrap_or(&0))))
     }
 }

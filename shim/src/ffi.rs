@@ -168,6 +168,9 @@ unsafe extern "C" {
     pub fn bioscan_bam_writer_open(path: *const c_char, header_text: *const c_char, ref_names: *const *const c_char,
                                    ref_lengths: *const i64, n_ref: i32, coordinate_system_zero_based: i32, device_id: i32,
                                    out: *mut *mut bioscan_bam_writer) -> c_int;
+    pub fn bioscan_bam_writer_open_schema(path: *const c_char, schema: *const FFI_ArrowSchema, sort_on_write: i32, device_id: i32,
+                                          out: *mut *mut bioscan_bam_writer) -> c_int;
+    pub fn bioscan_bam_header_from_schema(schema: *const FFI_ArrowSchema, sort_on_write: i32, header_text: *mut *mut c_char) -> c_int;
     pub fn bioscan_bam_writer_write(w: *mut bioscan_bam_writer, batch: *const FFI_ArrowArray, schema: *const FFI_ArrowSchema) -> c_int;
     pub fn bioscan_bam_writer_finish(w: *mut bioscan_bam_writer, n_records: *mut u64, n_members: *mut u64, n_bytes: *mut u64) -> c_int;
     pub fn bioscan_bam_writer_close(w: *mut bioscan_bam_writer);
