@@ -370,6 +370,34 @@ __device__ __forceinline__ int v3_build(V3Lds& L, const uint8_t* lens, int n, ui
 #else
 #define V3_SRC(i) gsrc[i]
 #endif
+// The lane's bit window: dwords wp (d0) and wp + 1 (d1) feed v_alignbit, the dwords behind them are prefetched.
+// V3_REFILL8: two more dwords are held and every SECOND crossing loads 8 bytes -- half the L2 requests of the refill (K1's
+// speed follows the number of vector-memory requests per member, not its instruction count: profiles/r03).
+#ifdef V3_REFILL8
+#define V3_WIN_DECL(wp0) uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC((wp0) + 1), n0 = V3_SRC((wp0) + 2), n1 = V3_SRC((wp0) + 3), n2 = V3_SRC((wp0) + 4)
+#define V3_WIN_CROSS()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));                                              \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(n0));                                              \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n0) : "v"(n1));                                              \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(n1) : "v"(n2));                                              \
+    wp++;                                                                                                \
+    if (wp & 1u) {                                                                                       \
+      n1 = gsrc[wp + 3]; n2 = gsrc[wp + 4];   /* adjacent: one global_load_dwordx2 */                  \
+    }                                                                                                    \
+  } while (0)
+#else
+#define V3_WIN_DECL(wp0) uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC((wp0) + 1), nxt = V3_SRC((wp0) + 2)
+// explicit moves: left to the register allocator, the fresh load is copied into place right away and the
+// wave waits for it here instead of one crossing later
+#define V3_WIN_CROSS()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));                                              \
+    asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));                                             \
+    wp++;                                                                                                \
+    nxt = V3_SRC(wp + 2);                                                                                \
+  } while (0)
+#endif
 constexpr uint32_t V3_DIST_BASE = 2u * ((1u << V3_LIT_BITS) + V3_LIT_SUB);
 constexpr uint32_t V3_CK_ROW = 3u * 64u;  // dwords per checkpoint index: pos[64], acc[64], state[64]
 static_assert((uint32_t)V3_CK_MAX * V3_CK_ROW == V3_CK_DWORDS, "kernels.h sizes the checkpoint scratch for V3_CK_MAX rows");
@@ -385,7 +413,7 @@ __device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t c
   const bool run0 = pos < count_from;  // a lane that starts exactly on its boundary (lane 0: the round's first bit) is there already
   uint32_t wp = pos >> 5;
   const uint32_t wp0 = run0 ? wp : 0u;
-  uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC(wp0 + 1), nxt = V3_SRC(wp0 + 2);
+  V3_WIN_DECL(wp0);
   const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;
   uint32_t tb = run0 ? 0u : STOP_END, mb = run0 ? (uint32_t)V3_LIT_BITS : 0u;
   while (__ballot(tb < V3_NULL_BASE) != 0ull) {
@@ -407,12 +435,7 @@ __device__ __forceinline__ uint32_t v3_sync(V3Lds& L, uint32_t start, uint32_t c
     const bool is_len = lenlike && in_lit;
     const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
     pos += ptr ? mb : l + ebv;
-    if ((pos >> 5) != wp) {
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));
-      wp++;
-      nxt = V3_SRC(wp + 2);
-    }
+    if ((pos >> 5) != wp) V3_WIN_CROSS();
     // next lookup: a completed symbol at / after count_from is what the lane was looking for
     const bool arrived = pos >= count_from;
     uint32_t ntb = is_len ? V3_DIST_BASE : (arrived ? STOP_END : 0u);
@@ -446,7 +469,7 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
   // (a lane that does not run keeps pos, so it never crosses a dword and never loads again: its three reads are parked at 0)
   uint32_t wp = pos >> 5;
   const uint32_t wp0 = run0 ? wp : 0u;
-  uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC(wp0 + 1), nxt = V3_SRC(wp0 + 2);
+  V3_WIN_DECL(wp0);
   const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;  // dist_fast follows lit_fast in LDS
   uint32_t tb = run0 ? 0u : STOP_END, mb = run0 ? (uint32_t)V3_LIT_BITS : 0u, mlen = 0;
   uint32_t cd = V3_CK_STEPS, c = 0;  // wave-uniform: steps to the next checkpoint, checkpoint row
@@ -495,14 +518,7 @@ __device__ __forceinline__ bool v3_count(V3Lds& L, bool active, uint32_t start, 
     const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
     const uint32_t val = base + __builtin_amdgcn_ubfe(w, l, ebv);
     pos += ptr ? mb : l + ebv;
-    if ((pos >> 5) != wp) {
-      // explicit moves: left to the register allocator, the fresh load is copied into place right away and the
-      // wave waits for it here instead of one crossing later
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));
-      wp++;
-      nxt = V3_SRC(wp + 2);
-    }
+    if ((pos >> 5) != wp) V3_WIN_CROSS();
     if (is_len) mlen = val + (1u << 20);                   // the match count rides in the same accumulator
     const uint32_t produced = is_lit ? 1u : (is_dist ? mlen : 0u);
     acc += produced;
@@ -540,7 +556,7 @@ __device__ __forceinline__ uint32_t v3_write(V3Lds& L, bool active, uint32_t pos
   const bool run0 = active && pos < stop_any;
   uint32_t wp = pos >> 5;
   const uint32_t wp0 = run0 ? wp : 0u;
-  uint32_t d0 = V3_SRC(wp0), d1 = V3_SRC(wp0 + 1), nxt = V3_SRC(wp0 + 2);
+  V3_WIN_DECL(wp0);
   const uint8_t* __restrict__ T = (const uint8_t*)L.lit_fast;
   uint32_t tb = run0 ? tb0 : STOP_END, mb = run0 ? mb0 : 0u;
   while (__ballot(tb < V3_NULL_BASE) != 0ull) {
@@ -565,12 +581,7 @@ __device__ __forceinline__ uint32_t v3_write(V3Lds& L, bool active, uint32_t pos
     const uint32_t ebv = lenlike ? ((e >> 4) & 15u) : 0u;
     const uint32_t val = base + __builtin_amdgcn_ubfe(w, l, ebv);
     pos += ptr ? mb : l + ebv;
-    if ((pos >> 5) != wp) {
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d0) : "v"(d1));
-      asm volatile("v_mov_b32 %0, %1" : "=v"(d1) : "v"(nxt));
-      wp++;
-      nxt = V3_SRC(wp + 2);
-    }
+    if ((pos >> 5) != wp) V3_WIN_CROSS();
     bool bad = false;                                      // (an unassigned code is a pointer to STOP_BAD)
     if (MODE == 1) { if (is_lit && !V3_G(opos >= win_base, 2, opos)) out[opos] = (uint8_t)(e >> 4); }
     if (MODE == 2) { if (is_lit) (L.win - win_base)[opos] = (uint8_t)(e >> 4); }  // base pointer folded: one VALU less than an index subtraction
@@ -1092,12 +1103,14 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
         uint64_t want = pred_bits > used + pred_bits / 8 ? pred_bits - used : pred_bits / 8;
         want += want / 16 + 64;
         if (want > rem_bits) want = rem_bits;
-#ifndef V3_NO_EXACT_FINAL
-        // A member's FINAL block ends with its payload (at most 7 bits of padding behind the END-OF-BLOCK), so its length
-        // needs no prediction: the rounds that are left share the remaining bits evenly and the last one ends with the
-        // block.  (A BGZF member is usually one block.  Predicted from the previous member's block, 6 % of slack did not
-        // cover the variation between members: config 2 ran 2.97 rounds per member -- a third, short round whose
-        // sub-streams are too short for their pre-roll -- and one fix pass per round.)
+#ifdef V3_EXACT_FINAL
+        // Compile-time experiment, measured and NOT the default: a member's FINAL block ends with its payload (at most 7 bits of
+        // padding behind the END-OF-BLOCK), so its length needs no prediction -- the rounds that are left share the remaining
+        // bits evenly and the last one ends with the block.  Config 2: 2.07 rounds and 2.8 decode passes per member instead
+        // of 2.97 and 5.9 (the predictor's 6 % of slack does not cover the variation between members, so most members run a
+        // third, short round with a fix pass), 1.1 instead of 3.0 lanes idle behind the END-OF-BLOCK -- and 2 % SLOWER
+        // (54.1 against 52.8 ms on 262 144 members): the passes it removes are the cheap ones (short sub-streams), while two
+        // equal rounds of 50 dwords balance their lanes a little worse than one of 64 and one of 42.
         if (uni2(L.blk_final)) {
           const uint32_t round_max = 64u * 32u * (uint32_t)V3_MAX_SUB_DW;   // (a payload is < 2^19 bits)
           const uint32_t rb = (uint32_t)rem_bits;
