@@ -2174,6 +2174,16 @@ int bioscan_udf_vcf_set_gts(const struct ArrowArray* gt, const struct ArrowSchem
   udf_set_gts_host(gt, gt_schema, mask, mask_schema, replacement, device_id, out, out_schema);
   API_END
 }
+int bioscan_udf_vcf_allele_stats(const struct ArrowArray* gt, const struct ArrowSchema* gt_schema, const struct ArrowArray* alt,
+                                 const struct ArrowSchema* alt_schema, int32_t which, int32_t device_id, struct ArrowArray* out,
+                                 struct ArrowSchema* out_schema) {
+  API_BEGIN
+  char nm[8];
+  if (bioscan_device_check(device_id, nm, sizeof nm)) throw Error(bioscan_last_error());
+  udf_allele_stats_host(gt, gt_schema, alt, alt_schema, which, device_id, out, out_schema);
+  API_END
+}
+
 int bioscan_stream_list_udf(bioscan_stream* s, const char* field, int32_t udf, double threshold, bioscan_udf_stats* out) {
   API_BEGIN
   if (!s->vcf) throw Error("list UDFs apply to VCF streams");

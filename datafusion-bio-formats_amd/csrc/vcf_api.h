@@ -38,5 +38,7 @@ void udf_list_and_host(const ArrowArray* a, const ArrowSchema* as, const ArrowAr
                        ArrowArray* out, ArrowSchema* out_schema);
 void udf_set_gts_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowArray* mask, const ArrowSchema* ms, const char* replacement,
                       int32_t device_id, ArrowArray* out, ArrowSchema* out_schema);
+void udf_allele_stats_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowArray* alt, const ArrowSchema* as, int32_t which,
+                           int32_t device_id, ArrowArray* out, ArrowSchema* out_schema);
 
 }  // namespace bioscan

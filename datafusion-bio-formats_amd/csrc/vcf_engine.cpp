@@ -1455,6 +1455,139 @@ void udf_set_gts_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowAr
   add_child(out_schema, std::move(cs));
 }
 
+// vcf_an / vcf_ac / vcf_af (bio-format-vcf/src/udfs.rs:161-552).  which: 0 = AN (Int32), 1 = AC (List<Int32>), 2 = AF (List<Float64>).
+// `alt` (Utf8, the provider's pipe-separated ALT column) is the optional second argument of AC / AF: the list of a row is as long
+// as the larger of its ALT count and the largest allele index its genotypes call.  The GT strings are parsed on the device
+// (two passes: called alleles + largest index per row, then the per-allele counts); the per-row list lengths, their prefix
+// sum and AF's division run on the host over n rows.
+void udf_allele_stats_host(const ArrowArray* gt, const ArrowSchema* gs, const ArrowArray* alt, const ArrowSchema* as, int32_t which,
+                           int32_t device_id, ArrowArray* out, ArrowSchema* out_schema) {
+  static const char* const NAMES[3] = {"vcf_an", "vcf_ac", "vcf_af"};
+  if (which < 0 || which > 2) throw Error("unknown allele statistic");
+  const std::string fn = NAMES[which];
+  if (!gt || !gs || strcmp(gs->format, "+l") != 0 || gs->n_children != 1 || strcmp(gs->children[0]->format, "u") != 0)
+    throw Error(fn + " expects List<Utf8> input");
+  if (alt && (!as || strcmp(as->format, "u") != 0)) throw Error(fn + " 2nd argument must be Utf8 (alt column)");
+  const uint64_t n = (uint64_t)gt->length;
+  if (alt && (uint64_t)alt->length != n) throw Error(fn + ": the two arguments have different lengths");
+  const int32_t* off = (const int32_t*)gt->buffers[1] + gt->offset;
+  const ArrowArray* ch = gt->children[0];
+  const uint64_t e0 = n ? (uint64_t)off[0] : 0, e1 = n ? (uint64_t)off[n] : 0, E = e1 - e0;
+  std::vector<uint64_t> off_g(n + 1), goff(E + 1), gvalid, glvalid;
+  for (uint64_t i = 0; i <= n; i++) off_g[i] = n ? (uint64_t)off[i] - e0 : 0;
+  const int32_t* so = (const int32_t*)ch->buffers[1] + ch->offset + e0;
+  const uint64_t b0 = E ? (uint64_t)so[0] : 0, b1 = E ? (uint64_t)so[E] : 0;
+  for (uint64_t i = 0; i <= E; i++) goff[i] = E ? (uint64_t)so[i] - b0 : 0;
+  if (ch->buffers[0] && ch->null_count != 0) bits_to_words((const uint8_t*)ch->buffers[0], (uint64_t)ch->offset + e0, E, gvalid);
+  if (gt->buffers[0] && gt->null_count != 0) bits_to_words((const uint8_t*)gt->buffers[0], (uint64_t)gt->offset, n, glvalid);
+  const uint64_t data_len = b1 - b0;
+  HIP_CHECK(hipSetDevice(device_id));
+  DevBuf<uint8_t> d_u(data_len + 64);
+  if (data_len) HIP_CHECK(hipMemcpy(d_u.p, (const uint8_t*)ch->buffers[2] + b0, data_len, hipMemcpyHostToDevice));
+  DevBuf<uint64_t> d_og, d_goff, d_gv;
+  up(d_og, off_g); up(d_goff, goff);
+  if (!gvalid.empty()) up(d_gv, gvalid);
+  DevBuf<int32_t> d_an(std::max<uint64_t>(n, 1));
+  DevBuf<unsigned long long> d_mx(std::max<uint64_t>(n, 1));
+  launch_gt_stats(d_u.p, d_goff.p, gvalid.empty() ? nullptr : d_gv.p, d_og.p, n, d_an.p, d_mx.p, nullptr);
+  std::vector<int32_t> an(n);
+  std::vector<unsigned long long> mx(n);
+  HIP_CHECK(hipDeviceSynchronize());
+  if (n) {
+    HIP_CHECK(hipMemcpy(an.data(), d_an.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(mx.data(), d_mx.p, n * 8, hipMemcpyDeviceToHost));
+  }
+  auto keep = std::make_shared<UdfKeep>();
+  keep->lbits.assign((n + 7) / 8 + 8, 0xFF);
+  int64_t lnulls = 0;
+  if (!glvalid.empty()) {
+    memcpy(keep->lbits.data(), glvalid.data(), (n + 7) / 8);
+    for (uint64_t i = 0; i < n; i++) lnulls += !word_bit(glvalid, i);
+  }
+  if (which == 0) {
+    keep->off.resize(n + 1);   // (Int32 values live in `off`)
+    for (uint64_t i = 0; i < n; i++) keep->off[i] = word_bit(glvalid, i) ? an[i] : 0;
+    UdfPriv* pr = init_udf_array(out, keep, (int64_t)n);
+    out->null_count = lnulls;
+    pr->buffers.push_back(lnulls ? keep->lbits.data() : nullptr);
+    pr->buffers.push_back(keep->off.data());
+    finish_udf_array(out);
+    fill_schema(out_schema, "vcf_an", "i", true, {});
+    return;
+  }
+  // list lengths: max(ALT count of the row, largest called allele index); a NULL list is a NULL (empty) list
+  auto alt_valid = [&](uint64_t i) {
+    if (!alt) return false;
+    const uint8_t* v = (const uint8_t*)alt->buffers[0];
+    const uint64_t j = i + (uint64_t)alt->offset;
+    return alt->null_count == 0 || !v || ((v[j >> 3] >> (j & 7)) & 1);
+  };
+  auto is_space = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
+  std::vector<uint64_t> out_off(n + 1, 0);
+  for (uint64_t i = 0; i < n; i++) {
+    uint64_t len = 0;
+    if (word_bit(glvalid, i)) {
+      len = mx[i];
+      if (alt_valid(i)) {
+        // count_alt_alleles (udfs.rs:146-154): trimmed; "" and "." have none; else pieces between '|'
+        const int32_t* ao = (const int32_t*)alt->buffers[1] + alt->offset;
+        const uint8_t* ad = (const uint8_t*)alt->buffers[2];
+        uint64_t a = (uint64_t)ao[i], b = (uint64_t)ao[i + 1];
+        while (a < b && is_space(ad[a])) a++;
+        while (b > a && is_space(ad[b - 1])) b--;
+        uint64_t cnt = 0;
+        if (b > a && !(b - a == 1 && ad[a] == '.')) { cnt = 1; for (uint64_t k = a; k < b; k++) cnt += ad[k] == '|'; }
+        len = std::max<uint64_t>(len, cnt);
+      }
+      if (len > 0x7FFFFFFFull) throw Error(fn + ": allele index " + std::to_string(len) + " is out of range");
+    }
+    out_off[i + 1] = out_off[i] + len;
+  }
+  const uint64_t T = out_off[n];
+  if (T > 0x7FFFFFFFull) throw Error(fn + ": result exceeds the int32 offsets of one list array");
+  DevBuf<uint64_t> d_oo;
+  up(d_oo, out_off);
+  DevBuf<int32_t> d_cnt(std::max<uint64_t>(T, 1));
+  HIP_CHECK(hipMemset(d_cnt.p, 0, std::max<uint64_t>(T, 1) * 4));
+  launch_gt_ac(d_u.p, d_goff.p, gvalid.empty() ? nullptr : d_gv.p, d_og.p, n, d_oo.p, d_cnt.p, nullptr);
+  HIP_CHECK(hipDeviceSynchronize());
+  std::vector<int32_t> counts(T);
+  if (T) HIP_CHECK(hipMemcpy(counts.data(), d_cnt.p, T * 4, hipMemcpyDeviceToHost));
+  keep->off.resize(n + 1);
+  for (uint64_t i = 0; i <= n; i++) keep->off[i] = (int32_t)out_off[i];
+  int64_t enulls = 0;
+  if (which == 1) {
+    keep->off2.assign(counts.begin(), counts.end());   // Int32 element values
+    keep->off2.push_back(0);
+  } else {
+    keep->f64.assign(T + 1, 0.0);
+    keep->bits2.assign((T + 7) / 8 + 8, 0);
+    for (uint64_t i = 0; i < n; i++)
+      for (uint64_t k = out_off[i]; k < out_off[i + 1]; k++) {
+        if (an[i] == 0) { enulls++; continue; }            // all missing: NULLs of the list's length (udfs.rs:505-511)
+        keep->f64[k] = (double)counts[k] / (double)an[i];
+        keep->bits2[k >> 3] |= (uint8_t)(1u << (k & 7));
+      }
+  }
+  UdfPriv* pr = init_udf_array(out, keep, (int64_t)n);
+  out->null_count = lnulls;
+  pr->buffers.push_back(lnulls ? keep->lbits.data() : nullptr);
+  pr->buffers.push_back(keep->off.data());
+  std::unique_ptr<ArrowArray> item(new ArrowArray);
+  UdfPriv* ip = init_udf_array(item.get(), keep, (int64_t)T);
+  item->null_count = enulls;
+  ip->buffers.push_back(enulls ? keep->bits2.data() : nullptr);
+  if (which == 1) ip->buffers.push_back(keep->off2.data()); else ip->buffers.push_back(keep->f64.data());
+  finish_udf_array(item.get());
+  pr->children.push_back(item.get());
+  pr->owned.push_back(std::move(item));
+  finish_udf_array(out);
+  fill_schema(out_schema, which == 1 ? "vcf_ac" : "vcf_af", "+l", true, {});
+  std::unique_ptr<ArrowSchema> cs(new ArrowSchema);
+  fill_schema(cs.get(), "item", which == 1 ? "i" : "g", true, {});
+  add_child(out_schema, std::move(cs));
+}
+
 // ---- open -----------------------------------------------------------------------------------------------------
 VcfProviderI* vcf_open(const char* path, const bioscan_vcf_options* o) {
   std::unique_ptr<VcfProvider> pp(new VcfProvider);

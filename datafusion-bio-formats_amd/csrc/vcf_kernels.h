@@ -124,6 +124,12 @@ void launch_set_gts_plan(const uint64_t* off_g, const uint64_t* goff, const uint
                          const uint64_t* mlvalid, const uint64_t* mval, const uint64_t* mvalid, uint64_t n, uint64_t rep_off,
                          uint32_t rep_len, uint64_t* src, uint32_t* len, uint8_t* ovalid, hipStream_t st);
 void launch_count_bits(const uint64_t* bits, const uint64_t* valid, uint64_t n_elems, unsigned long long* counts, hipStream_t st);
+// vcf_an / vcf_ac / vcf_af: per row (list of GT strings: element byte offsets goff, element validity words or null, row offsets
+// off_g) the number of called alleles and the largest allele index; then the per-ALT-allele counts into zeroed `counts`
+void launch_gt_stats(const uint8_t* bytes, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_g, uint64_t n, int32_t* an,
+                     unsigned long long* max_allele, hipStream_t st);
+void launch_gt_ac(const uint8_t* bytes, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_g, uint64_t n, const uint64_t* out_off,
+                  int32_t* counts, hipStream_t st);
 void launch_list_cmp(const uint32_t* values, uint64_t n_elems, int is_float, int op, uint32_t thr_bits, uint64_t* out_bits, hipStream_t st);
 
 }  // namespace bioscan

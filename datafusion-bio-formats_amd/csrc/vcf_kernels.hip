@@ -1309,6 +1309,87 @@ void launch_list_avg(const uint64_t* off, const uint32_t* values, const uint64_t
   hipLaunchKernelGGL(k_list_avg, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, off, values, evalid, lvalid, n, is_float, out,
                      out_valid);
 }
+// ---- vcf_an / vcf_ac / vcf_af (bio-format-vcf/src/udfs.rs:113-142 parse_gt_alleles, 161-552) ---------------------------------
+// One GT string: trimmed; ".", "./." and ".|." are entirely missing; otherwise it is split on '/' and '|', every piece trimmed,
+// "." and anything `usize::from_str` rejects (empty, sign other than one leading '+', a non-digit, overflow) is a missing allele.
+// `f(idx)` is called for every called allele.  (Rust's trim strips Unicode White_Space; the ASCII members are handled here.)
+__device__ __forceinline__ bool gt_is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+template <typename F>
+__device__ __forceinline__ void gt_for_each_allele(const uint8_t* s, uint32_t len, F f) {
+  uint32_t a = 0, b = len;
+  while (a < b && gt_is_space(s[a])) a++;
+  while (b > a && gt_is_space(s[b - 1])) b--;
+  const uint32_t n = b - a;
+  if (n == 1 && s[a] == '.') return;
+  if (n == 3 && s[a] == '.' && s[a + 2] == '.' && (s[a + 1] == '/' || s[a + 1] == '|')) return;
+  uint32_t p = a;
+  for (;;) {
+    uint32_t q = p;
+    while (q < b && s[q] != '/' && s[q] != '|') q++;
+    uint32_t x = p, y = q;   // the piece [x, y), trimmed
+    while (x < y && gt_is_space(s[x])) x++;
+    while (y > x && gt_is_space(s[y - 1])) y--;
+    if (x < y && s[x] == '+') x++;
+    bool ok = x < y;
+    unsigned long long v = 0;
+    for (uint32_t k = x; k < y && ok; k++) {
+      const uint32_t d = (uint32_t)s[k] - '0';
+      if (d > 9u) { ok = false; break; }
+      if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10ull) { ok = false; break; }   // usize overflow: parse error -> missing
+      v = v * 10ull + d;
+    }
+    if (ok) f(v);
+    if (q >= b) break;
+    p = q + 1;
+  }
+}
+// per row (one wave): AN = called alleles of its non-NULL GT strings, the largest allele index, both by wave reduction
+__global__ __launch_bounds__(256) void k_gt_stats(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ goff,
+                                                   const uint64_t* __restrict__ gvalid, const uint64_t* __restrict__ off_g, uint64_t n,
+                                                   int32_t* __restrict__ an, unsigned long long* __restrict__ max_allele) {
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  long long cnt = 0;
+  unsigned long long mx = 0;
+  for (uint64_t k = off_g[r] + lane; k < off_g[r + 1]; k += WAVE) {
+    if (!bit_at(gvalid, k)) continue;
+    gt_for_each_allele(bytes + goff[k], (uint32_t)(goff[k + 1] - goff[k]), [&](unsigned long long idx) { cnt++; if (idx > mx) mx = idx; });
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    cnt += __shfl_down(cnt, d, 64);
+    const unsigned long long o = __shfl_down(mx, d, 64);
+    if (o > mx) mx = o;
+  }
+  if (lane == 0) { an[r] = (int32_t)cnt; max_allele[r] = mx; }
+}
+// counts[out_off[r] + idx - 1] += 1 for every called allele 1 <= idx <= out_off[r + 1] - out_off[r] of row r (counts zeroed)
+__global__ __launch_bounds__(256) void k_gt_ac(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ goff,
+                                                const uint64_t* __restrict__ gvalid, const uint64_t* __restrict__ off_g, uint64_t n,
+                                                const uint64_t* __restrict__ out_off, int32_t* __restrict__ counts) {
+  const uint64_t r = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const uint64_t base = out_off[r], vec_len = out_off[r + 1] - base;
+  if (!vec_len) return;
+  for (uint64_t k = off_g[r] + lane; k < off_g[r + 1]; k += WAVE) {
+    if (!bit_at(gvalid, k)) continue;
+    gt_for_each_allele(bytes + goff[k], (uint32_t)(goff[k + 1] - goff[k]), [&](unsigned long long idx) {
+      if (idx >= 1 && idx <= vec_len) atomicAdd(&counts[base + idx - 1], 1);
+    });
+  }
+}
+void launch_gt_stats(const uint8_t* bytes, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_g, uint64_t n, int32_t* an,
+                     unsigned long long* max_allele, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gt_stats, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, bytes, goff, gvalid, off_g, n, an, max_allele);
+}
+void launch_gt_ac(const uint8_t* bytes, const uint64_t* goff, const uint64_t* gvalid, const uint64_t* off_g, uint64_t n, const uint64_t* out_off,
+                  int32_t* counts, hipStream_t st) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_gt_ac, dim3((uint32_t)((n * 64 + 255) / 256)), dim3(256), 0, st, bytes, goff, gvalid, off_g, n, out_off, counts);
+}
 // list_gte / list_lte: element-wise compare -> Boolean value bits (element validity and list offsets are the input's)
 __global__ __launch_bounds__(256) void k_list_cmp(const uint32_t* __restrict__ values, uint64_t n_elems, int is_float, int op,
                                                    uint32_t thr_bits, uint64_t* __restrict__ out_bits) {

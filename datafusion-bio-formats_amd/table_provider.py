@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
-    "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts",
+    "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts", "bioscan_udf_vcf_allele_stats",
     "bioscan_scan_devices", "bioscan_plan_partition_device", "bioscan_plan_make_resident", "bioscan_provider_resident_range",
     "bioscan_debug_shard_partitions", "bioscan_debug_extract_regions",
     "bioscan_bam_writer_open", "bioscan_bam_writer_open_schema", "bioscan_bam_header_from_schema", "bioscan_bam_writer_write", "bioscan_bam_writer_finish", "bioscan_bam_writer_close", "bioscan_bgzf_deflate",
@@ -139,6 +139,7 @@ def load_library():
     lib.bioscan_udf_list_cmp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_udf_list_and.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_udf_vcf_set_gts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.bioscan_udf_vcf_allele_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.bioscan_stream_list_udf.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_double, C.POINTER(UdfStats)]
     lib.bioscan_scan_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.POINTER(_Filter), C.c_int32, C.c_int64,
                                          C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
@@ -753,3 +754,35 @@ def bam_header_from_schema(schema: pa.Schema, sort_on_write: Optional[bool] = No
             lib.bioscan_free(out)
         if sch.release:
             C.CFUNCTYPE(None, C.c_void_p)(sch.release)(C.addressof(sch))
+
+
+def _allele_stats(gt: pa.Array, alt, which: int, device_id: int) -> pa.Array:
+    lib = load_library()
+    ga, gsch, aa, asch, oa, osch = _ArrowArray(), _ArrowSchema(), _ArrowArray(), _ArrowSchema(), _ArrowArray(), _ArrowSchema()
+    gt._export_to_c(C.addressof(ga), C.addressof(gsch))
+    if alt is not None:
+        alt._export_to_c(C.addressof(aa), C.addressof(asch))
+    rel = C.CFUNCTYPE(None, C.c_void_p)
+    try:
+        _check(lib.bioscan_udf_vcf_allele_stats(C.addressof(ga), C.addressof(gsch), C.addressof(aa) if alt is not None else None,
+                                                C.addressof(asch) if alt is not None else None, which, device_id, C.addressof(oa), C.addressof(osch)))
+        return pa.Array._import_from_c(C.addressof(oa), C.addressof(osch))
+    finally:
+        for st in (ga, gsch) + ((aa, asch) if alt is not None else ()):
+            if st.release:
+                rel(st.release)(C.addressof(st))
+
+
+def vcf_an(gt: pa.Array, device_id: int = 0) -> pa.Array:
+    """`vcf_an` UDF (udfs.rs:161-232): Int32 count of called alleles per row of a List<Utf8> GT column."""
+    return _allele_stats(gt, None, 0, device_id)
+
+
+def vcf_ac(gt: pa.Array, alt: Optional[pa.Array] = None, device_id: int = 0) -> pa.Array:
+    """`vcf_ac` UDF (udfs.rs:238-392): List<Int32> count per ALT allele; `alt` = the pipe-separated ALT column (2-argument form)."""
+    return _allele_stats(gt, alt, 1, device_id)
+
+
+def vcf_af(gt: pa.Array, alt: Optional[pa.Array] = None, device_id: int = 0) -> pa.Array:
+    """`vcf_af` UDF (udfs.rs:398-552): List<Float64> AC / AN per ALT allele (NULL elements when no allele is called)."""
+    return _allele_stats(gt, alt, 2, device_id)

@@ -107,6 +107,15 @@ int bioscan_udf_list_and(const struct ArrowArray* a, const struct ArrowSchema* a
 int bioscan_udf_vcf_set_gts(const struct ArrowArray* gt, const struct ArrowSchema* gt_schema, const struct ArrowArray* mask,
                             const struct ArrowSchema* mask_schema, const char* replacement, int32_t device_id,
                             struct ArrowArray* out, struct ArrowSchema* out_schema);
+/* vcf_an / vcf_ac / vcf_af (bio-format-vcf/src/udfs.rs:113-142 parse_gt_alleles, 161-552): allele statistics of a List<Utf8> GT
+ * column.  which: 0 = AN -> Int32 (called alleles of the row's non-NULL genotypes; ".", "./." and ".|." are entirely missing,
+ * a piece that is "." or not a usize is a missing allele), 1 = AC -> List<Int32> (count of allele 1, 2, ...; the list is as long
+ * as the larger of the largest called allele index and -- when `alt`, the provider's pipe-separated Utf8 ALT column, is given
+ * and not NULL in the row -- the number of ALT alleles), 2 = AF -> List<Float64> (AC / AN; NULL elements when AN is 0).  A NULL
+ * list gives NULL.  `alt` / `alt_schema` may be NULL (the one-argument forms). */
+int bioscan_udf_vcf_allele_stats(const struct ArrowArray* gt, const struct ArrowSchema* gt_schema, const struct ArrowArray* alt,
+                                 const struct ArrowSchema* alt_schema, int32_t which, int32_t device_id, struct ArrowArray* out,
+                                 struct ArrowSchema* out_schema);
 /* Device-resident form for a stream returned by bioscan_execute_device: applies the UDF to `genotypes.<field>` (or a
  * top-level List column named `field`) of the whole partition without leaving HBM.  udf: 0 list_avg, 1 list_gte,
  * 2 list_lte.  Reports the kernel time and two checksums the caller can compare with an oracle: for list_avg the

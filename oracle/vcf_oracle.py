@@ -1142,3 +1142,75 @@ def vcf_set_gts(gt: pa.ListArray, mask: pa.ListArray, replacement: str = "./.") 
             row.append(v if keep else replacement)
         out.append(row)
     return pa.array(out, type=pa.list_(pa.field("item", pa.utf8(), True)))
+
+
+# ---- vcf_an / vcf_ac / vcf_af (bio-format-vcf/src/udfs.rs:113-154, 161-552) ---------------------------------------------------
+def parse_gt_alleles(gt: str):
+    """udfs.rs:117-142: None for an entirely missing genotype (".", "./.", ".|."); else one entry per piece between '/' and '|',
+    None for "." and for anything Rust's `usize::from_str` rejects (empty, a sign other than one leading '+', a non-digit, overflow)."""
+    gt = gt.strip()   # Rust's trim: Unicode White_Space, as Python's str.strip
+    if gt in (".", "./.", ".|."):
+        return None
+    out = []
+    for piece in gt.replace("|", "/").split("/"):
+        a = piece.strip()
+        if a == ".":
+            out.append(None)
+            continue
+        digits = a[1:] if a[:1] == "+" else a
+        if digits and all("0" <= c <= "9" for c in digits) and int(digits) < (1 << 64):
+            out.append(int(digits))
+        else:
+            out.append(None)
+    return out
+
+
+def count_alt_alleles(alt: str) -> int:
+    """udfs.rs:146-154"""
+    alt = alt.strip()
+    return 0 if alt in ("", ".") else len(alt.split("|"))
+
+
+def _called(gts):
+    for g in gts:
+        if g is None:
+            continue
+        al = parse_gt_alleles(g)
+        if al is not None:
+            for a in al:
+                if a is not None:
+                    yield a
+
+
+def vcf_an(gt: pa.Array) -> pa.Array:
+    """udfs.rs:201-232"""
+    return pa.array([None if not g.is_valid else sum(1 for _ in _called(g.as_py())) for g in gt], type=pa.int32())
+
+
+def _ac_rows(gt: pa.Array, alt):
+    for i, g in enumerate(gt):
+        if not g.is_valid:
+            yield None, 0
+            continue
+        called = list(_called(g.as_py()))
+        vec_len = max(called, default=0)
+        if alt is not None and alt[i].is_valid:
+            vec_len = max(vec_len, count_alt_alleles(alt[i].as_py()))
+        counts = [0] * vec_len
+        for a in called:
+            if 1 <= a <= vec_len:
+                counts[a - 1] += 1
+        yield counts, len(called)
+
+
+def vcf_ac(gt: pa.Array, alt=None) -> pa.Array:
+    """udfs.rs:283-381: the list is as long as max(number of ALT alleles when `alt` is given, largest called allele index)."""
+    return pa.array([c for c, _ in _ac_rows(gt, alt)], type=pa.list_(pa.field("item", pa.int32(), True)))
+
+
+def vcf_af(gt: pa.Array, alt=None) -> pa.Array:
+    """udfs.rs:443-541: AC / AN; NULL elements when AN is 0."""
+    out = []
+    for c, an in _ac_rows(gt, alt):
+        out.append(None if c is None else [None if an == 0 else x / an for x in c])
+    return pa.array(out, type=pa.list_(pa.field("item", pa.float64(), True)))

@@ -136,6 +136,9 @@ unsafe extern "C" {
     pub fn bioscan_udf_vcf_set_gts(gt: *const FFI_ArrowArray, gt_schema: *const FFI_ArrowSchema, mask: *const FFI_ArrowArray,
                                    mask_schema: *const FFI_ArrowSchema, replacement: *const c_char, device_id: i32,
                                    out: *mut FFI_ArrowArray, out_schema: *mut FFI_ArrowSchema) -> c_int;
+    pub fn bioscan_udf_vcf_allele_stats(gt: *const FFI_ArrowArray, gt_schema: *const FFI_ArrowSchema, alt: *const FFI_ArrowArray,
+                                        alt_schema: *const FFI_ArrowSchema, which: i32, device_id: i32, out: *mut FFI_ArrowArray,
+                                        out_schema: *mut FFI_ArrowSchema) -> c_int;
     pub fn bioscan_stream_list_udf(s: *mut bioscan_stream, field: *const c_char, udf: i32, threshold: f64,
                                    out: *mut bioscan_udf_stats) -> c_int;
 

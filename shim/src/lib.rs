@@ -30,7 +30,7 @@ mod write;
 pub use bam::{BamOptions, BamTableProvider};
 pub use exec::BioscanExec;
 pub use fastq::FastqTableProvider;
-pub use udfs::{list_and_udf, list_avg_udf, list_gte_udf, list_lte_udf, register_vcf_udfs, vcf_set_gts_udf};
+pub use udfs::{list_and_udf, list_avg_udf, list_gte_udf, list_lte_udf, register_vcf_udfs, vcf_ac_udf, vcf_af_udf, vcf_an_udf, vcf_set_gts_udf};
 pub use vcf::VcfTableProvider;
 pub use write::BamWriteExec;
 

@@ -1,6 +1,6 @@
 //! The list UDFs of bio-format-vcf/src/udfs.rs on the GPU: `list_avg` (:67-110), `list_gte` (:606-650), `list_lte`,
-//! `list_and` (:765-850), `vcf_set_gts` (:857-953).  Arrow C Data in, Arrow C Data out; signatures and NULL rules are
-//! the reference's.
+//! `list_and` (:765-850), `vcf_set_gts` (:857-953), `vcf_an` / `vcf_ac` / `vcf_af` (:161-552).  Arrow C Data in, Arrow C Data out;
+//! signatures and NULL rules are the reference's.
 use crate::ffi;
 use crate::handles::{check, cstring};
 use arrow::array::{Array, ArrayRef, make_array};
@@ -173,8 +173,69 @@ pub fn vcf_set_gts_udf() -> ScalarUDF {
     })
 }
 
-/// `register_vcf_udfs` (bio-format-vcf/src/udfs.rs:976): the five list UDFs under the reference's names.
+/// `vcf_an` / `vcf_ac` / `vcf_af` (bio-format-vcf/src/udfs.rs:161-552) over `bioscan_udf_vcf_allele_stats`; the optional second
+/// argument of AC / AF is the provider's pipe-separated ALT column (a scalar is broadcast, as `into_array(list.len())` does).
+#[derive(Debug, PartialEq, Eq, Hash)]
+struct AlleleStat {
+    signature: Signature,
+    which: i32,
+}
+impl ScalarUDFImpl for AlleleStat {
+    fn as_any(&self) -> &dyn Any {
+        self
+    }
+    fn name(&self) -> &str {
+        match self.which {
+            0 => "vcf_an",
+            1 => "vcf_ac",
+            _ => "vcf_af",
+        }
+    }
+    fn signature(&self) -> &Signature {
+        &self.signature
+    }
+    fn return_type(&self, _: &[DataType]) -> Result<DataType> {
+        Ok(match self.which {
+            0 => DataType::Int32,
+            1 => list_of(DataType::Int32),
+            _ => list_of(DataType::Float64),
+        })
+    }
+    fn invoke_with_args(&self, args: ScalarFunctionArgs) -> Result<ColumnarValue> {
+        let gt = args.args[0].clone().into_array(1)?;
+        let (ga, gs) = export(&gt)?;
+        let alt = if args.args.len() > 1 { Some(export(&args.args[1].clone().into_array(gt.len())?)?) } else { None };
+        let (ap, sp) = match &alt {
+            Some((a, s)) => (a as *const FFI_ArrowArray, s as *const FFI_ArrowSchema),
+            None => (std::ptr::null(), std::ptr::null()),
+        };
+        let (mut oa, mut os) = (FFI_ArrowArray::empty(), FFI_ArrowSchema::empty());
+        check(unsafe { ffi::bioscan_udf_vcf_allele_stats(&ga, &gs, ap, sp, self.which, DEVICE, &mut oa, &mut os) })?;
+        import(oa, os)
+    }
+}
+fn allele_sig(two_arg: bool) -> Signature {
+    if two_arg {
+        Signature::one_of(vec![Exact(vec![list_of(DataType::Utf8)]), Exact(vec![list_of(DataType::Utf8), DataType::Utf8])], Volatility::Immutable)
+    } else {
+        Signature::exact(vec![list_of(DataType::Utf8)], Volatility::Immutable)
+    }
+}
+pub fn vcf_an_udf() -> ScalarUDF {
+    ScalarUDF::from(AlleleStat { signature: allele_sig(false), which: 0 })
+}
+pub fn vcf_ac_udf() -> ScalarUDF {
+    ScalarUDF::from(AlleleStat { signature: allele_sig(true), which: 1 })
+}
+pub fn vcf_af_udf() -> ScalarUDF {
+    ScalarUDF::from(AlleleStat { signature: allele_sig(true), which: 2 })
+}
+
+/// `register_vcf_udfs` (bio-format-vcf/src/udfs.rs:976-986): every UDF of the reference under its name.
 pub fn register_vcf_udfs(ctx: &datafusion::prelude::SessionContext) {
+    ctx.register_udf(vcf_an_udf());
+    ctx.register_udf(vcf_ac_udf());
+    ctx.register_udf(vcf_af_udf());
     ctx.register_udf(list_avg_udf());
     ctx.register_udf(list_gte_udf());
     ctx.register_udf(list_lte_udf());

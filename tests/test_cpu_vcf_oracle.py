@@ -237,3 +237,20 @@ def test_csi_index_contributes_names_only():
     assert b"bio.vcf.contigs.indexed" not in o2.schema.metadata
     _, batches = o2.execute(o2.scan())
     assert sum(b.num_rows for b in batches) == 1000
+
+
+def test_allele_stat_kats():
+    """vcf_an / vcf_ac / vcf_af of the oracle against the reference's unit tests (udfs.rs:1165-1562)."""
+    import allele_stat_cases as K
+    for s, want in K.PARSE_KATS:
+        assert V.parse_gt_alleles(s) == want, s
+    for s, want in K.ALT_KATS:
+        assert V.count_alt_alleles(s) == want, s
+    for name, rows, alt, an, ac, af in K.STAT_KATS:
+        gt, alt_arr = K.arrays(rows, alt)
+        assert V.vcf_an(gt).to_pylist() == an, name
+        assert V.vcf_ac(gt, alt_arr).to_pylist() == ac, name
+        got = V.vcf_af(gt, alt_arr).to_pylist()
+        assert len(got) == len(af), name
+        for g, w in zip(got, af):
+            assert len(g) == len(w) and all((a is None and b is None) or abs(a - b) < 0.001 for a, b in zip(g, w)), (name, g, w)
