@@ -255,10 +255,16 @@ void BgzfSource::report_k1_debug(const uint32_t* ctr_dev, uint32_t nb) {
   memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
   fprintf(stderr, "[bioscan] inflate: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
           h[2] ? (double)h[3] / h[2] : 0.0);
-  double tot = 0;
+  unsigned long long tx[2];
+  memcpy(tx, h + 28, sizeof tx);   // dbg + 26, dbg + 28: header parse alone, sync pass alone
+  double tot = (double)tx[0] + (double)tx[1];
   for (int i = 0; i < 5; i++) tot += (double)tc[i];
-  const char* nm[5] = {"header+tables", "stage", "count passes", "scan+write pass", "resolve"};
-  for (int i = 0; i < 5; i++) fprintf(stderr, "[bioscan]   %-16s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+  const char* nm[5] = {"table builds", "stage", "count + fix passes", "scan+write pass", "resolve"};
+  fprintf(stderr, "[bioscan]   %-18s %6.2f %% of wave cycles\n", "header parse", tot ? 100.0 * (double)tx[0] / tot : 0.0);
+  for (int i = 0; i < 5; i++) {
+    fprintf(stderr, "[bioscan]   %-18s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
+    if (i == 1) fprintf(stderr, "[bioscan]   %-18s %6.2f %% of wave cycles\n", "sync pass", tot ? 100.0 * (double)tx[1] / tot : 0.0);
+  }
   fprintf(stderr, "[bioscan]   write mini-rounds %u (%.2f per round), lanes idle behind END-OF-BLOCK %.1f per round, %u mini-rounds through HBM\n", h[24], h[2] ? (double)h[24] / h[2] : 0.0,
           h[2] ? (double)h[25] / h[2] : 0.0, h[26]);
   fprintf(stderr, "[bioscan]   LZ77 matches %u (%.1f per round), %.1f %% with a source inside the round's window\n", h[14], h[2] ? (double)h[14] / h[2] : 0.0,

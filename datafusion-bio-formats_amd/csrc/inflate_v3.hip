@@ -1085,6 +1085,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
           V3_SYNC();
         }
       }
+      TOCK(5);
       if (v3_build(L, L.b.lens, 288, L.lit_fast, 0u, V3_LIT_BITS, V3_LIT_SUB, L.b.lit_sorted, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
       if (v3_build(L, L.b.lens + 288, 32, L.dist_fast, (1u << V3_LIT_BITS) + V3_LIT_SUB, V3_DIST_BITS, V3_DIST_SUB, L.b.dist_sorted, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
       P = ub_bitpos(in);
@@ -1139,6 +1140,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
           const uint32_t room = (uint32_t)lane * subb;
           const uint32_t ov = room < ovb ? room : ovb;
           start = v3_sync(L, bnd - ov, bnd, limit, gsrc);   // first symbol start at / after the lane's boundary (speculative)
+          TOCK(6);
           if (start >= limit) { end = start; }               // (a symbol that spans the whole sub-stream: the lane owns nothing)
           ovf = v3_count(L, start < limit, start, limit, gsrc, ck, lane, end, acc, flags, cn);
         }
@@ -1282,6 +1284,8 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
     atomicAdd(&dbg[0], dbg_rounds);
     atomicAdd(&dbg[1], dbg_passes);
     for (int i = 0; i < 5; i++) atomicAdd((unsigned long long*)(dbg + 2) + i, tc[i]);
+    atomicAdd((unsigned long long*)(dbg + 26), tc[5]);
+    atomicAdd((unsigned long long*)(dbg + 28), tc[6]);
     atomicAdd(&dbg[12], dbg_matches);
     atomicAdd(&dbg[13], dbg_near);
     atomicAdd(&dbg[22], dbg_minis);
