@@ -204,6 +204,7 @@ void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members
   }
   if (c.scratch.n < need) c.scratch.alloc(need);
   if (c.status.n < max_members) c.status.alloc(std::max<uint32_t>(max_members, 1));
+  if (env_knobs().k1_preheaders && c.pre.n < (size_t)max_members * V3_PRE_DWORDS) c.pre.alloc((size_t)std::max<uint32_t>(max_members, 1) * V3_PRE_DWORDS);
 }
 
 void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status) {
@@ -211,9 +212,12 @@ void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* ds
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
   if (c.n_slots) HIP_CHECK(hipMemsetAsync(status, 0xFF, (size_t)nb * 4, c.stream));  // a member no bounded wave took reads as an error
+  // K0: the first block header of every member, one member per lane, ahead of K1 on the same stream
+  const bool k0 = c.pre.p && (size_t)nb * V3_PRE_DWORDS <= c.pre.n;
+  if (k0) launch_bgzf_headers(img.comp_base, img.d_coff.p + b0, nb, c.pre.p, c.stream);
   launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
                          env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,
-                         (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw);
+                         (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw, k0 ? c.pre.p : nullptr);
 }
 void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0) {
   launch_inflate_to(c, img, dst, nb, b0, c.status.p);

@@ -31,6 +31,7 @@ struct K1Ctx {
   // several launches of one context may be in flight at once
   DevBuf<uint32_t> slots;
   uint32_t n_slots = 0;
+  DevBuf<uint32_t> pre;     // K0's header records of the members of one launch (V3_PRE_DWORDS each); empty = K0 off
   K1Ctx() = default;
   K1Ctx(const K1Ctx&) = delete;
   K1Ctx& operator=(const K1Ctx&) = delete;

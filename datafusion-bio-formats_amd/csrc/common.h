@@ -75,6 +75,7 @@ struct EnvKnobs {
   bool chunk_members_device_set = false;
   uint32_t chunk_members_lookahead = 65536;  // ... with the look-ahead inflate on: small enough to pipeline
   int lookahead = 0;      // BIOSCAN_LOOKAHEAD=1: inflate of chunk c + 1 overlapped with the other stages of chunk c (measured: no gain)
+  int k1_preheaders = 0;  // BIOSCAN_K1_PREHEADERS=1: K0 (inflate_headers.hip) parses the first block header of every member ahead of K1 (measured: time-neutral)
   int k1_oneshot = 1;     // BIOSCAN_K1_ONESHOT=0: look-ahead launches keep K1's persistent grid
   int k1_bounded_wpw = 4; // BIOSCAN_K1_BOUNDED_WPW=1: one-wave workgroups in bounded launches
   int k1_slots_pct = 200; // BIOSCAN_K1_SLOTS_PCT: scratch strides of a bounded context, percent of what the device holds at once

@@ -113,6 +113,7 @@ struct __attribute__((aligned(16))) V3Lds {
   uint16_t null_slot[7];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v3_pass)
   uint16_t eob_fix;       // bits a lane over-consumed when it followed the end-of-block pointer (see E_EOB)
   uint32_t bnd_slot, bnd_budget;  // bounded launches: the scratch stride this wave borrowed, members it may still take
+  uint32_t pre_lo, pre_hi;        // K0's records (address, or 0), parked here for the same reason as blk_final
   uint32_t blk_final;             // BFINAL of the block being decoded (kept here, not in a register: the kernel is at its SGPR limit)
 #ifdef V3_PAD_LDS
   uint32_t pad_lds[V3_PAD_LDS / 4];  // occupancy experiment only
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
                                                            uint32_t n_blocks, uint32_t* __restrict__ status,
                                                            uint32_t* counter, unsigned long long* scratch,
                                                            uint32_t scratch_stride, uint32_t* dbg, uint32_t* slots, uint32_t n_slots,
-                                                           uint32_t per_wave) {
+                                                           uint32_t per_wave, const uint32_t* __restrict__ pre) {
   __shared__ V3Lds L_all[WPW];
   V3Lds& L = L_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
@@ -919,6 +920,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
     if (lane < 32) { len_base_extra((uint32_t)lane, &base, &eb); L.be_lut[lane] = lane > 28 ? 0u : base; }
     else { dist_base_extra((uint32_t)lane - 32u, &base, &eb); L.be_lut[lane] = lane - 32 > 29 ? 0u : base; }
     if (lane < 7) L.null_slot[lane] = (uint16_t)(E_SUB | (((V3_NULL_BASE >> 1) + (uint32_t)lane) << 4));
+    if (lane == 0) { L.pre_lo = (uint32_t)(uintptr_t)pre; L.pre_hi = (uint32_t)((uintptr_t)pre >> 32); }
   }
   V3_SYNC();
 
@@ -984,7 +986,29 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
         if (bfinal) break;
         continue;
       }
-      if (btype == 1) {
+      // A member's first block header may have been parsed by K0 (inflate_headers.hip, one member per lane): the bits the
+      // header took and the 320 code lengths as nibbles.  A record K0 did not mark usable means "parse it here".
+      uint32_t pre_bits = 0;
+      const uint32_t* pr = nullptr;
+      if (first_block && btype == 2) {
+        pr = (const uint32_t*)((uint64_t)uni2(L.pre_lo) | (uint64_t)uni2(L.pre_hi) << 32);
+        if (pr) {
+          pr += (size_t)b * V3_PRE_DWORDS;
+          if (uni2(pr[0]) & 1u) pre_bits = uni2(pr[1]);
+        }
+      }
+      if (pre_bits) {
+        if (lane < 40) {
+          const uint32_t w = pr[2 + lane];
+          uint32_t lo = w & 0xFFFFu, hi = w >> 16;  // 8 nibbles -> 8 bytes
+          lo = (lo | (lo << 8)) & 0x00FF00FFu; lo = (lo | (lo << 4)) & 0x0F0F0F0Fu;
+          hi = (hi | (hi << 8)) & 0x00FF00FFu; hi = (hi | (hi << 4)) & 0x0F0F0F0Fu;
+          ((uint32_t*)L.b.lens)[2 * lane] = lo;
+          ((uint32_t*)L.b.lens)[2 * lane + 1] = hi;
+        }
+        V3_SYNC();
+        ub_init(in, base32, skew + pre_bits, lane);
+      } else if (btype == 1) {
         for (int i = lane; i < 320; i += WAVE) {
           uint8_t l;
           if (i < 144) l = 8; else if (i < 256) l = 9; else if (i < 280) l = 7; else if (i < 288) l = 8; else l = 5;
@@ -1314,7 +1338,8 @@ int v3_resident_wg_per_cu() {
 }
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
-                            uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots, uint32_t n_slots, uint32_t per_wave, uint32_t wpw) {
+                            uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots, uint32_t n_slots, uint32_t per_wave, uint32_t wpw,
+                            const uint32_t* pre) {
   if (!n_blocks) return;
   if (wpw != 1) wpw = V3_BOUNDED_WPW;
   (void)hipMemsetAsync(counter, 0, 4, st);
@@ -1325,15 +1350,15 @@ void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const
     const uint32_t g = (n_blocks + per_wg - 1) / per_wg;
     if (wpw == 1)
       hipLaunchKernelGGL((k_bgzf_inflate_v3<1, true>), dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
-                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave);
+                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave, pre);
     else
       hipLaunchKernelGGL((k_bgzf_inflate_v3<V3_BOUNDED_WPW, true>), dim3(g), dim3(WAVE * V3_BOUNDED_WPW), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
-                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave);
+                         status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave, pre);
   } else {
     uint32_t g = grid < n_blocks ? grid : n_blocks;
     g = (g + V3_WAVES_PER_WG - 1) / V3_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V3_WAVES_PER_WG strides
     hipLaunchKernelGGL((k_bgzf_inflate_v3<V3_WAVES_PER_WG, false>), dim3(g), dim3(WAVE * V3_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
-                       status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, nullptr, 0u, 0u);
+                       status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, dbg, nullptr, 0u, 0u, pre);
   }
 #ifdef V3_GUARD
   v3_guard_report();

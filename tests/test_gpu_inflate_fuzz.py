@@ -157,3 +157,19 @@ def test_invalid_code_length_sets_are_rejected(pkg):
             zlib.decompress(body, -15)
         with pytest.raises(pkg.BioscanError):
             pkg.bgzf_inflate(m + eof)
+
+
+def test_header_prepass_opt_in():
+    """BIOSCAN_K1_PREHEADERS=1 (K0, inflate_headers.hip: the first block header of every member parsed one member per lane
+    ahead of K1; off by default): the cases of this file once more, in ONE child process started with
+    the knob set (the library reads its knobs once per process)."""
+    import subprocess
+    import sys
+    if os.environ.get("BIOSCAN_K1_PREHEADERS") == "1":
+        pytest.skip("already running with the knob set")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BIOSCAN_K1_PREHEADERS="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_inflate_fuzz.py"), os.path.join(root, "tests", "test_gpu_bam_edge_cases.py"),
+                          "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
