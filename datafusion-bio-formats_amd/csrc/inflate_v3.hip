@@ -913,6 +913,23 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
   unsigned long long t0 = 0;
 #define TICK() (t0 = dbg ? clock64() : 0)
 #define TOCK(i) do { if (dbg) { unsigned long long t1 = clock64(); tc[i] += t1 - t0; t0 = t1; } } while (0)
+  // Compile-time experiment (tools/build_variant.sh): s_setprio around one phase, so that the SIMD's issue arbiter prefers the
+  // waves that are in it.  V3_PRIO_DECODE / _WRITE / _RESOLVE = priority (1..3) of that phase, 0 elsewhere.
+#ifdef V3_PRIO_DECODE
+#define PRIO_DECODE(on) __builtin_amdgcn_s_setprio((on) ? V3_PRIO_DECODE : 0)
+#else
+#define PRIO_DECODE(on) do {} while (0)
+#endif
+#ifdef V3_PRIO_WRITE
+#define PRIO_WRITE(on) __builtin_amdgcn_s_setprio((on) ? V3_PRIO_WRITE : 0)
+#else
+#define PRIO_WRITE(on) do {} while (0)
+#endif
+#ifdef V3_PRIO_RESOLVE
+#define PRIO_RESOLVE(on) __builtin_amdgcn_s_setprio((on) ? V3_PRIO_RESOLVE : 0)
+#else
+#define PRIO_RESOLVE(on) do {} while (0)
+#endif
 
   // base / extra-bit LUT of the length and distance symbols (RFC 1951 3.2.5), once per wave
   {
@@ -1154,6 +1171,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
         const uint64_t wb = P >> 5;
         v3_gsrc_t gsrc = (v3_gsrc_t)(base32 + wb);
         TOCK(1);
+        PRIO_DECODE(1);
         const uint32_t rel0 = (uint32_t)(P & 31);
         const uint32_t bnd = rel0 + (uint32_t)lane * subb;
         const uint32_t limit = rel0 + (uint32_t)(lane + 1) * subb;
@@ -1192,6 +1210,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
           continue;
         }
         force_dw = 0;
+        PRIO_DECODE(0);
         TOCK(2);
         const unsigned long long stopm = __ballot(flags != 0);
         const int last = stopm ? __builtin_ctzll(stopm) : 63;
@@ -1259,6 +1278,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
             uint32_t f2 = 0;
             const uint32_t tb0 = st0 & 0xFFFu, mb0 = (st0 >> 12) & 15u, ml0 = st0 >> 16;
 #ifndef V3_ABLATE_WRITE
+            PRIO_WRITE(1);
             if (use_win) f2 = v3_write<2>(L, has, p0, tb0, mb0, ml0, o_limit, p1, out, my_opos, mlist, my_mabs - M0, R, gsrc);
 #ifdef V3_GUARD
             else f2 = v3_write<1>(L, has, p0, tb0, mb0, ml0, o_limit, p1, out, my_opos, mlist, my_mabs - M0, isize, gsrc);
@@ -1266,13 +1286,16 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
             else f2 = v3_write<1>(L, has, p0, tb0, mb0, ml0, o_limit, p1, out, my_opos, mlist, my_mabs - M0, R, gsrc);
 #endif
 #endif
+            PRIO_WRITE(0);
             dbg_minis++;
             if (__ballot(f2 & F_BAD) != 0ull) { st = INF_BAD_DIST; break; }
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           TOCK(3);
 #ifndef V3_ABLATE_RESOLVE
+          PRIO_RESOLVE(1);
           v3_resolve(L, out, mlist, lane, R, out_s, m_s, use_win, dbg != nullptr, dbg_matches, dbg_near);
+          PRIO_RESOLVE(0);
 #endif
           TOCK(4);
         }
