@@ -1318,6 +1318,10 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
       if (bfinal) break;
     }
     if (st == INF_OK && opos != isize) st = INF_SIZE_MISMATCH;
+    // every block header and every symbol must lie inside the member's payload (libdeflate: reading past the input is bad
+    // data): a member whose last block lost its BFINAL bit would otherwise go on into the trailer, which may parse as one
+    // more, empty, final block
+    if (st == INF_OK && P > end_bits) st = INF_OVERRUN | (4u << 8);
 #if defined(V3_ABLATE_WRITE) || defined(V3_ABLATE_RESOLVE)
     st = INF_OK;  // timing-only build: the bytes are wrong on purpose
 #endif

@@ -89,6 +89,47 @@ def test_corrupt_members_are_rejected(pkg):
         pkg.bgzf_inflate(b"\x1f\x8b\x08\x00" + bytes(40))
 
 
+def test_member_whose_last_block_is_not_final_is_rejected(pkg):
+    """A member whose only block has BFINAL = 0 and ends exactly where the payload ends: a decoder that goes on reads the
+    trailer.  The payload is chosen so that its CRC32 field parses as one more block -- BFINAL = 1, fixed Huffman, END-OF-BLOCK
+    at once (low ten bits 0b0000000_01_1) -- and ISIZE and CRC32 are right, so only "every block header lies inside the
+    payload" rejects it (libdeflate: reading past the input is bad data; zlib: incomplete stream).  Found by
+    tools/fuzz_k1_corrupt.py (seed 12, case 273: a flipped BFINAL bit)."""
+    import deflate_build as db
+    tail = bytes([200, 201, 202, 203, 204, 205])          # six 9-bit literals: 3 + 8 a + 9 * 6 + 7 bits = whole bytes
+    k = 0
+    while True:
+        payload = b"not final %08d " % k + tail
+        if zlib.crc32(payload) & 0x3FF == 0x003:
+            break
+        k += 1
+    w = db.BitWriter()
+    w.bits(0, 1)                                            # BFINAL = 0
+    w.bits(1, 2)                                            # fixed Huffman
+    for byte in payload:
+        if byte < 144:
+            w.code(0x30 + byte, 8)
+        else:
+            w.code(0x190 + byte - 144, 9)
+    w.code(0, 7)                                            # END-OF-BLOCK
+    assert w.n == 0                                         # the block ends on a byte boundary
+    body = w.finish()
+    with pytest.raises(zlib.error):
+        zlib.decompress(body, -15)
+    assert zlib.decompressobj(-15).decompress(body) == payload   # ... although every byte comes out
+    total = 18 + len(body) + 8
+    bad = (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", total - 1) + body +
+           struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    with pytest.raises(pkg.BioscanError):
+        pkg.bgzf_inflate(bad + eof)
+    # the same block marked final is a valid member
+    good_body = bytes([body[0] | 1]) + body[1:]
+    good = bad[:18] + good_body + bad[18 + len(body):]
+    got, _ = pkg.bgzf_inflate(good + eof)
+    assert bytes(got) == payload
+
+
 def test_inflate_handcrafted_huffman_codes(pkg, oracle):
     """Dynamic blocks whose code lengths zlib's encoder never picks (tests/deflate_build.py): complete but wildly
     skewed trees with 15-bit literal/length and distance codes (9-bit second-level distance tables), unused symbols
