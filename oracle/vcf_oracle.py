@@ -402,8 +402,12 @@ _MISSING = object()   # bare non-flag key ("missing value" error that the refere
 FLAG = object()
 
 
-def parse_info_fields(info: str, infos: dict):
-    """-> [(key, value)] in file order; value is FLAG, None ('.'), a scalar, a list, or _MISSING."""
+def parse_info_fields(info: str, infos: dict, selected=None, strict: bool = True, stop_at=None):
+    """-> [(key, value)] in file order; value is FLAG, None ('.'), a scalar, a list, or _MISSING.
+    noodles' `info.iter(header)` types EVERY entry by the header as it goes (physical_exec.rs:561-571: an error in any entry
+    is the record's error), whether or not the caller wants that key.  strict=False restates the product's documented
+    deviation instead: an entry whose key is not in `selected` is skipped unparsed.
+    stop_at: stop behind the first entry with this key (`Info::get`, used for END)."""
     if info == "." or info == "":
         return []
     out = []
@@ -411,6 +415,8 @@ def parse_info_fields(info: str, infos: dict):
         if ent == "":
             continue
         key, sep, raw = ent.partition("=")
+        if not strict and selected is not None and key not in selected:
+            continue
         d = infos.get(key)
         number, ty = (d.number, d.type) if d is not None else ("1", "String")
         if not sep:
@@ -440,13 +446,16 @@ def parse_info_fields(info: str, infos: dict):
                 raise VcfError(f"Unsupported INFO value type for field '{key}'")
             else:
                 out.append((key, [None if p == "." else _percent_decode(p) for p in parts]))
+        if stop_at is not None and key == stop_at:
+            break
     return out
 
 
 class Rec:
-    __slots__ = ("f", "chrom", "pos", "_info")
+    __slots__ = ("f", "chrom", "pos", "_info", "sel", "strict")
 
-    def __init__(self, line: str):
+    def __init__(self, line: str, selected_info=None, strict: bool = True):
+        self.sel, self.strict = selected_info, strict
         f = line.split("\t")
         if len(f) < 8:
             raise VcfError("VCF read error: invalid record")
@@ -454,18 +463,33 @@ class Rec:
         self.chrom = f[0]
         if f[1] == "0":
             raise VcfError("Missing variant start")
-        self.pos = int(f[1])
+        # noodles parses POS as usize (Rust's from_str: digits with an optional leading '+', no '-', no blanks, no '_')
+        digits = f[1][1:] if f[1][:1] == "+" else f[1]
+        if not digits or not digits.isascii() or not digits.isdigit():
+            raise VcfError(f"VCF read error: invalid position {f[1]!r}")
+        self.pos = int(digits)
+        if self.pos > 0xFFFFFFFF:
+            # the reference casts the usize to u32 (`get() as u32`, physical_exec.rs:762): a position that does not fit
+            # would silently wrap; both the product and this restatement refuse it
+            raise VcfError(f"VCF read error: invalid position {f[1]!r}")
         self._info = None
 
     def info(self, infos):
         if self._info is None:
-            self._info = parse_info_fields(self.f[7], infos)
+            self._info = parse_info_fields(self.f[7], infos, self.sel, self.strict)
         return self._info
 
     def variant_end(self, infos) -> int:
-        for k, v in self.info(infos):
-            if k == "END" and isinstance(v, int):
-                return v
+        # noodles `variant_end`: `info.get(header, "END")` walks the entries, typing each, up to the first END
+        if self.strict:
+            ents = self._info if self._info is not None else parse_info_fields(self.f[7], infos, stop_at="END")
+        else:
+            ents = parse_info_fields(self.f[7], infos, {"END"}, False, stop_at="END")
+        for k, v in ents:
+            if k == "END":
+                if isinstance(v, int):
+                    return v
+                break
         return self.pos + len(self.f[3]) - 1
 
 
@@ -503,8 +527,11 @@ def render_gt(raw: str) -> str:
     return "".join(out)
 
 
-def parse_sample_values(fmt_keys, sample: str, formats: dict):
-    """-> [(key, value)]; value None for '.', python scalar / list otherwise; GT -> rendered string tagged."""
+def parse_sample_values(fmt_keys, sample: str, formats: dict, selected=None, strict: bool = True):
+    """-> [(key, value)]; value None for '.', python scalar / list otherwise; GT -> rendered string tagged.
+    `sample.iter(header)` types every value of the sample (physical_exec.rs:1661-1666); a genotype stays lazy and is only
+    walked when GT is one of the selected fields (:1668-1676).  strict=False: values of unselected keys are not looked at
+    (the product's documented deviation)."""
     if sample == "." or sample == "":
         vals = []
     else:
@@ -514,8 +541,12 @@ def parse_sample_values(fmt_keys, sample: str, formats: dict):
         if raw == ".":
             out.append((key, None))
             continue
+        unselected = selected is not None and key not in selected
         if key == "GT":
-            out.append((key, ("GT", render_gt(raw))))
+            out.append((key, None) if unselected else (key, ("GT", render_gt(raw))))
+            continue
+        if unselected and not strict:
+            out.append((key, None))
             continue
         d = formats.get(key)
         number, ty = (d.number, d.type) if d is not None else ("1", "String")
@@ -586,7 +617,11 @@ class VcfOracle:
     """Mirror of VcfTableProvider::new_with_samples + scan + VcfExec::execute on the CPU."""
 
     def __init__(self, path: str, info_fields=None, format_fields=None, samples=None, zero_based: bool = True,
-                 index_path: Optional[str] = "auto"):
+                 index_path: Optional[str] = "auto", strict_unselected: bool = True):
+        # strict_unselected=False: INFO entries / FORMAT values whose key is not selected are not validated (what the HIP
+        # path does; the reference's noodles iterators type every entry they pass)
+        self.strict_unselected = strict_unselected
+        self._lax_info, self._lax_fmt = set(), set()
         self.path = path
         self.zero_based = zero_based
         self.compression, self.u, self.blocks = _read_text_source(path)
@@ -798,7 +833,7 @@ class VcfOracle:
         infos = self.header.infos
         for (cb, ce) in tbi_query_chunks(self.tbi, idx, region.start, region.end):
             for _, line in self._lines_from(self._voff_abs(cb), self._voff_abs(ce)):
-                rec = Rec(line)
+                rec = self._rec(line)
                 if rec.chrom != region.chrom:
                     continue
                 if rec.pos <= e and rec.variant_end(infos) >= s:
@@ -812,17 +847,26 @@ class VcfOracle:
         fl["any_format"] = projection is None or any(i >= 8 + self.n_info for i in projection)
         return fl
 
-    def _core_row(self, rec: Rec):
-        f = rec.f
-        start = rec.pos - 1 if self.zero_based else rec.pos
-        return {
-            "chrom": rec.chrom, "start": start, "end": get_variant_end(rec, self.header.infos),
-            "id": "" if f[2] == "." else f[2], "ref": f[3], "alt": "" if f[4] == "." else f[4].replace(",", "|"),
-            "qual": None if f[5] == "." else parse_f32(f[5]), "filter": "" if f[6] == "." else f[6],
-        }
+    def _rec(self, line: str) -> Rec:
+        return Rec(line, set(self.info_fields) if self.strict_unselected else self._lax_info, self.strict_unselected)
 
-    def _info_row(self, rec: Rec):
-        """load_infos_single_pass -> list of per-field python values in self.info_fields order."""
+    def _core_row(self, rec: Rec, fl=None):
+        """The eight core columns, each only when the projection holds it (physical_exec.rs:800-822: noodles' record is lazy,
+        so a QUAL that does not parse, or an INFO entry in front of END, is an error only for a scan that asks for it)."""
+        f = rec.f
+        need = (lambda k: True) if fl is None else (lambda k: fl[k])
+        row = {"chrom": rec.chrom, "start": rec.pos - 1 if self.zero_based else rec.pos,
+               "id": "" if f[2] == "." else f[2], "ref": f[3], "alt": "" if f[4] == "." else f[4].replace(",", "|"),
+               "filter": "" if f[6] == "." else f[6]}
+        row["end"] = get_variant_end(rec, self.header.infos) if need("end") else None
+        row["qual"] = (None if f[5] == "." else parse_f32(f[5])) if need("qual") else None
+        return row
+
+    def _info_row(self, rec: Rec, projected=None):
+        """load_infos_single_pass -> list of per-field python values in self.info_fields order.
+        projected: indices (into info_fields) of the INFO columns the batch will hold (None = all).  A key that occurs twice
+        is appended twice to its builder (:572-575), which leaves THAT column one row longer than the others: the batch
+        cannot be assembled if the column is part of it (RecordBatch::try_new), and nobody notices if it is not."""
         h = self.header
         types = [info_to_arrow_type(h.infos, t) for t in self.info_fields]
         idx_of = {t: i for i, t in enumerate(self.info_fields)}
@@ -835,7 +879,9 @@ class VcfOracle:
             if i is None:
                 continue
             if populated[i]:
-                raise VcfError(f"duplicate INFO key {key} (the reference appends twice and misaligns rows)")
+                if projected is None or i in projected:
+                    raise VcfError(f"duplicate INFO key {key} (the reference appends twice and misaligns rows)")
+                continue
             populated[i] = True
             t = types[i]
             if v is FLAG:
@@ -880,7 +926,7 @@ class VcfOracle:
             oi = out_of_header.get(hi)
             if oi is None:
                 continue
-            for key, v in parse_sample_values(keys, s, h.formats):
+            for key, v in parse_sample_values(keys, s, h.formats, set(self.format_fields) if self.strict_unselected else self._lax_fmt, self.strict_unselected):
                 i = field_idx.get(key)
                 if i is None:
                     continue
@@ -960,7 +1006,7 @@ class VcfOracle:
         if not samples:
             return None  # no sample iterated: nothing appended (would misalign rows in the reference)
         field_idx = {t: i for i, t in enumerate(self.format_fields)}
-        for key, v in parse_sample_values(keys, samples[0], h.formats):
+        for key, v in parse_sample_values(keys, samples[0], h.formats, set(self.format_fields) if self.strict_unselected else self._lax_fmt, self.strict_unselected):
             i = field_idx.get(key)
             if i is None:
                 continue
@@ -996,9 +1042,9 @@ class VcfOracle:
         rows = []
         total = 0
         for rec in recs:
-            row = self._core_row(rec)
-            if fl["any_info"]:
-                row["_info"] = self._info_row(rec)
+            row = self._core_row(rec, fl)
+            if fl["any_info"] and self.n_info:          # load_infos_single_pass returns at once without builders (:552-555)
+                row["_info"] = self._info_row(rec, None if projection is None else {i - 8 for i in projection if 8 <= i < 8 + self.n_info})
             if has_format and fl["any_format"]:
                 row["_fmt"] = self._format_multi_row(rec) if multi else self._format_single_row(rec)
             rows.append(row)
@@ -1038,10 +1084,21 @@ class VcfOracle:
 
     def execute(self, plan, partition: int = 0, batch_size: int = 8192):
         projection, limit = plan["projection"], plan["limit"]
+        # strict_unselected=False looks only at the keys of PROJECTED columns (a multi-sample `genotypes` column holds every
+        # selected FORMAT field)
+        self._lax_info = set(self.info_fields if projection is None else
+                             [self.info_fields[i - 8] for i in projection if 8 <= i < 8 + self.n_info])
+        if len(self.source_samples) > 1:
+            any_fmt = projection is None or any(i >= 8 + self.n_info for i in projection)
+            self._lax_fmt = set(self.format_fields) if any_fmt else set()
+        else:
+            self._lax_fmt = set(self.format_fields if projection is None else
+                                [self.format_fields[i - 8 - self.n_info] for i in projection
+                                 if 8 + self.n_info <= i < 8 + self.n_info + len(self.format_fields)])
         if plan["kind"] == "empty":
             return self.projected_schema(projection), []
         if plan["kind"] == "sequential":
-            recs = (Rec(t) for _, t in self._lines_from(self.data_start))
+            recs = (self._rec(t) for _, t in self._lines_from(self.data_start))
             return self._batches(recs, projection, batch_size, limit)
         residual = plan["residual"]
         if self.tbi is None:  # physical_exec.rs:2766-2768

@@ -254,3 +254,58 @@ def test_allele_stat_kats():
         assert len(got) == len(af), name
         for g, w in zip(got, af):
             assert len(g) == len(w) and all((a is None and b is None) or abs(a - b) < 0.001 for a, b in zip(g, w)), (name, g, w)
+
+
+def test_lazy_columns_follow_the_reference(tmp_path):
+    """noodles' record is lazy and the reference asks it per projected column (physical_exec.rs:758-823): a QUAL that does not
+    parse, an INFO entry that does not parse, a genotype that does not parse are errors only for a scan that asks for that
+    column -- INFO as a whole (every entry is typed once any INFO column is asked for and at least one INFO field is selected,
+    :552-571), a FORMAT value as a whole per selected sample (:1661-1666), a genotype only when GT is a selected field
+    (:1668-1676); a key that occurs twice breaks only the batch that holds its column (:572-575)."""
+    hdr = ("##fileformat=VCFv4.3\n##contig=<ID=c,length=1000>\n"
+           '##INFO=<ID=DP,Number=1,Type=Integer,Description="d">\n##INFO=<ID=MQ,Number=1,Type=Float,Description="m">\n'
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">\n'
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="q">\n'
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\n")
+
+    def scan(body, names, **kw):
+        p = tmp_path / "t.vcf"
+        p.write_text(hdr + body)
+        o = V.VcfOracle(str(p), **kw)
+        proj = None if names is None else [o.schema.get_field_index(n) for n in names]
+        plan = o.scan(projection=proj, filters=[], limit=None, target_partitions=1)
+        return o.execute(plan, 0, 100)[1]
+
+    bad_qual = "c\t5\t.\tA\tT\tabc\t.\tDP=1\tGT:GQ\t0/1:5\n"
+    assert scan(bad_qual, ["chrom", "start", "DP"])[0].num_rows == 1
+    with pytest.raises(ValueError):
+        scan(bad_qual, ["qual"])
+    bad_info = "c\t5\t.\tA\tT\t1\t.\tDP=1;MQ=--\tGT:GQ\t0/1:5\n"
+    assert scan(bad_info, ["chrom", "qual", "GT"])[0].num_rows == 1                  # no INFO column asked for
+    assert scan(bad_info, None, info_fields=[])[0].num_rows == 1                      # no INFO field selected: no builders
+    for names in (["DP"], ["MQ"], None):
+        with pytest.raises((V.VcfError, ValueError)):
+            scan(bad_info, names)                                                     # every entry is typed
+    with pytest.raises((V.VcfError, ValueError)):
+        scan(bad_info, ["DP"], info_fields=["DP"])                                    # ... selected or not
+    assert scan(bad_info, ["DP"], info_fields=["DP"], strict_unselected=False)[0].num_rows == 1   # the product's rule
+    # END sits in front of the entry that does not parse: `end` only walks up to END
+    assert scan("c\t5\t.\tAC\tT\t1\t.\tEND=9;MQ=--\tGT:GQ\t0/1:5\n", ["end"])[0].column(0).to_pylist() == [9]
+    with pytest.raises((V.VcfError, ValueError)):
+        scan("c\t5\t.\tAC\tT\t1\t.\tMQ=--;END=9\tGT:GQ\t0/1:5\n", ["end"])
+    bad_gt = "c\t5\t.\tA\tT\t1\t.\tDP=1\tGT:GQ\t0/x:5\n"
+    assert scan(bad_gt, None, format_fields=["GQ"])[0].num_rows == 1                  # GT not selected: never walked
+    with pytest.raises(V.VcfError):
+        scan(bad_gt, None, format_fields=["GT"])
+    bad_gq = "c\t5\t.\tA\tT\t1\t.\tDP=1\tGT:GQ\t0/1:5x\n"
+    with pytest.raises((V.VcfError, ValueError)):
+        scan(bad_gq, None, format_fields=["GT"])                                      # a value of the sample is typed anyway
+    assert scan(bad_gq, None, format_fields=["GT"], strict_unselected=False)[0].num_rows == 1
+    dup = "c\t5\t.\tA\tT\t1\t.\tDP=1;DP=2;MQ=3\tGT:GQ\t0/1:5\n"
+    assert scan(dup, ["MQ"])[0].column(0).to_pylist() == [3.0]
+    with pytest.raises(V.VcfError):
+        scan(dup, ["DP"])
+    for pos in ("-5", "x", "", "12a", "4294967296"):
+        with pytest.raises(V.VcfError):
+            scan(f"c\t{pos}\t.\tA\tT\t1\t.\tDP=1\tGT:GQ\t0/1:5\n", ["chrom"])
+    assert scan("c\t+5\t.\tA\tT\t1\t.\tDP=1\tGT:GQ\t0/1:5\n", ["start"])[0].column(0).to_pylist() == [4]

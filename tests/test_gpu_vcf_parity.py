@@ -667,3 +667,22 @@ def test_large_file_properties(pkg, tmp_path):
                 os.unlink(f)
             except OSError:
                 pass
+
+
+def test_differential_fuzz_of_whole_files(pkg, vo):
+    """tools/fuzz_vcf_parity.py, a fixed number of files of two seeds: random headers (every Number / Type), 0..5 samples,
+    missing values wherever the grammar allows them, escapes, lines spanning 150-byte BGZF members, one file in five with a
+    malformed record -- schema, plan and rows against the oracle under random selections, projections and batch sizes; a file
+    one side refuses the other refuses too (the one documented exception is counted: a malformed value under a key whose
+    column is not projected, which the reference's iterators would still type)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_vcf_parity as F
+    tot = dict(files=0, scans=0, rows=0, refused_by_both=0, read_under_product_rule=0)
+    for seed in (5, 6):
+        t, failures = F.run(pkg, seed=seed, max_files=60, verbose=False)
+        assert not failures, failures[:3]
+        for k in tot:
+            tot[k] += t[k]
+    assert tot["rows"] > 10000 and tot["refused_by_both"] > 5, tot
+    from conftest import report_size
+    report_size("test_differential_fuzz_of_whole_files", **tot)

@@ -1,0 +1,293 @@
+"""dev tool: differential fuzz of the VCF read path.  Random VCF files -- INFO definitions of every Number / Type the schema
+rules distinguish, FORMAT definitions, 0..5 samples, records with missing values in every position the grammar allows,
+percent escapes, multi-allelic ALT, symbolic alleles, END, lines that span BGZF members of 150 .. 65 280 bytes -- are
+scanned by the GPU provider and by oracle/vcf_oracle.py with random field selections, sample subsets, projections,
+coordinate systems and batch sizes; schemas, plans and every partition's rows are compared (tests/test_gpu_vcf_parity.py:
+_parity).  A file one side refuses must be refused by the other.  A share of the files carries one malformed record.
+usage: fuzz_vcf_parity.py [seconds=60] [seed=1]"""
+import os
+import random
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import test_gpu_vcf_parity as T  # noqa: E402
+import vcf_oracle as vo  # noqa: E402
+
+INFO_POOL = [("DP", "1", "Integer"), ("AN", "1", "Integer"), ("AC", "A", "Integer"), ("AF", "A", "Float"), ("AD", "R", "Integer"),
+             ("GL", "G", "Float"), ("MQ", "1", "Float"), ("DB", "0", "Flag"), ("SOMATIC", "0", "Flag"), ("GENE", "1", "String"),
+             ("CSQ", ".", "String"), ("LST", ".", "Integer"), ("FL2", "2", "Float"), ("END", "1", "Integer"), ("NOTE", "1", "String"),
+             ("IV3", "3", "Integer")]
+FORMAT_POOL = [("GT", "1", "String"), ("GQ", "1", "Integer"), ("DP", "1", "Integer"), ("AD", "R", "Integer"), ("PL", "G", "Integer"),
+               ("FT", "1", "String"), ("XF", "1", "Float"), ("HQ", "2", "Integer"), ("GL", "G", "Float"), ("TAGS", ".", "String")]
+BASES = "ACGT"
+
+
+def rint(rng):
+    return rng.choice(["0", "1", "7", "42", "99", "250", "1000", "65535", "-1", "-17", "2147483647", "-2147483648", "+5", "007",
+                       str(rng.randrange(-100000, 100000))])
+
+
+def rfloat(rng):
+    return rng.choice(["0", "0.5", "1e-3", "12.25", "0.1", "3.1e-42", "1E5", "-2.5", "100", ".5", "5.", "0.30000001", "1e38", "-0.0",
+                       "%.*g" % (rng.randrange(1, 12), rng.random() * 10 ** rng.randrange(-8, 8)), str(rng.randrange(0, 1000) / 7.0)])
+
+
+def rstr(rng):
+    return rng.choice(["x", "abc", "BRCA1", "a_b-c", "p.Val600Glu", "x%3By", "50%25", "a%2Cb", "a|b|c", "longer_value_of_some_length_0123456789",
+                       "".join(rng.choice("abcXYZ019_-|/()") for _ in range(rng.randrange(1, 30)))])
+
+
+def value(rng, typ):
+    return rint(rng) if typ == "Integer" else rfloat(rng) if typ == "Float" else rstr(rng)
+
+
+def values(rng, number, typ, n_alt, ploidy=2):
+    if number == "1":
+        n = 1
+    elif number == "A":
+        n = n_alt
+    elif number == "R":
+        n = n_alt + 1
+    elif number == "G":
+        n = (n_alt + 1) * (n_alt + 2) // 2
+    elif number == ".":
+        n = rng.randrange(1, 5)
+    else:
+        n = int(number)
+    if number != "1" and rng.random() < 0.1:
+        n = max(1, n + rng.choice([-1, 1]))          # the reference does not check a list's length against Number
+    out = [("." if rng.random() < 0.12 else value(rng, typ)) for _ in range(max(1, n))]
+    if rng.random() < 0.06:
+        return "."
+    return ",".join(out)
+
+
+def gt(rng, n_alt):
+    if rng.random() < 0.08:
+        return rng.choice([".", "./.", ".|."])
+    k = rng.choice([1, 2, 2, 2, 2, 3])
+    al = [("." if rng.random() < 0.05 else str(rng.randrange(0, n_alt + 1))) for _ in range(k)]
+    sep = rng.choice(["/", "|"])
+    s = sep.join(al) if rng.random() < 0.8 else "".join(a + rng.choice(["/", "|"]) for a in al)[:-1]
+    return s
+
+
+def make_vcf(rng, malformed):
+    contigs = ["chr1", "chr2", "21", "X"][:rng.randrange(1, 5)]
+    infos = rng.sample(INFO_POOL, rng.randrange(0, len(INFO_POOL) + 1))
+    fmts = rng.sample(FORMAT_POOL, rng.randrange(1, len(FORMAT_POOL) + 1))
+    n_samples = rng.choice([0, 0, 1, 2, 3, 5])
+    samples = [f"S{i}" for i in range(n_samples)]
+    hdr = ["##fileformat=VCFv4.3"]
+    for c in contigs:
+        hdr.append(f"##contig=<ID={c},length={rng.randrange(100000, 250000000)}>")
+    if rng.random() < 0.5:
+        hdr.append('##FILTER=<ID=q10,Description="Quality below 10">')
+    for k, n, t in infos:
+        hdr.append(f'##INFO=<ID={k},Number={n},Type={t},Description="{k} of the site">')
+    if n_samples:
+        for k, n, t in fmts:
+            hdr.append(f'##FORMAT=<ID={k},Number={n},Type={t},Description="{k} of the sample">')
+    cols = "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"
+    if n_samples:
+        cols += "\tFORMAT\t" + "\t".join(samples)
+    hdr.append(cols)
+    n_rec = rng.choice([0, 1, 3, 40, 300, 2000])
+    bad_at = rng.randrange(n_rec) if malformed and n_rec else -1
+    lines = []
+    for c in contigs:
+        pos = rng.randrange(1, 1000)
+        for r in range(n_rec // len(contigs) + 1):
+            pos += rng.randrange(0, 500)
+            ref = "".join(rng.choice(BASES) for _ in range(rng.choice([1, 1, 1, 2, 5, 30])))
+            n_alt = rng.choice([0, 1, 1, 1, 2, 3])
+            alts = []
+            for _ in range(n_alt):
+                alts.append(rng.choice(["".join(rng.choice(BASES) for _ in range(rng.choice([1, 1, 2, 8]))), "<DEL>", "*", "<INS:ME>", "N"]))
+            alt = ",".join(alts) if alts else "."
+            vid = rng.choice([".", ".", f"rs{rng.randrange(1, 10**9)}", f"rs{rng.randrange(1, 999)};id{rng.randrange(1, 99)}"])
+            qual = rng.choice([".", "60", "29.5", "0", rfloat(rng).lstrip("-+") or "1"])
+            filt = rng.choice([".", "PASS", "q10", "q10;s50"])
+            items = []
+            for k, n, t in infos:
+                if rng.random() < 0.45:
+                    continue
+                if t == "Flag":
+                    items.append(k)
+                elif k == "END":
+                    items.append(f"END={pos + rng.randrange(0, 5000)}")
+                else:
+                    items.append(f"{k}={values(rng, n, t, n_alt)}")
+            rng.shuffle(items)
+            info = ";".join(items) if items else "."
+            line = f"{c}\t{pos}\t{vid}\t{ref}\t{alt}\t{qual}\t{filt}\t{info}"
+            if n_samples:
+                keys = [f for f in fmts if rng.random() < 0.7] or [fmts[0]]
+                if any(k == "GT" for k, _, _ in keys):                     # GT comes first when present
+                    keys = [f for f in keys if f[0] == "GT"] + [f for f in keys if f[0] != "GT"]
+                cells = []
+                for _ in samples:
+                    vals = []
+                    for k, n, t in keys:
+                        vals.append(gt(rng, n_alt) if k == "GT" else values(rng, n, t, n_alt))
+                    cut = rng.choice([None, None, None, 1, 2])
+                    if cut is not None:
+                        vals = vals[:max(1, min(cut, len(vals)))]
+                    cells.append("." if rng.random() < 0.04 else ":".join(vals))
+                line += "\t" + ":".join(k for k, _, _ in keys) + "\t" + "\t".join(cells)
+            if len(lines) == bad_at:
+                kind = rng.randrange(6)
+                f = line.split("\t")
+                if kind == 0:
+                    f[1] = rng.choice(["x", "", "-5", "12a", "99999999999"])
+                elif kind == 1:
+                    f = f[:rng.randrange(1, 8)]
+                elif kind == 2 and infos:
+                    k, n, t = infos[0]
+                    f[7] = f"{k}=" + ("1x" if t == "Integer" else "--" if t == "Float" else "\x01") if t != "Flag" else f"{k}=1"
+                elif kind == 3 and n_samples:
+                    f[9] = "0/x" if "GT" in f[8].split(":")[:1] else "1x"
+                elif kind == 4:
+                    f[5] = rng.choice(["abc", "1..2", "--1"])
+                else:
+                    f[7] = "DP=1;DP=2" if any(k == "DP" for k, _, _ in infos) else f[7] + ";;"
+                line = "\t".join(f)
+            lines.append(line)
+    return "\n".join(hdr + lines) + "\n", [k for k, _, _ in infos], [k for k, _, _ in fmts] if n_samples else [], samples
+
+
+class _Lax:
+    """vcf_oracle with VcfOracle(strict_unselected=False), for T._parity"""
+    def __init__(self, mod):
+        self._m = mod
+
+    def __getattr__(self, k):
+        return getattr(self._m, k)
+
+    def VcfOracle(self, path, **kw):
+        return self._m.VcfOracle(path, strict_unselected=False, **kw)
+
+
+def run(pkg, seconds=60.0, seed=1, max_files=None, verbose=True):
+    """-> (totals dict, list of divergences)"""
+    rng = random.Random(seed)
+    t0 = time.time()
+    n_files = n_rows = n_refused = n_scans = n_lax = 0
+    failures = []
+    keep_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "fuzz_vcf_cases")
+
+    def diverged(what, ctx, names, detail, path):
+        failures.append((what, ctx, names, detail))
+        print("DIVERGENCE:", what, ctx, names, detail[:400], flush=True)
+        if len(failures) <= 6:
+            os.makedirs(keep_dir, exist_ok=True)
+            import shutil
+            shutil.copy(path, os.path.join(keep_dir, f"seed{seed}_{os.path.basename(path)}"))
+    with tempfile.TemporaryDirectory() as tmp:
+        while (time.time() - t0 < seconds) if max_files is None else (n_files < max_files):
+            malformed = rng.random() < 0.2
+            text, info_keys, fmt_keys, samples = make_vcf(rng, malformed)
+            gz = rng.random() < 0.7
+            path = os.path.join(tmp, f"f{n_files}.vcf" + (".gz" if gz else ""))
+            raw = text.encode()
+            with open(path, "wb") as f:
+                f.write(T.bgzf_compress(raw, rng.choice([150, 211, 1000, 4096, 65280])) if gz else raw)
+            n_files += 1
+            for _ in range(rng.choice([1, 2, 3])):
+                kw = dict(zero_based=rng.random() < 0.5)
+                if rng.random() < 0.7:
+                    kw["info_fields"] = rng.sample(info_keys, rng.randrange(0, len(info_keys) + 1))
+                if rng.random() < 0.7:
+                    kw["format_fields"] = rng.sample(fmt_keys, rng.randrange(0, len(fmt_keys) + 1))
+                if samples and rng.random() < 0.4:
+                    kw["samples"] = rng.sample(samples + ["nobody"], rng.randrange(1, len(samples) + 1))
+                ctx = (seed, n_files - 1, path, kw)
+                try:
+                    o = vo.VcfOracle(path, **kw)
+                    names = None
+                    if rng.random() < 0.5:
+                        names = rng.sample(o.schema.names, rng.randrange(0, len(o.schema.names) + 1))
+                    want_err = None
+                except (vo.VcfError, ValueError) as e:
+                    want_err, names = e, None
+                bs = rng.choice([1, 7, 100, 8192])
+                if want_err is None:
+                    try:
+                        rows = T._parity(pkg, vo, path, kw, names=names, bs=bs, exact_batches=not (fmt_keys and len(samples) > 1))
+                        n_rows += rows
+                        n_scans += 1
+                        continue
+                    except (vo.VcfError, ValueError) as e:
+                        want_err = e
+                    except pkg.BioscanError as e:
+                        # the GPU refused something: the oracle must refuse it too
+                        try:
+                            o = vo.VcfOracle(path, **kw)
+                            plan = o.scan(projection=None if names is None else [o.schema.get_field_index(n) for n in names], filters=[], limit=None,
+                                          target_partitions=1)
+                            for p in range(o.num_partitions(plan)):
+                                o.execute(plan, p, bs)
+                        except (vo.VcfError, ValueError):
+                            n_refused += 1
+                            continue
+                        diverged("GPU refused a file the oracle reads", ctx, names, str(e), path)
+                        continue
+                    except AssertionError as e:
+                        diverged("rows differ", ctx, names, str(e), path)
+                        continue
+                # the oracle refused: so must the GPU -- unless what the oracle objects to is a value under a key the scan
+                # does not select: the reference's noodles iterators type every INFO entry / FORMAT value they pass, the
+                # product only looks at selected keys (documented deviation).  The oracle restates
+                # that rule with strict_unselected=False: if it then reads the file, the rows must agree.
+                try:
+                    rows = T._parity(pkg, _Lax(vo), path, kw, names=names, bs=bs, exact_batches=not (fmt_keys and len(samples) > 1))
+                    n_lax += 1
+                    n_rows += rows
+                    continue
+                except (vo.VcfError, ValueError, pkg.BioscanError):
+                    pass
+                except AssertionError as e:
+                    diverged("rows differ (unselected keys not validated)", ctx, names, str(e), path)
+                    continue
+                try:
+                    g = pkg.VcfTableProvider(path, kw.get("info_fields"), kw.get("format_fields"), None, kw.get("zero_based", True), kw.get("samples"))
+                    sch = g.schema()
+                    proj = None if names is None else [sch.get_field_index(n) for n in names]
+                    plan = g.scan(projection=proj, filters=[], limit=None, target_partitions=1)
+                    for p in range(plan.num_partitions()):
+                        list(plan.execute(p, bs))
+                except pkg.BioscanError:
+                    n_refused += 1
+                    continue
+                diverged("the oracle refused a file the GPU reads", ctx, names, str(want_err), path)
+            if verbose and n_files % 25 == 0:
+                print(f"{n_files} files, {n_scans} scans, {n_rows} rows, {n_refused} refused by both sides", flush=True)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+    totals = dict(files=n_files, scans=n_scans, rows=n_rows, refused_by_both=n_refused, read_under_product_rule=n_lax)
+    return totals, failures
+
+
+def main():
+    import __graft_entry__ as ge
+    pkg = ge._load_pkg()
+    pkg.load_library()
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t, failures = run(pkg, seconds, seed)
+    print(f"{'OK' if not failures else 'FAILED'}: {t['files']} files, {t['scans']} scans, {t['rows']} rows compared, "
+          f"{t['refused_by_both']} scans refused by both sides, {t['read_under_product_rule']} read by both under the product's rule for "
+          f"unselected keys (the reference would refuse them), {len(failures)} divergences")
+    if failures:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
