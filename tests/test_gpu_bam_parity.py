@@ -181,3 +181,23 @@ def test_tag_type_inference_options(pkg, oracle, golden, fname, tags):
             continue
         got = list(prov.scan().execute(0, 8192))
         _cmp_batches(got, want, (fname, kw))
+
+
+def test_differential_fuzz_of_indexed_scans(pkg, oracle):
+    """tools/fuzz_bam_indexed.py, a fixed number of files of two seeds: random coordinate-sorted BAMs (crowded and empty bins,
+    reference spans across bin and linear-index boundaries, placed-unmapped and unplaced reads, members of 200 .. 60 000 bytes)
+    with a BAI built by the tool, scanned with random target_partitions, filters, projections, batch sizes, coordinate
+    systems and pipeline chunk sizes -- partition plans and every partition's batches against the oracle; a scan one side
+    refuses (a region on a reference the file does not have) the other refuses too."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_bam_indexed as F
+    tot = dict(files=0, scans=0, partitions=0, rows=0, refused_by_both=0)
+    for seed in (11, 12):
+        t, failures = F.run(pkg, seed=seed, max_files=50, verbose=False)
+        assert not failures, failures[:3]
+        for k in tot:
+            tot[k] += t[k]
+    assert tot["scans"] > 150 and tot["rows"] > 5000, tot
+    from conftest import report_size
+    report_size("test_differential_fuzz_of_indexed_scans", **tot)

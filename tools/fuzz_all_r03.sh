@@ -14,3 +14,5 @@ for k in 0 1; do
 done
 unset BIOSCAN_K1_PREHEADERS
 timeout -k 10 200 python3 $R/tools/fuzz_w2.py 60 5 2>&1 | tail -2
+timeout -k 10 200 python3 $R/tools/fuzz_bam_indexed.py 90 7 2>&1 | tail -1
+timeout -k 10 200 python3 $R/tools/fuzz_vcf_parity.py 90 7 2>&1 | tail -1
