@@ -39,9 +39,6 @@ namespace bioscan {
 #ifndef V3_CK_STEPS
 #define V3_CK_STEPS 24        // decode steps between two checkpoints = longest segment of the write phase
 #endif
-#ifndef V3_FIRST_BLOCK_BITS
-#define V3_FIRST_BLOCK_BITS (12u * 1024u * 8u)   // size guess for the first block a wave ever sees
-#endif
 #ifndef V3_OV_MAX
 #define V3_OV_MAX 480         // pre-roll: half a sub-stream, at least V3_OV_MIN, at most this
 #endif
@@ -905,7 +902,11 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
   unsigned long long* mlist = scratch + (size_t)slot * scratch_stride;
   uint32_t* ck = (uint32_t*)(mlist + V3_ML_ENTRIES);
   uint32_t dbg_rounds = 0, dbg_passes = 0, dbg_matches = 0, dbg_near = 0, dbg_minis = 0, dbg_idle = 0, dbg_hbm = 0;
-  uint64_t pred_bits = V3_FIRST_BLOCK_BITS;  // expected length of the next DEFLATE block body (the previous block's)
+  // expected length of the next DEFLATE block body: the previous block's; for the first member a wave takes, that member's
+  // payload (a BGZF member is usually one block, and an overestimate only idles lanes behind the END-OF-BLOCK while an
+  // underestimate costs whole rounds -- with the fixed 12 KiB guess the first member of a wave ran 2.4 extra rounds, which is
+  // most of what a launch of a few thousand members costs: 5.4 rounds per member instead of 3)
+  uint64_t pred_bits = 0;
 #ifdef V3_FIXSTAT
   uint32_t fs_lanes[4] = {0, 0, 0, 0}, fs_iters[4] = {0, 0, 0, 0};  // lanes re-decoded by / runs of the 1st, 2nd, 3rd, later fix pass
 #endif
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
     const uint64_t skew = (uint64_t)((uintptr_t)payload & 3) * 8;
     const uint64_t end_bits = skew + payload_len * 8;
     // a bounded wave lives for a few members: the block length is predicted from the member itself (a BGZF member is usually one block)
-    if constexpr (BOUNDED) pred_bits = payload_len * 8 < 2048 ? 2048 : payload_len * 8;
+    if (BOUNDED || pred_bits == 0) pred_bits = payload_len * 8 < 2048 ? 2048 : payload_len * 8;
     uint64_t P = skew;
     uint32_t opos = 0;
     bool first_block = true;
