@@ -564,6 +564,24 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
       const long ref = ref_index(r.chrom);
       if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
       auto chunks = bai_query_chunks(p.bai, (size_t)ref, r.has_start, r.start, r.has_end, r.end);
+      if (r.has_end && r.end >= 1 && (size_t)ref < p.bai.refs.size()) {
+        // The BAI query has no upper bound: the bins of the coarser levels that overlap the region hold reads up to 64 Mb
+        // (512 Mb) behind its end -- single-read chunks the reference seeks to, inflates and filters out one by one, and
+        // which here would stretch the decode span over every member in between (config 2 cut into 8 partitions: 7.6 % more
+        // members than the file has).  The first record of the next non-empty LEAF bin behind the region's last 16 kb
+        // window starts behind the region's end, and so does every record after it (the file is sorted by start): chunks
+        // from there on cannot hold a row of the answer.
+        const BaiRef& br = p.bai.refs[(size_t)ref];
+        const uint64_t w_end = (r.end - 1) >> 14;
+        auto it = br.bins.upper_bound((uint32_t)std::min<uint64_t>(4681 + w_end, 37448));
+        if (4681 + w_end < 37448 && it != br.bins.end() && it->first < 37449 && !it->second.empty()) {
+          uint64_t V = ~0ull;
+          for (auto& c : it->second) V = std::min(V, c.first);
+          std::vector<std::pair<uint64_t, uint64_t>> kept;
+          for (auto& c : chunks) if (c.first < V) kept.push_back({c.first, std::min(c.second, V)});
+          chunks.swap(kept);
+        }
+      }
       if (chunks.empty()) continue;  // nothing indexed for the region
       uint64_t lo = ~0ull, hi = 0;
       for (auto& c : chunks) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
