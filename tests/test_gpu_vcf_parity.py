@@ -677,7 +677,7 @@ def test_differential_fuzz_of_whole_files(pkg, vo):
     column is not projected, which the reference's iterators would still type)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_vcf_parity as F
-    tot = dict(files=0, scans=0, rows=0, refused_by_both=0, read_under_product_rule=0)
+    tot = dict(files=0, scans=0, indexed_scans=0, rows=0, refused_by_both=0, read_under_product_rule=0)
     for seed in (5, 6):
         t, failures = F.run(pkg, seed=seed, max_files=60, verbose=False)
         assert not failures, failures[:3]

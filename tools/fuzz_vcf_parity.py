@@ -3,7 +3,9 @@ rules distinguish, FORMAT definitions, 0..5 samples, records with missing values
 percent escapes, multi-allelic ALT, symbolic alleles, END, lines that span BGZF members of 150 .. 65 280 bytes -- are
 scanned by the GPU provider and by oracle/vcf_oracle.py with random field selections, sample subsets, projections,
 coordinate systems and batch sizes; schemas, plans and every partition's rows are compared (tests/test_gpu_vcf_parity.py:
-_parity).  A file one side refuses must be refused by the other.  A share of the files carries one malformed record.
+_parity).  A file one side refuses must be refused by the other.  A share of the files carries one malformed record; six in ten
+of the well-formed compressed ones get a tabix index built here and are also scanned through it (TBI size estimates, balanced
+partitions, region queries, residual filters) with random region filters and target_partitions.
 usage: fuzz_vcf_parity.py [seconds=60] [seed=1]"""
 import os
 import random
@@ -161,6 +163,106 @@ def make_vcf(rng, malformed):
     return "\n".join(hdr + lines) + "\n", [k for k, _, _ in infos], [k for k, _, _ in fmts] if n_samples else [], samples
 
 
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def bgzf_and_tbi(text: str, member: int):
+    """-> (bgzf bytes, tbi bytes) for a position-sorted VCF text: BGZF members of `member` bytes and a tabix index built the way
+    htslib builds one for VCF (names in order of appearance, span = END when INFO carries one, else POS .. POS + len(REF) - 1;
+    bins with merged chunks, 16 kb linear index, the 37450 pseudo-bin)."""
+    import struct
+    import zlib
+    raw = text.encode()
+    out, coffs = bytearray(), []
+    for ch in [raw[i:i + member] for i in range(0, len(raw), member)] + [b""]:
+        coffs.append(len(out))
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = c.compress(ch) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(ch), len(ch))
+
+    def voff(u):
+        k, w = divmod(u, member)
+        return (coffs[k] << 16) | w
+    names, refs = [], []
+    u = 0
+    for line in text.split("\n")[:-1]:
+        n = len(line.encode()) + 1
+        if not line.startswith("#"):
+            f = line.split("\t")
+            if f[0] not in names:
+                names.append(f[0])
+                refs.append(dict(bins={}, lin={}, beg=None, end=None, n=0))
+            r = refs[names.index(f[0])]
+            beg = int(f[1]) - 1
+            end = beg + max(1, len(f[3]))
+            for ent in f[7].split(";"):
+                if ent.startswith("END=") and ent[4:].isdigit() and int(ent[4:]) > beg:
+                    end = int(ent[4:])
+            v0, v1 = voff(u), voff(u + n)
+            ch = r["bins"].setdefault(_reg2bin(beg, end), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1] = (ch[-1][0], v1)
+            else:
+                ch.append((v0, v1))
+            for w in range(beg >> 14, ((end - 1) >> 14) + 1):
+                r["lin"].setdefault(w, v0)
+            r["beg"] = v0 if r["beg"] is None else r["beg"]
+            r["end"] = v1
+            r["n"] += 1
+        u += n
+    nm = b"".join(x.encode() + b"\0" for x in names)
+    t = bytearray(b"TBI\1" + struct.pack("<8i", len(names), 2, 1, 2, 0, ord("#"), 0, len(nm)) + nm)
+    for r in refs:
+        t += struct.pack("<i", len(r["bins"]) + 1)
+        for b in sorted(r["bins"]):
+            t += struct.pack("<Ii", b, len(r["bins"][b]))
+            for c in r["bins"][b]:
+                t += struct.pack("<QQ", *c)
+        t += struct.pack("<Ii", 37450, 2) + struct.pack("<QQQQ", r["beg"], r["end"], r["n"], 0)
+        n_intv = max(r["lin"]) + 1
+        t += struct.pack("<i", n_intv)
+        last = 0
+        for w in range(n_intv):
+            last = r["lin"].get(w, last)
+            t += struct.pack("<Q", last)
+    t += struct.pack("<Q", 0)
+    return bytes(out), T.bgzf_compress(bytes(t), 60000), names
+
+
+def vcf_filters(rng, names):
+    f = []
+    k = rng.random()
+    if k < 0.2:
+        return f
+    if k < 0.75:
+        c = rng.choice(names + ["nope"])
+        f.append(("chrom", "=", c))
+        if rng.random() < 0.6:
+            a = rng.randrange(0, 60000)
+            b = a + rng.choice([1, 100, 5000, 40000, 10 ** 7])
+            form = rng.random()
+            if form < 0.4:
+                f += [("start", ">=", a), ("start", "<=", b)]
+            elif form < 0.6:
+                f += [("start", ">=", a), ("end", "<=", b)]
+            elif form < 0.8:
+                f.append(("start", ">", a))
+            else:
+                f.append(("end", "<", b))
+    else:
+        f.append(("chrom", "in", [rng.choice(names + ["nope"]) for _ in range(rng.randrange(1, 4))]))
+    if rng.random() < 0.2:
+        f.append(("qual", ">=", 30.0))
+    if rng.random() < 0.15:
+        f.append(("id", "!=", "."))
+    return f
+
+
 class _Lax:
     """vcf_oracle with VcfOracle(strict_unselected=False), for T._parity"""
     def __init__(self, mod):
@@ -177,7 +279,7 @@ def run(pkg, seconds=60.0, seed=1, max_files=None, verbose=True):
     """-> (totals dict, list of divergences)"""
     rng = random.Random(seed)
     t0 = time.time()
-    n_files = n_rows = n_refused = n_scans = n_lax = 0
+    n_files = n_rows = n_refused = n_scans = n_lax = n_indexed = 0
     failures = []
     keep_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "fuzz_vcf_cases")
 
@@ -195,9 +297,38 @@ def run(pkg, seconds=60.0, seed=1, max_files=None, verbose=True):
             gz = rng.random() < 0.7
             path = os.path.join(tmp, f"f{n_files}.vcf" + (".gz" if gz else ""))
             raw = text.encode()
-            with open(path, "wb") as f:
-                f.write(T.bgzf_compress(raw, rng.choice([150, 211, 1000, 4096, 65280])) if gz else raw)
+            member = rng.choice([150, 211, 1000, 4096, 65280])
+            tbi_names = None
+            n_data = sum(1 for ln in text.split("\n") if ln and not ln.startswith("#"))
+            if gz and not malformed and n_data and rng.random() < 0.6:
+                bz, tbi, tbi_names = bgzf_and_tbi(text, member)
+                with open(path, "wb") as f:
+                    f.write(bz)
+                with open(path + ".tbi", "wb") as f:
+                    f.write(tbi)
+            else:
+                with open(path, "wb") as f:
+                    f.write(T.bgzf_compress(raw, member) if gz else raw)
             n_files += 1
+            if tbi_names is not None:
+                # indexed scans: TBI size estimates, balanced partitions, region queries, residual filters
+                for _ in range(rng.choice([2, 3])):
+                    filters = vcf_filters(rng, tbi_names)
+                    target = rng.choice([1, 2, 3, 5, 8])
+                    kw = dict(zero_based=rng.random() < 0.5)
+                    if rng.random() < 0.5:
+                        kw["info_fields"] = rng.sample(info_keys, rng.randrange(0, len(info_keys) + 1))
+                    if rng.random() < 0.5:
+                        kw["format_fields"] = rng.sample(fmt_keys, rng.randrange(0, len(fmt_keys) + 1))
+                    ctx = (seed, n_files - 1, path, kw, filters, target)
+                    try:
+                        n_rows += T._parity(pkg, vo, path, kw, filters=filters, target=target, bs=rng.choice([1, 100, 8192]),
+                                            exact_batches=not (fmt_keys and len(samples) > 1))
+                        n_indexed += 1
+                    except AssertionError as e:
+                        diverged("indexed scan differs", ctx, None, str(e), path)
+                    except (vo.VcfError, ValueError, pkg.BioscanError) as e:
+                        diverged("indexed scan raised", ctx, None, repr(e), path)
             for _ in range(rng.choice([1, 2, 3])):
                 kw = dict(zero_based=rng.random() < 0.5)
                 if rng.random() < 0.7:
@@ -267,11 +398,12 @@ def run(pkg, seconds=60.0, seed=1, max_files=None, verbose=True):
                 diverged("the oracle refused a file the GPU reads", ctx, names, str(want_err), path)
             if verbose and n_files % 25 == 0:
                 print(f"{n_files} files, {n_scans} scans, {n_rows} rows, {n_refused} refused by both sides", flush=True)
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
-    totals = dict(files=n_files, scans=n_scans, rows=n_rows, refused_by_both=n_refused, read_under_product_rule=n_lax)
+            for q in (path, path + ".tbi"):
+                try:
+                    os.unlink(q)
+                except OSError:
+                    pass
+    totals = dict(files=n_files, scans=n_scans, indexed_scans=n_indexed, rows=n_rows, refused_by_both=n_refused, read_under_product_rule=n_lax)
     return totals, failures
 
 
@@ -282,7 +414,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     t, failures = run(pkg, seconds, seed)
-    print(f"{'OK' if not failures else 'FAILED'}: {t['files']} files, {t['scans']} scans, {t['rows']} rows compared, "
+    print(f"{'OK' if not failures else 'FAILED'}: {t['files']} files, {t['scans']} scans + {t['indexed_scans']} indexed scans, {t['rows']} rows compared, "
           f"{t['refused_by_both']} scans refused by both sides, {t['read_under_product_rule']} read by both under the product's rule for "
           f"unselected keys (the reference would refuse them), {len(failures)} divergences")
     if failures:
