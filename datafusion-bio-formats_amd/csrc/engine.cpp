@@ -559,7 +559,20 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
         if (!have)
           for (auto& rf : p.bai.refs) if (!rf.intervals.empty()) { seek = have ? std::max(seek, rf.intervals.back()) : rf.intervals.back(); have = true; }
       }
-      w.range = (have && seek) ? range_from_voffs(p, seek, 0, true) : p.whole_file();
+      // Where the scan can end at the latest: a reference's records (placed-unmapped ones included) all lie in front of the
+      // first record of any later reference, and the index knows where that is.  Without this bound the decode range of
+      // every tail ran to the end of the file (one chunk = up to 2^20 members inflated to find a handful of reads, and a
+      // device image that spans the rest of the file); the scan itself still stops where the reference changes.
+      uint64_t bound = 0;
+      if (w.sel.mode == 2) {
+        for (size_t r2 = (size_t)w.sel.ref + 1; r2 < p.bai.refs.size() && !bound; r2++) {
+          uint64_t first = ~0ull;
+          for (auto& b2 : p.bai.refs[r2].bins) for (auto& c : b2.second) first = std::min(first, c.first);
+          if (first != ~0ull) bound = first;
+        }
+      }
+      if (have && seek && bound > seek) w.range = range_from_voffs(p, seek, bound, false);
+      else w.range = (have && seek) ? range_from_voffs(p, seek, 0, true) : p.whole_file();
     } else {
       const long ref = ref_index(r.chrom);
       if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
@@ -701,10 +714,14 @@ struct BamExecState {
   // only when the chunk size was not set by the caller (tests drive exact chunk sizes).
   const bool ramp;
   uint32_t chunks_done = 0;
+  uint32_t item_chunks = 0;  // chunks of the current work item so far
+  bool item_is_tail = false; // an unmapped-tail scan: usually over within the first member
   uint32_t chunk_len(uint32_t k) const {
-    if (!ramp) return chunk_members;
-    const uint64_t c = 2048ull << std::min<uint32_t>(k, 16);
-    return (uint32_t)std::min<uint64_t>(c, chunk_members);
+    uint64_t c = chunk_members;
+    if (ramp) c = std::min<uint64_t>(c, 2048ull << std::min<uint32_t>(k, 16));
+    // a tail scan ends where the reference changes: 4, 16, 64, ... members instead of a whole chunk to find that out
+    if (item_is_tail) c = std::min<uint64_t>(c, 4ull << std::min<uint32_t>(2 * (item_chunks + (k - chunks_done)), 24));
+    return (uint32_t)std::max<uint64_t>(c, 1);
   }
   std::shared_ptr<DeviceImage> img;  // this partition's device: resident members + tables + reference names
   K1Ctx k1;
@@ -831,6 +848,8 @@ struct BamExecState {
         carry_len = 0;
         tail_seen = false;
         tail_done = false;
+        item_chunks = 0;
+        item_is_tail = w.sel.mode == 2;
         item_open = true;
         if (w.range.b_hi <= w.range.b_lo || w.range.first_rel >= w.range.stop_rel) { item_open = false; item++; continue; }
       }
@@ -1091,6 +1110,7 @@ struct BamExecState {
       cur = nxt;
     }
     chunks_done++;
+    item_chunks++;
     // every kernel that reads this chunk's scratch (record table, keys, row list) has to be done before the scratch
     // is released at the end of this scope; the Arrow buffers live on in `res`
     HIP_CHECK(hipStreamSynchronize(st));
