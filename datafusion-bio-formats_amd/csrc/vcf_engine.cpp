@@ -611,7 +611,23 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
         q.chunks_abs = it->second;
         for (auto& c : q.chunks_abs) { mn = std::min(mn, c.first); mx = std::max(mx, c.second); }
       } else {
-        for (auto& ch : bai_query_chunks(p.tbi.idx, (size_t)idx, r.has_start, r.start, r.has_end, r.end)) {
+        auto chunks = bai_query_chunks(p.tbi.idx, (size_t)idx, r.has_start, r.start, r.has_end, r.end);
+        if (r.has_end && r.end >= 1 && (size_t)idx < p.tbi.idx.refs.size()) {
+          // as for BAM (engine.cpp: build_work_uncached): the bins of the coarser levels reach up to 64 Mb behind the region's
+          // end; the first line of the next non-empty LEAF bin behind the region's last 16 kb window has POS > end, and so
+          // has every line after it -- chunks from there on hold no row of the answer and would only stretch the span
+          const BaiRef& br = p.tbi.idx.refs[(size_t)idx];
+          const uint64_t w_end = (r.end - 1) >> 14;
+          auto it = br.bins.upper_bound((uint32_t)std::min<uint64_t>(4681 + w_end, 37448));
+          if (4681 + w_end < 37448 && it != br.bins.end() && it->first < 37449 && !it->second.empty()) {
+            uint64_t V = ~0ull;
+            for (auto& c : it->second) V = std::min(V, c.first);
+            std::vector<std::pair<uint64_t, uint64_t>> kept;
+            for (auto& c : chunks) if (c.first < V) kept.push_back({c.first, std::min(c.second, V)});
+            chunks.swap(kept);
+          }
+        }
+        for (auto& ch : chunks) {
           const uint64_t a = voff_to_abs(p, ch.first), b = voff_to_abs(p, ch.second);
           if (b > a) { q.chunks_abs.emplace_back(a, b); mn = std::min(mn, a); mx = std::max(mx, b); }
         }
