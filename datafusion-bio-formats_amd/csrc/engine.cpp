@@ -317,6 +317,8 @@ struct WorkItem {
   // over the union of their members with the OR of their predicates returns the same rows in the same order as one pass
   // per region -- without re-inflating the boundary members and without one small K1 launch per region.
   std::vector<RowSelect> more;
+  // [begin, end) pairs of absolute inflated offsets: the BAI chunks of `sel` and of every entry of `more` (RowSelect::ch_lo / ch_n)
+  std::vector<uint64_t> chunk_tab;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -571,8 +573,14 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
           if (first != ~0ull) bound = first;
         }
       }
-      if (have && seek && bound > seek) w.range = range_from_voffs(p, seek, bound, false);
-      else w.range = (have && seek) ? range_from_voffs(p, seek, 0, true) : p.whole_file();
+      if (have && seek && bound) {
+        // the usual case is bound == seek: the reference's last chunk ends where the next reference begins and there is no
+        // tail at all (the reference's reader would run to the end of the file looking for it and return nothing)
+        if (bound <= seek) continue;
+        w.range = range_from_voffs(p, seek, bound, false);
+      } else {
+        w.range = (have && seek) ? range_from_voffs(p, seek, 0, true) : p.whole_file();
+      }
     } else {
       const long ref = ref_index(r.chrom);
       if (ref < 0) throw Error("BAM region query failed: region reference sequence does not exist in reference sequences: " + r.chrom);
@@ -599,6 +607,13 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
       uint64_t lo = ~0ull, hi = 0;
       for (auto& c : chunks) { lo = std::min(lo, c.first); hi = std::max(hi, c.second); }
       w.range = range_from_voffs(p, lo, hi, false);
+      // the decode covers the span of the chunks; the answer only holds records that start inside one of them
+      for (auto& c : chunks) {
+        w.chunk_tab.push_back(p.blk_uoff[block_of_coff(p, c.first >> 16)] + (c.first & 0xFFFF));
+        w.chunk_tab.push_back(p.blk_uoff[block_of_coff(p, c.second >> 16)] + (c.second & 0xFFFF));
+      }
+      w.sel.ch_lo = 0;
+      w.sel.ch_n = (uint32_t)chunks.size();
       w.sel.mode = 1;
       w.sel.ref = (int32_t)ref;
       w.sel.start1 = r.has_start ? (int64_t)r.start : 0;
@@ -615,6 +630,8 @@ static std::vector<WorkItem> build_work_uncached(const Plan& plan, int partition
         const uint64_t shift = p.blk_uoff[w.range.b_lo] - p.blk_uoff[a.range.b_lo];
         a.range.stop_rel = std::max(a.range.stop_rel, w.range.stop_rel + shift);
         a.range.b_hi = w.range.b_hi;
+        w.sel.ch_lo = (uint32_t)(a.chunk_tab.size() / 2);
+        a.chunk_tab.insert(a.chunk_tab.end(), w.chunk_tab.begin(), w.chunk_tab.end());
         a.more.push_back(w.sel);
         continue;
       }
@@ -984,10 +1001,14 @@ struct BamExecState {
       for (auto& extra : w.more) sels.push_back(extra);
       DevBuf<RowSelect> d_sels(sels.size());
       HIP_CHECK(hipMemcpyAsync(d_sels.p, sels.data(), sels.size() * sizeof(RowSelect), hipMemcpyHostToDevice, st));
+      DevBuf<uint64_t> d_chunks(std::max<size_t>(w.chunk_tab.size(), 1));
+      if (!w.chunk_tab.empty()) HIP_CHECK(hipMemcpyAsync(d_chunks.p, w.chunk_tab.data(), w.chunk_tab.size() * 8, hipMemcpyHostToDevice, st));
       DevBuf<uint32_t> kerr(1), keep(n_rec);
       DevBuf<uint64_t> kscan(n_rec + 1), tmp(scan_tmp_elems(n_rec));
       HIP_CHECK(hipMemsetAsync(kerr.p, 0, 4, st));
-      launch_row_flags_rec(u, rec_off.p, n_rec, d_sels.p, (int)sels.size(), d_terms.p, keep.p, kerr.p, st);
+      // u[0] is the first carried byte: the bytes of member m0 start carry_len further on
+      launch_row_flags_rec(u, rec_off.p, n_rec, d_sels.p, (int)sels.size(), d_terms.p, keep.p, kerr.p, st,
+                           w.chunk_tab.empty() ? nullptr : d_chunks.p, p.blk_uoff[m0] - carry_len);
       launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n_rec, tmp.p, st);
       uint64_t tsel = 0;
       uint32_t e8 = 0;

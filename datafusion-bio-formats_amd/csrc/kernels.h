@@ -94,10 +94,14 @@ struct RowSelect {
   uint64_t i_lo, i_hi;   // record index range considered (mode 2: run bounds)
   int32_t zero_based;
   int32_t n_terms;
+  // mode 1: the region's merged BAI chunks as [begin, end) pairs of absolute inflated offsets, entries ch_lo .. ch_lo + ch_n of
+  // the item's chunk table; a record belongs to the answer only if it STARTS inside one of them (the reference reads the
+  // chunks, not what lies between them: a record the index does not list is not returned).  ch_n == 0: no such test.
+  uint32_t ch_lo, ch_n;
 };
 void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st);
 void launch_row_flags_rec(const uint8_t* u, const uint64_t* rec_off, uint64_t n, const RowSelect* sels_dev, int n_sel, const FilterTerm* terms_dev,
-                          uint32_t* keep, uint32_t* err, hipStream_t st);
+                          uint32_t* keep, uint32_t* err, hipStream_t st, const uint64_t* chunk_tab = nullptr, uint64_t buf_base_abs = 0);
 void launch_compact_rows(const uint64_t* rec_off, const uint32_t* keep, const uint64_t* keep_scan, uint64_t n,
                          uint64_t* rows, uint64_t row_base, hipStream_t st);
 // tail run finder: first index >= i0 with refid==ref  /  first index > a with refid != ref

@@ -442,8 +442,21 @@ __global__ void k_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTe
   else keep[i] = kp ? 1u : 0u;
 }
 // One record's verdict for one selection (shared by the key-table form above and the fused form below)
+// is the absolute inflated offset `apos` inside one of the region's chunks?  (sorted, disjoint [begin, end) pairs)
+__device__ __forceinline__ bool in_region_chunks(const RowSelect& sel, const uint64_t* __restrict__ tab, uint64_t apos) {
+  if (!tab || sel.ch_n == 0) return true;
+  const uint64_t* t = tab + 2ull * sel.ch_lo;
+  uint32_t lo = 0, hi = sel.ch_n;   // first chunk whose begin is > apos
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (t[2 * mid] <= apos) lo = mid + 1; else hi = mid;
+  }
+  return lo > 0 && apos < t[2 * (lo - 1) + 1];
+}
+
 __device__ __forceinline__ bool row_verdict(const RowSelect& sel, uint64_t i, int32_t refid, int32_t pos, uint32_t end1, uint32_t fm,
-                                            const FilterTerm* __restrict__ terms) {
+                                            const FilterTerm* __restrict__ terms, const uint64_t* __restrict__ chunk_tab = nullptr,
+                                            uint64_t apos = 0) {
   bool kp = false;
   bool has_chrom = false, has_start = false, has_end = false;
   int32_t chrom_ref = -1;
@@ -455,7 +468,7 @@ __device__ __forceinline__ bool row_verdict(const RowSelect& sel, uint64_t i, in
       const int64_t s1 = (int64_t)pos + 1;
       const bool inter = sel.q_start1 <= (int64_t)end1 && s1 <= sel.end1;
       const bool dedup = s1 >= sel.start1 && s1 <= sel.end1;
-      kp = inter && dedup;
+      kp = inter && dedup && in_region_chunks(sel, chunk_tab, apos);
       has_chrom = true; chrom_ref = refid;
       has_start = true; start_out = sel.zero_based ? (uint32_t)pos : (uint32_t)pos + 1u;
       has_end = true;
@@ -475,7 +488,8 @@ __device__ __forceinline__ bool row_verdict(const RowSelect& sel, uint64_t i, in
 // registers and every region of the decode is tried at once (regions are disjoint: OR).  It replaces k_rec_keys + one
 // k_row_flags per region + the 16-byte-per-record key table between them (config 2 as a BAI plan: 9.4 + 13.2 ms).
 __global__ void k_row_flags_rec(const uint8_t* __restrict__ u, const uint64_t* __restrict__ rec_off, uint64_t n, const RowSelect* __restrict__ sels,
-                                int n_sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep, uint32_t* err) {
+                                int n_sel, const FilterTerm* __restrict__ terms, uint32_t* __restrict__ keep, uint32_t* err,
+                                const uint64_t* __restrict__ chunk_tab, uint64_t buf_base_abs) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* r = u + rec_off[i];
@@ -493,13 +507,15 @@ __global__ void k_row_flags_rec(const uint8_t* __restrict__ u, const uint64_t* _
   for (int k = 0; k < n_sel; k++) want_end = want_end || (sels[k].mode == 1 && sels[k].ref == refid);
   const uint32_t end1 = want_end ? rec_end1(r) : 0u;
   bool kp = false;
-  for (int k = 0; k < n_sel && !kp; k++) kp = row_verdict(sels[k], i, refid, pos, end1, fm, terms);
+  const uint64_t apos = buf_base_abs + rec_off[i];
+  for (int k = 0; k < n_sel && !kp; k++) kp = row_verdict(sels[k], i, refid, pos, end1, fm, terms, chunk_tab, apos);
   keep[i] = kp ? 1u : 0u;
 }
 void launch_row_flags_rec(const uint8_t* u, const uint64_t* rec_off, uint64_t n, const RowSelect* sels_dev, int n_sel, const FilterTerm* terms_dev,
-                          uint32_t* keep, uint32_t* err, hipStream_t st) {
+                          uint32_t* keep, uint32_t* err, hipStream_t st, const uint64_t* chunk_tab, uint64_t buf_base_abs) {
   if (!n) return;
-  hipLaunchKernelGGL(k_row_flags_rec, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, sels_dev, n_sel, terms_dev, keep, err);
+  hipLaunchKernelGGL(k_row_flags_rec, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, rec_off, n, sels_dev, n_sel, terms_dev, keep, err,
+                     chunk_tab, buf_base_abs);
 }
 
 void launch_row_flags(RecKeys k, uint64_t n, RowSelect sel, const FilterTerm* terms_dev, uint32_t* keep, int accumulate, hipStream_t st) {

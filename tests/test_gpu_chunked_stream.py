@@ -102,3 +102,79 @@ def test_truncated_last_record_is_an_error_in_every_chunking(pkg, tmp_path):
         prov = pkg.BamTableProvider(path, None, True, None, index_path="", chunk_members=chunk)
         with pytest.raises(pkg.BioscanError, match="record"):
             list(prov.scan().execute(0, 8192))
+
+
+@pytest.mark.parametrize("index_unmapped", [True, False])
+def test_unmapped_tails_do_not_decode_the_rest_of_the_file(pkg, oracle, tmp_path, index_unmapped):
+    """An unmapped-tail scan starts at the reference's last chunk and ends where the reference changes -- its decode range
+    must end there too (r03: it ran to the end of the file, so an indexed scan of a file with placed-unmapped reads on every
+    reference inflated the file once per reference).  Four references, placed-unmapped reads behind the mapped ones of each,
+    members of 2 000 bytes; with index_unmapped=False the index does not list those reads (their chunk is missing, so the
+    tail really holds them), with True it does (the tail is empty: the last chunk ends where the next reference begins).
+    Rows equal the oracle's per partition, and all partitions together inflate about one file's worth of members."""
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bam_build as bb
+    import fuzz_bam_indexed as F
+    refs = [(f"chr{i + 1}", 2_000_000) for i in range(4)]
+    recs, meta = [], []
+    for refid in range(4):
+        for k in range(600):
+            pos = 1000 + k * 3000
+            recs.append(bb.record(name=f"m{refid}_{k}", refid=refid, pos=pos, mapq=60, flag=99, cigar=((100, "M"),), seq="ACGT" * 25))
+            meta.append((refid, pos, 100, 99, True))
+        for k in range(3):
+            pos = 1000 + 599 * 3000 + 50
+            recs.append(bb.record(name=f"u{refid}_{k}", refid=refid, pos=pos, mapq=0, flag=69, cigar=(), seq="ACGT" * 25))
+            meta.append((refid, pos, 0, 69, index_unmapped))
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
+    tb = text.encode()
+    h = b"BAM\1" + struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(refs))
+    for n, l in refs:
+        nb = n.encode() + b"\0"
+        h += struct.pack("<i", len(nb)) + nb + struct.pack("<i", l)
+    payload = h + b"".join(recs)
+    member = 2000
+    data, coffs = F.bgzf_with_offsets(payload, member)
+    full, u = [], len(h)
+    for (refid, pos, span, flag, listed), r in zip(meta, recs):
+        if listed:
+            full.append((refid, pos, span, flag, u, u + len(r)))
+        u += len(r)
+    bai = bytearray(F.build_bai(4, full, lambda x: (coffs[x // member] << 16) | (x % member)))
+    if not index_unmapped:
+        # the pseudo-bin still says that unmapped reads exist (that is what makes the planner add the tail regions): patch
+        # n_unmapped of every reference from 0 to 3
+        o = 8
+        for _ in range(4):
+            n_bin = struct.unpack_from("<i", bai, o)[0]
+            o += 4
+            for _ in range(n_bin):
+                b, n_chunk = struct.unpack_from("<Ii", bai, o)
+                if b == 37450:
+                    struct.pack_into("<Q", bai, o + 8 + 24, 3)
+                o += 8 + 16 * n_chunk
+            n_intv = struct.unpack_from("<i", bai, o)[0]
+            o += 4 + 8 * n_intv
+    path = tmp_path / "tails.bam"
+    path.write_bytes(data)
+    (tmp_path / "tails.bam.bai").write_bytes(bytes(bai))
+    n_members = len(coffs) - 1
+    prov = pkg.BamTableProvider(str(path))
+    orc = oracle.BamOracle(str(path))
+    for target in (1, 4):
+        plan = prov.scan(target_partitions=target)
+        parts, residual = orc.scan(target_partitions=target)
+        assert plan.num_partitions() == len(parts)
+        if target > 1:
+            assert any(g.unmapped_tail for part in parts for g in part.regions)
+        rows = inflated = 0
+        for p in range(len(parts)):
+            got = list(plan.execute(p, 500))
+            _, want = orc.execute_partition(parts[p].regions, None, residual, 500)
+            _cmp_batches(got, want, ("tails", index_unmapped, target, p))
+            rows += sum(b.num_rows for b in got)
+            inflated += plan.execute_device(p, 500)["n_blocks"]
+        assert rows == (4 * 603 if index_unmapped else 4 * 600), rows   # (reads the index does not list and that have a position: no scan of the reference returns them)
+        assert inflated <= n_members + 8 * len(parts) + 16, (inflated, n_members)
