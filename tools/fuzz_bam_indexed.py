@@ -147,9 +147,13 @@ def make_bam(rng):
     def voff_of(u):
         k, w = divmod(u, member)
         return (coffs[k] << 16) | w
+    # one file in five has an index that does not list every read (an indexer that skips unmapped reads, or a stale index):
+    # a record that lies between two chunks is then not part of any region's answer, although a decode of the span sees it
+    omit = rng.random() < 0.2
     full, u = [], len(h)
     for (refid, pos, span, flag), r in zip(meta, recs):
-        full.append((refid, pos, span, flag, u, u + len(r)))
+        if not (omit and refid >= 0 and ((flag & 4) or rng.random() < 0.03)):
+            full.append((refid, pos, span, flag, u, u + len(r)))
         u += len(r)
     return data, build_bai(len(refs), full, voff_of), refs, len(recs)
 
