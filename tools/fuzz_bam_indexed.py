@@ -95,7 +95,7 @@ def build_bai(n_ref, recs, voff_of):
     return bytes(out)
 
 
-def make_bam(rng):
+def make_bam(rng, want_records=False):
     n_ref = rng.randrange(1, 6)
     refs = [(f"chr{i + 1}" if rng.random() < 0.8 else f"scaffold_{i}", rng.choice([20000, 70000, 1 << 20, 50_000_000, 500_000_000])) for i in range(n_ref)]
     member = rng.choice([200, 1000, 4096, 20000, 60000])
@@ -155,6 +155,13 @@ def make_bam(rng):
         if not (omit and refid >= 0 and ((flag & 4) or rng.random() < 0.03)):
             full.append((refid, pos, span, flag, u, u + len(r)))
         u += len(r)
+    if want_records:
+        # (refid, pos0, span, flag, virtual offset of the record) of every record, listed by the index or not
+        allr, u = [], len(h)
+        for (refid, pos, span, flag), r in zip(meta, recs):
+            allr.append((refid, pos, span, flag, voff_of(u)))
+            u += len(r)
+        return data, build_bai(len(refs), full, voff_of), refs, allr
     return data, build_bai(len(refs), full, voff_of), refs, len(recs)
 
 
