@@ -89,7 +89,7 @@ void BgzfSource::frame() {
 static void k1_launch_params(int device, uint32_t* grid, size_t* stride) {
   hipDeviceProp_t pr;
   HIP_CHECK(hipGetDeviceProperties(&pr, device));
-  const int occ = v3_resident_wg_per_cu();
+  const int occ = env_knobs().k1_version == 4 ? v4_resident_wg_per_cu() : v3_resident_wg_per_cu();
   *stride = V3_SCRATCH_STRIDE;
   const int per_cu = env_knobs().k1_waves_per_cu > 0 ? env_knobs().k1_waves_per_cu : occ;
   *grid = (uint32_t)pr.multiProcessorCount * (uint32_t)per_cu;
@@ -124,8 +124,9 @@ void BgzfSource::make_resident() {
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(d_k1_ctr.p, 0, 128, stream));
-  launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
-                         env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream);
+  (env_knobs().k1_version == 4 ? launch_bgzf_inflate_v4 : launch_bgzf_inflate_v3)(
+      d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
+      env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream, nullptr, 0, 0, 0, nullptr);
 }
 
 K1Ctx::~K1Ctx() {
@@ -215,7 +216,8 @@ void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* ds
   // K0: the first block header of every member, one member per lane, ahead of K1 on the same stream
   const bool k0 = c.pre.p && (size_t)nb * V3_PRE_DWORDS <= c.pre.n;
   if (k0) launch_bgzf_headers(img.comp_base, img.d_coff.p + b0, nb, c.pre.p, c.stream);
-  launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
+  (env_knobs().k1_version == 4 ? launch_bgzf_inflate_v4 : launch_bgzf_inflate_v3)(
+                         img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
                          env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,
                          (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw, k0 ? c.pre.p : nullptr);
 }

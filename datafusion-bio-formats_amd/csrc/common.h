@@ -68,6 +68,7 @@ void set_last_error(const std::string& msg);
 struct EnvKnobs {
   bool debug = false, laps = false;
   int k1_waves_per_cu = 0;
+  int k1_version = 3;     // BIOSCAN_K1=4: the v4 decode step (inflate_v4.hip)
   double host_pool_gb = 64.0;
   double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
   uint32_t chunk_members = 16384;          // BGZF members per pipeline chunk of a host stream (~1.3 GB of Arrow buffers for short reads)

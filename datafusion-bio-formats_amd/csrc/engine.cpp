@@ -48,6 +48,7 @@ const EnvKnobs& env_knobs() {
     if (const char* e = getenv("BIOSCAN_LOOKAHEAD")) v.lookahead = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_ONESHOT")) v.k1_oneshot = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_PREHEADERS")) v.k1_preheaders = atoi(e);
+    if (const char* e = getenv("BIOSCAN_K1")) v.k1_version = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("BIOSCAN_K1_PER_WAVE")) v.k1_per_wave = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_BOUNDED_WPW")) v.k1_bounded_wpw = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_SLOTS_PCT")) v.k1_slots_pct = atoi(e);

@@ -33,6 +33,12 @@ void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots = nullptr, uint32_t n_slots = 0,
                             uint32_t per_wave = 0, uint32_t wpw = 0, const uint32_t* pre = nullptr);
+// K1 with the v4 decode step (inflate_v4.hip): same launch contract and scratch layout.
+int v4_resident_wg_per_cu();
+void launch_bgzf_inflate_v4(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
+                            uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
+                            uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots = nullptr, uint32_t n_slots = 0,
+                            uint32_t per_wave = 0, uint32_t wpw = 0, const uint32_t* pre = nullptr);
 // K0 (inflate_headers.hip): the first DEFLATE block header of every member, one member per lane; rec holds V3_PRE_DWORDS
 // dwords per member (flags, header bits, 320 code lengths as nibbles) that K1 reads through its `pre` argument.
 constexpr uint32_t V3_PRE_DWORDS = 42;

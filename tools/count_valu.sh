@@ -2,7 +2,7 @@
 # dev tool: static VALU / SALU / LDS instruction counts of the K1 decode loops (K1 is VALU-issue bound: SQ_INSTS_VALU x 4
 # cycles = 96 % of the kernel's cycles), from the gfx950 ISA blocks of the loops that hold the V2LOOP markers
 SRC=${1:-/root/repo/datafusion-bio-formats_amd/csrc/inflate_v3.hip}
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DV3_ASM_MARKERS $EXTRA -S --cuda-device-only -o /tmp/v2m.s $SRC 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -DV3_ASM_MARKERS -DV4_ASM_MARKERS $EXTRA -S --cuda-device-only -o /tmp/v2m.s $SRC 2>/dev/null
 python3 - <<'PY'
 import re
 lines=open('/tmp/v2m.s').read().split('\n')
@@ -20,11 +20,11 @@ for l in lines:
     if h and not cur[2]: cur[1]=(cur[0],int(h.group(2)))
     t=l.strip()
     if t and not t.startswith((';','.')): cur[2].append(t)
-    if 'V3LOOP_BEGIN' in l: cur[2].append(l.strip())
+    if re.search('V[34]LOOP_BEGIN', l): cur[2].append(l.strip())
 seen=set()
 for b in blocks:
     for t in b[2]:
-        m=re.search(r'V3LOOP_BEGIN (\d)',t)
+        m=re.search(r'V[34]LOOP_BEGIN (\d)',t)
         if m and b[1] and b[1] not in seen:
             seen.add(b[1])
             body=[x for bb in blocks if bb[1]==b[1] for x in bb[2]]
