@@ -112,7 +112,7 @@ void BgzfSource::make_resident() {
     size_t stride = 0;
     k1_launch_params(device, &k1_grid, &stride);
     k1_grid = std::min<uint32_t>(k1_grid, std::max<uint32_t>(n_blocks(), 1));
-    d_k1_ctr.alloc(32);
+    d_k1_ctr.alloc(64);
     d_k1_scratch.alloc(((size_t)k1_grid + 8) * stride);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -123,10 +123,17 @@ void BgzfSource::make_resident() {
 
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
-  HIP_CHECK(hipMemsetAsync(d_k1_ctr.p, 0, 128, stream));
-  (env_knobs().k1_version == 4 ? launch_bgzf_inflate_v4 : launch_bgzf_inflate_v3)(
-      d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
-      env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream, nullptr, 0, 0, 0, nullptr);
+  HIP_CHECK(hipMemsetAsync(d_k1_ctr.p, 0, 256, stream));
+  if (env_knobs().k1_version == 4) {
+    launch_bgzf_inflate_v4(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
+                           env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream, nullptr, 0, 0, 0, nullptr);
+    // members whose Huffman codes do not fit v4's table pool (it counts them in ctr[1]): the wide-table kernel, same stream
+    launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
+                           nullptr, stream, nullptr, 0, 0, 0, nullptr, true);
+  } else {
+    launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
+                           env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream, nullptr, 0, 0, 0, nullptr);
+  }
 }
 
 K1Ctx::~K1Ctx() {
@@ -194,7 +201,7 @@ void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members
   c.device = img.device;
   if (!c.stream) HIP_CHECK(hipStreamCreate(&c.stream));
   c.grid = std::min<uint32_t>(img.grid_max, std::max<uint32_t>(max_members, 1));
-  if (!c.ctr.p) c.ctr.alloc(32);
+  if (!c.ctr.p) c.ctr.alloc(64);
   size_t need = ((size_t)c.grid + 8) * img.scratch_stride;
   if (oneshot) {
     // twice what the device holds at once: a wave finds a free stride within a few probes
@@ -211,15 +218,21 @@ void BgzfSource::init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members
 void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status) {
   if (b0 < img.m_lo || b0 + nb > img.m_hi) throw Error("internal: members outside the resident range of the device image");
   uint8_t* base = dst - blk_uoff[b0];
-  HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 128, c.stream));
+  HIP_CHECK(hipMemsetAsync(c.ctr.p, 0, 256, c.stream));
   if (c.n_slots) HIP_CHECK(hipMemsetAsync(status, 0xFF, (size_t)nb * 4, c.stream));  // a member no bounded wave took reads as an error
   // K0: the first block header of every member, one member per lane, ahead of K1 on the same stream
   const bool k0 = c.pre.p && (size_t)nb * V3_PRE_DWORDS <= c.pre.n;
   if (k0) launch_bgzf_headers(img.comp_base, img.d_coff.p + b0, nb, c.pre.p, c.stream);
-  (env_knobs().k1_version == 4 ? launch_bgzf_inflate_v4 : launch_bgzf_inflate_v3)(
-                         img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
-                         env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,
-                         (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw, k0 ? c.pre.p : nullptr);
+  if (env_knobs().k1_version == 4 && !c.n_slots) {
+    launch_bgzf_inflate_v4(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
+                           env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, nullptr, 0, 0, 0, k0 ? c.pre.p : nullptr);
+    launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
+                           nullptr, c.stream, nullptr, 0, 0, 0, nullptr, true);
+  } else {
+    launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
+                           env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,
+                           (uint32_t)std::max(1, env_knobs().k1_per_wave), (uint32_t)env_knobs().k1_bounded_wpw, k0 ? c.pre.p : nullptr);
+  }
 }
 void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0) {
   launch_inflate_to(c, img, dst, nb, b0, c.status.p);
@@ -255,8 +268,8 @@ void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
 void BgzfSource::report_k1_debug(uint32_t nb) { report_k1_debug(d_k1_ctr.p, nb); }
 void BgzfSource::report_k1_debug(const uint32_t* ctr_dev, uint32_t nb) {
   if (!env_knobs().debug || !ctr_dev) return;
-  uint32_t h[32];
-  HIP_CHECK(hipMemcpy(h, ctr_dev, 128, hipMemcpyDeviceToHost));
+  uint32_t h[64];
+  HIP_CHECK(hipMemcpy(h, ctr_dev, 256, hipMemcpyDeviceToHost));
   unsigned long long tc[5];
   memcpy(tc, h + 4, sizeof tc);  // dbg = ctr+1; cycle sums start at dbg+2 (8-byte aligned: ctr+3 -> see kernel) 
   fprintf(stderr, "[bioscan] inflate: %u members, %u rounds, %u decode passes (%.2f per round)\n", nb, h[2], h[3],
@@ -270,6 +283,14 @@ void BgzfSource::report_k1_debug(const uint32_t* ctr_dev, uint32_t nb) {
   for (int i = 0; i < 5; i++) {
     fprintf(stderr, "[bioscan]   %-18s %6.2f %% of wave cycles\n", nm[i], tot ? 100.0 * (double)tc[i] / tot : 0.0);
     if (i == 1) fprintf(stderr, "[bioscan]   %-18s %6.2f %% of wave cycles\n", "sync pass", tot ? 100.0 * (double)tx[1] / tot : 0.0);
+  }
+  {
+    // K1 v4 only: the write phase and the resolve split further (dbg + 32 ...)
+    unsigned long long ty[8];
+    memcpy(ty, h + 34, sizeof ty);
+    const char* ny[8] = {"mini-round setup", "write loop", "resolve: entries", "resolve: far copy", "resolve: near walk", "resolve: flush", "-", "-"};
+    if (ty[0] | ty[1] | ty[2])
+      for (int i = 0; i < 6; i++) fprintf(stderr, "[bioscan]     %-18s %6.2f %% of wave cycles\n", ny[i], tot ? 100.0 * (double)ty[i] / tot : 0.0);
   }
   fprintf(stderr, "[bioscan]   write mini-rounds %u (%.2f per round), lanes idle behind END-OF-BLOCK %.1f per round, %u mini-rounds through HBM\n", h[24], h[2] ? (double)h[24] / h[2] : 0.0,
           h[2] ? (double)h[25] / h[2] : 0.0, h[26]);

@@ -858,7 +858,10 @@ __device__ __forceinline__ void v3_resolve(V3Lds& L, uint8_t* out, unsigned long
 #ifndef V3_WAVES_PER_EU
 #define V3_WAVES_PER_EU 5
 #endif
-template <int WPW, bool BOUNDED>
+// RETRY: the launch behind K1 v4 (inflate_v4.hip) -- only the members v4 marked INF_RETRY (Huffman codes that need more
+// sub-table space than v4's LDS pool; this kernel's tables hold zlib's worst case) are decoded, and when counter[1] says
+// there is none the grid leaves at once.
+template <int WPW, bool BOUNDED, bool RETRY = false>
 __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3(const uint8_t* __restrict__ comp,
                                                            const uint64_t* __restrict__ blk_coff,
                                                            const uint64_t* __restrict__ blk_uoff, uint8_t* out_all,
@@ -869,6 +872,10 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
   __shared__ V3Lds L_all[WPW];
   V3Lds& L = L_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
+  if constexpr (RETRY) {
+    if (uni2(counter[1]) == 0u) return;
+    if (lane == 0) L.bnd_budget = blockIdx.x;
+  }
   // Two launch shapes.  PERSISTENT (slots == nullptr): the grid is what the device holds at once, every wave owns scratch
   // stride blockIdx and pulls members from the atomic counter until none is left.  BOUNDED (slots != nullptr): workgroups
   // of WPW waves, every wave pulls at most `per_wave` members and retires, so a workgroup lives a few milliseconds and
@@ -951,9 +958,20 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
       if (lane == 0) L.bnd_budget = left - 1u;
     }
     uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(counter, 1u);
-    b = uni2(b);
-    if (b >= n_blocks) break;
+    if constexpr (RETRY) {
+      // (no shared counter: 65 536 atomic pulls to find 80 members took a quarter as long as the launch they repair; every
+      // wave looks at its own stride of the status array)
+      b = uni2(L.bnd_budget);  // the wave's next member, parked in LDS like the bounded shape's loop state
+      V3_SYNC();
+      if (lane == 0) L.bnd_budget = b + gridDim.x;
+      V3_SYNC();
+      if (b >= n_blocks) break;
+      if (uni2(status[b]) != (uint32_t)INF_RETRY) continue;
+    } else {
+      if (lane == 0) b = atomicAdd(counter, 1u);
+      b = uni2(b);
+      if (b >= n_blocks) break;
+    }
 
     const uint64_t coff = blk_coff[b];
     const uint64_t cend = blk_coff[b + 1];
@@ -1367,8 +1385,16 @@ int v3_resident_wg_per_cu() {
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots, uint32_t n_slots, uint32_t per_wave, uint32_t wpw,
-                            const uint32_t* pre) {
+                            const uint32_t* pre, bool retry_only) {
   if (!n_blocks) return;
+  if (retry_only) {
+    // (persistent shape only; counter[0] is this launch's member counter, counter[1] the retry count v4 left)
+    (void)hipMemsetAsync(counter, 0, 4, st);
+    uint32_t g = grid < n_blocks ? grid : n_blocks;
+    hipLaunchKernelGGL((k_bgzf_inflate_v3<1, false, true>), dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                       status, counter, scratch, (uint32_t)V3_SCRATCH_STRIDE, nullptr, nullptr, 0u, 0u, nullptr);
+    return;
+  }
   if (wpw != 1) wpw = V3_BOUNDED_WPW;
   (void)hipMemsetAsync(counter, 0, 4, st);
   if (slots) {

@@ -25,7 +25,7 @@ namespace bioscan {
 
 #define WAVE 64
 #ifndef V4_SUB_DW
-#define V4_SUB_DW 16          // longest sub-stream of a round, dwords: a round's compressed bits are staged in LDS (64 x this)
+#define V4_SUB_DW 11          // longest sub-stream of a round, dwords: a round's compressed bits are staged in LDS (64 x this)
 #endif
 #ifndef V4_CK_STEPS
 #define V4_CK_STEPS 24        // decode steps between two checkpoints = longest segment of the write phase
@@ -37,10 +37,10 @@ namespace bioscan {
 #define V4_OV_MIN 96
 #endif
 #ifndef V4_OV_QUARTERS
-#define V4_OV_QUARTERS 4      // pre-roll = this many quarters of a sub-stream (before the clamps)
+#define V4_OV_QUARTERS 8      // pre-roll = this many quarters of a sub-stream (before the clamps)
 #endif
 #ifndef V4_WIN_BYTES
-#define V4_WIN_BYTES 3072
+#define V4_WIN_BYTES 2496
 #endif
 #ifndef V4_NO_ASM
 #define V4_NO_ASM 0           // 1: the C++ forms of the sync / count loops everywhere (what the bounded launch shape always runs)
@@ -53,28 +53,33 @@ constexpr int V4_MAX_SUB_DW = V4_SUB_DW;
 constexpr int V4_WIN = V4_WIN_BYTES;                    // LDS output window of one round (multiple of 16)
 // The compressed bits of a round live in LDS while it is decoded (three passes over them): 64 sub-streams plus the dwords a
 // lane may look at behind the last sub-stream's end (a symbol that begins before the limit, the two prefetched dwords).
+constexpr uint32_t V4_LCAP = 256;                      // matches of a mini-round (together with the window size: what a mini-round takes)
 constexpr uint32_t V4_STAGE_SLACK = 16, V4_STAGE_DW = 64u * V4_SUB_DW + V4_STAGE_SLACK;
-constexpr int V4_LIT_SUB = 352;    // 852 - 512 = 340 sub-table entries at most
-constexpr int V4_DIST_SUB = 528;   // 592 - 64
-// One table of 32-bit entries, addressed in entry units (all table starts are even):
-//   [0, 512)            literal/length root            [512, 864)    its sub-tables
-//   [864, 928)          distance root                  [928, 1456)   its sub-tables
-//   [1456, 1458)        STOP_EOB                       [1458, 1460)  STOP_BAD
+// One table of 1024 32-bit entries, addressed in entry units (all table starts are even):
+//   [0, 64)             distance root
+//   [64, 508)           the sub-table POOL: distance sub-tables from its low end up, literal/length sub-tables from its
+//                       high end down (zlib's worst cases are 528 and 340 entries; config 2 needs 134 + 232, htslib-written
+//                       BAM 40 + 186 -- tools/experiments/subtable_need.py).  A block whose codes do not fit is not decoded
+//                       here: the member is marked INF_RETRY and the wide-table kernel (inflate_v3.hip) takes it.
+//   [508, 1020)         literal/length root
+//   [1020, 1022)        STOP_EOB                       [1022, 1024)  STOP_BAD
 // Entry:  nmb [3:0]   index width of the NEXT lookup
 //         ntb [14:4]  entry offset of the table the NEXT lookup goes to (even, so bit 4 is 0 and v_bfe_u32 can take the
-//                     entry itself as its width operand); 0 = literal/length root = "a symbol is complete"
+//                     entry itself as its width operand); V4_LIT_ROOT = "a symbol is complete", 0 = the distance root =
+//                     "that was a length symbol"
 //         adv [19:15] bits this step consumes (code bits + extra bits; a sub-table pointer: the index width of the table
 //                     it sits in)
 //         eb  [23:20] extra-bit count of a length / distance symbol
 //         m   [31:24] literal byte | (length base - 3) >> eb | (distance base - 1) >> eb   (RFC 1951 3.2.5: every base is
 //                     m << eb plus 3 resp. 1, with m < 256)
-// END-OF-BLOCK points to STOP_EOB, a bit pattern no code maps to and the symbols that must not occur (286, 287, distance
-// 30, 31) to STOP_BAD.  The count and write loops retire a lane that is sent to a STOP table; the sync pass, which decodes
-// garbage on purpose, follows it: the STOP entries lead back to the root without consuming anything (BAD itself
+// Which alphabet a table belongs to is its place: distance tables lie below the lowest literal/length sub-table (`lit_lo`,
+// per block).  END-OF-BLOCK points to STOP_EOB, a bit pattern no code maps to and the symbols that must not occur (286, 287,
+// distance 30, 31) to STOP_BAD.  The count and write loops retire a lane that is sent to a STOP table; the sync pass, which
+// decodes garbage on purpose, follows it: the STOP entries lead back to the root without consuming anything (BAD itself
 // consumes one bit, so a lane always moves on).
-constexpr uint32_t V4_LIT_ROOT = 0, V4_DIST_ROOT = (1u << V4_LIT_BITS) + V4_LIT_SUB, V4_STOP_EOB = V4_DIST_ROOT + (1u << V4_DIST_BITS) + V4_DIST_SUB,
-                   V4_STOP_BAD = V4_STOP_EOB + 2u, V4_NENT = V4_STOP_BAD + 2u;
-static_assert((V4_DIST_ROOT & 1u) == 0 && (V4_STOP_EOB & 1u) == 0 && V4_NENT < 2048u, "table starts are even and fit the 11-bit field");
+constexpr uint32_t V4_DIST_ROOT = 0, V4_POOL_LO = 1u << V4_DIST_BITS, V4_POOL = 444, V4_LIT_ROOT = V4_POOL_LO + V4_POOL,
+                   V4_STOP_EOB = V4_LIT_ROOT + (1u << V4_LIT_BITS), V4_STOP_BAD = V4_STOP_EOB + 2u, V4_NENT = V4_STOP_BAD + 2u;
+static_assert((V4_LIT_ROOT & 1u) == 0 && (V4_STOP_EOB & 1u) == 0 && V4_NENT == 1024u, "table starts are even and the table is 4 KiB");
 __host__ __device__ constexpr uint32_t v4_enc(uint32_t nmb, uint32_t ntb, uint32_t adv, uint32_t eb, uint32_t m) {
   return nmb | (ntb << 4) | (adv << 15) | (eb << 20) | (m << 24);
 }
@@ -110,11 +115,18 @@ struct __attribute__((aligned(16))) V4Lds {
   uint32_t bnd_slot, bnd_budget;  // bounded launches: the scratch stride this wave borrowed, members it may still take
   uint32_t pre_lo, pre_hi;        // K0's records (address, or 0), parked here for the same reason as blk_final
   uint32_t blk_final;             // BFINAL of the block being decoded (kept here, not in a register)
+  // The match list of a mini-round whose output lives in the window never leaves the chip: a match's length - 3 and
+  // distance - 1 are written into its own first three destination bytes (a match is at least 3 bytes long; 8 + 15 bits), and
+  // this list only says where the matches are (window-relative destination, in output order).  Through a list in global
+  // memory the resolve waited ~14 us per mini-round for the write pass's stores to drain and the entries to come back
+  // (a third of K1's wave cycles), and the list was 8.8 of K1's 33 GB of HBM traffic per 65 536 members.
+  uint16_t ml16[V4_LCAP];
+  uint32_t lit_lo;                // entry offset of the lowest literal/length sub-table of the block: tables below it are distance tables
 #ifdef V4_PAD_LDS
   uint32_t pad_lds[V4_PAD_LDS / 4];  // occupancy experiment only
 #endif
   union {
-    uint8_t win[V4_WIN] __attribute__((aligned(16)));
+    uint8_t win[V4_WIN + 16] __attribute__((aligned(16)));  // (+ 16: the near copy reads whole 16-byte chunks)
     V4Build b;
   };
 };
@@ -223,10 +235,15 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uin
 // code per lane (groups by comparing root prefixes of neighbours, sizes by a suffix scan -- sub-tables are handed out
 // from the END of the sub-table space, so a group's place is known from the groups to its right alone), root entries one
 // symbol per lane.
-__device__ __forceinline__ int v4_build(V4Lds& L, const uint8_t* lens, int n, uint32_t* fast, uint32_t abs_off, int root_bits, int sub_cap,
-                        uint16_t* sorted, bool is_dist, int lane) {
+// `root`: entry offset of the root table.  Sub-tables: the literal/length alphabet takes them from `sub_hi` downwards, the
+// distance alphabet (one chunk of symbols, so the total is known at once) from `sub_lo` upwards; `sub_total` = entries
+// taken.  Returns 1 for an invalid code, 2 when the sub-tables do not fit [sub_lo, sub_hi).
+__device__ __forceinline__ int v4_build(V4Lds& L, const uint8_t* lens, int n, uint32_t root, int root_bits, uint32_t sub_lo, uint32_t sub_hi,
+                        uint16_t* sorted, bool is_dist, int lane, uint32_t& sub_total) {
+  uint32_t* const fast = L.tab;
+  sub_total = 0;
   V4_SYNC();
-  for (int i = lane; i < (1 << root_bits) + sub_cap; i += WAVE) fast[i] = E4_BAD;  // bit patterns no code maps to
+  for (int i = lane; i < (1 << root_bits); i += WAVE) fast[root + i] = E4_BAD;  // bit patterns no code maps to
   // 1. histogram of code lengths: 64 symbols per step, one ballot per length value; lane l keeps count[l]
   uint32_t my_cnt = 0;
   for (int c0 = 0; c0 < n; c0 += WAVE) {
@@ -319,10 +336,13 @@ __device__ __forceinline__ int v4_build(V4Lds& L, const uint8_t* lens, int n, ui
       const int tl = tmask ? lane + __builtin_ctzll(tmask) : lane;
       uint32_t sbits = (uint32_t)__shfl((int)sub_len, tl, WAVE);
       if (!tmask) sbits = carry_sbits;
-      if (__ballot(in && suf > (uint32_t)sub_cap) != 0ull) { over = 1; break; }
-      const uint32_t base = (1u << root_bits) + (uint32_t)sub_cap - suf;  // entry index of the group's sub-table
+      const uint32_t tot_here = __builtin_amdgcn_readlane(suf, 0);  // everything from this chunk's first group to the right
+      if (tot_here > sub_hi - sub_lo) { over = 2; break; }
+      // entry offset of the group's sub-table (distance alphabet: its codes longer than the root are < 64, one chunk)
+      const uint32_t base = is_dist ? sub_lo + tot_here - suf : sub_hi - suf;
+      sub_total = tot_here;
       // (every sub-table size is a power of two >= 2 and the space ends on an even entry, so `base` is even)
-      if (is_tail) fast[bitrev2(prefix, root_bits)] = v4_enc(sbits, abs_off + base, (uint32_t)root_bits, 0u, 0u);  // following the pointer consumes the root bits
+      if (is_tail) fast[root + bitrev2(prefix, root_bits)] = v4_enc(sbits, base, (uint32_t)root_bits, 0u, 0u);  // following the pointer consumes the root bits
       if (in) {
         const uint32_t r = bitrev2(code, (int)len) >> root_bits;  // bits after the root, LSB-first
         const uint32_t e = sym_entry((int)sym, (int)sub_len, is_dist);
@@ -332,7 +352,7 @@ __device__ __forceinline__ int v4_build(V4Lds& L, const uint8_t* lens, int n, ui
       carry_sbits = __builtin_amdgcn_readlane(sbits, 0);
       carry_suffix = __builtin_amdgcn_readlane(suf, 0);
     }
-    if (over) return 1;
+    if (over) return over;
   }
   // 5. root entries: one symbol per lane, replicated over the unused high index bits
   for (uint32_t k = lane; k < k0; k += WAVE) {
@@ -341,7 +361,7 @@ __device__ __forceinline__ int v4_build(V4Lds& L, const uint8_t* lens, int n, ui
     const uint32_t c = (uint32_t)L.b.t_first[l] + (k - L.b.t_offs[l]);
     const uint32_t r = bitrev2(c, l);
     const uint32_t e = sym_entry(sym, l, is_dist);
-    for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[i] = e;
+    for (uint32_t i = r; i < (1u << root_bits); i += (1u << l)) fast[root + i] = e;
   }
   V4_SYNC();
   return 0;
@@ -436,6 +456,7 @@ __device__ __forceinline__ bool v4_count(V4Lds& L, bool active, uint32_t start, 
   const uint32_t p0 = run0 ? pos : 0u;
   V4_WIN_DECL(p0);
   uint32_t tb = V4_LIT_ROOT, st = (uint32_t)V4_LIT_BITS, mlen = 0;
+  const uint32_t lit_lo = uni2(L.lit_lo);
   uint32_t cd = V4_CK_STEPS, c = 0;  // wave-uniform: steps to the next checkpoint, checkpoint row
   uint32_t cn = 0;
   bool overflow = false;
@@ -462,7 +483,7 @@ __device__ __forceinline__ bool v4_count(V4Lds& L, bool active, uint32_t start, 
 #ifdef V4_ASM_MARKERS
       asm volatile("; V4LOOP_BEGIN %0" ::"n"(0));
 #endif
-      const bool in_lit = tb < V4_DIST_ROOT;
+      const bool in_lit = tb >= lit_lo;
       const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos);
       const uint32_t e = L.tab[tb + __builtin_amdgcn_ubfe(w, 0u, st)];
       const uint32_t adv = V4_ADV(e);
@@ -530,7 +551,7 @@ __device__ __forceinline__ uint32_t v4_sync_asm(V4Lds& L, uint32_t start, uint32
     "v_add_u32 %[pos], %[pos], %[t]\n\t"
     "v_bfe_u32 %[tb], %[st], 4, 11\n\t"
     V4_ASM_CROSS
-    "v_cmp_ne_u32 vcc, 0, %[tb]\n\t"              // not on a symbol boundary
+    "v_cmp_ne_u32 vcc, %[clit], %[tb]\n\t"        // not on a symbol boundary
     "v_cmp_gt_u32 %[s1], %[cf], %[pos]\n\t"       // or in front of count_from: carry on
     "s_or_b64 vcc, vcc, %[s1]\n\t"
     "s_and_b64 exec, exec, vcc\n\t"
@@ -540,14 +561,14 @@ __device__ __forceinline__ uint32_t v4_sync_asm(V4Lds& L, uint32_t start, uint32
     "s_waitcnt lgkmcnt(0)"
     : [pos] "+v"(pos), [tb] "+v"(tb), [st] "+v"(st), [d0] "+v"(d0), [d1] "+v"(d1), [nxt] "+v"(nxt), [xc] "+v"(xc),
       [w] "=&v"(w), [t] "=&v"(t), [sav] "=&s"(sav), [s1] "=&s"(s1)
-    : [run] "s"(run), [cf] "v"(count_from), [soff] "n"(offsetof(V4Lds, stage) + 4)
+    : [run] "s"(run), [cf] "v"(count_from), [clit] "s"(V4_LIT_ROOT), [soff] "n"(offsetof(V4Lds, stage) + 4)
     : "vcc", "scc", "memory");
   return pos;
 }
 
 // One block of at most V4_CK_STEPS count steps for the lanes in `run` (see v4_count).
 __device__ __forceinline__ void v4_count_asm_block(unsigned long long& run, uint32_t& pos, uint32_t& tb, uint32_t& st, uint32_t& d0, uint32_t& d1,
-                                                   uint32_t& nxt, uint32_t& xc, uint32_t& acc, uint32_t& mlen, uint32_t limit) {
+                                                   uint32_t& nxt, uint32_t& xc, uint32_t& acc, uint32_t& mlen, uint32_t limit, uint32_t lit_lo) {
   uint32_t w, t, a, k;
   unsigned long long sav, s1, s2, s3;
   asm volatile(
@@ -557,7 +578,7 @@ __device__ __forceinline__ void v4_count_asm_block(unsigned long long& run, uint
     "s_movk_i32 %[k], %[ksteps]\n"
     "1:\n\t"
     "v_alignbit_b32 %[w], %[d1], %[d0], %[pos]\n\t"
-    "v_cmp_gt_u32 %[s3], %[cdist], %[tb]\n\t"     // this lookup is in a literal/length table
+    "v_cmp_le_u32 %[s3], %[clo], %[tb]\n\t"       // this lookup is in a literal/length table
     "v_bfe_u32 %[t], %[w], 0, %[st]\n\t"
     "v_add_lshl_u32 %[t], %[t], %[tb], 2\n\t"
     "ds_read_b32 %[st], %[t]\n\t"
@@ -567,9 +588,9 @@ __device__ __forceinline__ void v4_count_asm_block(unsigned long long& run, uint
     "v_bfe_u32 %[tb], %[st], 4, 11\n\t"
     V4_ASM_CROSS
     "v_bfe_u32 %[t], %[st], 20, 4\n\t"            // eb
-    "v_cmp_eq_u32 %[s2], %[cdist], %[tb]\n\t"     // a length symbol: the next lookup is the distance root
+    "v_cmp_eq_u32 %[s2], 0, %[tb]\n\t"            // a length symbol: the next lookup is the distance root
     "v_sub_u32 %[a], %[a], %[t]\n\t"              // code bits
-    "v_cmp_eq_u32 vcc, 0, %[tb]\n\t"              // a literal or a distance symbol: back on a symbol boundary
+    "v_cmp_eq_u32 vcc, %[clit], %[tb]\n\t"        // a literal or a distance symbol: back on a symbol boundary
     "v_bfe_u32 %[a], %[w], %[a], %[t]\n\t"        // extra bits
     "v_lshlrev_b32_sdwa %[t], %[t], %[st] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  // m << eb
     "v_add3_u32 %[t], %[t], %[a], %[clen]\n\t"    // length + (1 << 20): the match count rides in the same accumulator
@@ -592,7 +613,7 @@ __device__ __forceinline__ void v4_count_asm_block(unsigned long long& run, uint
     : [run] "+s"(run), [pos] "+v"(pos), [tb] "+v"(tb), [st] "+v"(st), [d0] "+v"(d0), [d1] "+v"(d1), [nxt] "+v"(nxt), [xc] "+v"(xc),
       [acc] "+v"(acc), [mlen] "+v"(mlen), [w] "=&v"(w), [t] "=&v"(t), [a] "=&v"(a), [k] "=&s"(k),
       [sav] "=&s"(sav), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
-    : [limit] "v"(limit), [soff] "n"(offsetof(V4Lds, stage) + 4), [cdist] "s"(V4_DIST_ROOT), [cstop] "s"(V4_STOP_EOB), [clen] "s"(3u + (1u << 20)),
+    : [limit] "v"(limit), [soff] "n"(offsetof(V4Lds, stage) + 4), [clo] "s"(lit_lo), [clit] "s"(V4_LIT_ROOT), [cstop] "s"(V4_STOP_EOB), [clen] "s"(3u + (1u << 20)),
       [ksteps] "n"(V4_CK_STEPS - 1)
     : "vcc", "scc", "memory");
 }
@@ -604,11 +625,12 @@ __device__ __forceinline__ bool v4_count_asm(V4Lds& L, bool active, uint32_t sta
   const uint32_t p0 = run0 ? pos : 0u;
   uint32_t d0 = L.stage[p0 >> 5], d1 = L.stage[(p0 >> 5) + 1u], nxt = L.stage[(p0 >> 5) + 2u], xc = (p0 & ~31u) + 32u;
   uint32_t tb = V4_LIT_ROOT, st = (uint32_t)V4_LIT_BITS, mlen = 0;
+  const uint32_t lit_lo = uni2(L.lit_lo);
   uint32_t c = 0, cn = 0;
   bool overflow = false;
   unsigned long long run = __ballot(run0);
   while (run != 0ull) {
-    v4_count_asm_block(run, pos, tb, st, d0, d1, nxt, xc, acc, mlen, limit);
+    v4_count_asm_block(run, pos, tb, st, d0, d1, nxt, xc, acc, mlen, limit, lit_lo);
     // (an SGPR result of inline asm counts as divergent; said to be uniform, the loops around this one stay scalar)
     run = (unsigned long long)uni2((uint32_t)run) | (unsigned long long)uni2((uint32_t)(run >> 32)) << 32;
     if (run == 0ull) break;
@@ -643,13 +665,14 @@ __device__ __forceinline__ uint32_t v4_write(V4Lds& L, bool active, uint32_t pos
   const uint32_t p0 = run0 ? pos : 0u;
   V4_WIN_DECL(p0);
   uint32_t tb = tb0, st = mb0;
+  const uint32_t lit_lo = uni2(L.lit_lo);
   bool run = run0, bad = false;
   while (__ballot(run) != 0ull) {
     if (run) {
 #ifdef V4_ASM_MARKERS
       asm volatile("; V4LOOP_BEGIN %0" ::"n"(MODE));
 #endif
-      const bool in_lit = tb < V4_DIST_ROOT;
+      const bool in_lit = tb >= lit_lo;
       const uint32_t w = __builtin_amdgcn_alignbit(d1, d0, pos);
       const uint32_t e = L.tab[tb + __builtin_amdgcn_ubfe(w, 0u, st)];
       const uint32_t adv = V4_ADV(e);
@@ -666,7 +689,14 @@ __device__ __forceinline__ uint32_t v4_write(V4Lds& L, bool active, uint32_t pos
       if (is_len) mlen = val + 3u;
       bool okm = is_dist;
       if (okm && val >= opos) { bad = true; okm = false; }   // distance val + 1 reaches before the output's start
-      if (okm && !V4_G(mpos >= V4_ML_ENTRIES, 3, mpos)) { uint2 ent; ent.x = opos; ent.y = mlen | ((val + 1u) << 12); ((uint2*)mlist)[mpos] = ent; }  // = opos | mlen << 32 | dist << 44
+      if (MODE == 1) { if (okm && !V4_G(mpos >= V4_ML_ENTRIES, 3, mpos)) { uint2 ent; ent.x = opos; ent.y = mlen | ((val + 1u) << 12); ((uint2*)mlist)[mpos] = ent; } }  // = opos | mlen << 32 | dist << 44
+      if (MODE == 2) {
+        if (okm && !V4_G(mpos >= V4_LCAP, 3, mpos)) {
+          uint8_t* q = (L.win - win_base) + opos;
+          L.ml16[mpos] = (uint16_t)(opos - win_base);
+          q[0] = (uint8_t)(mlen - 3u); q[1] = (uint8_t)val; q[2] = (uint8_t)(val >> 8);
+        }
+      }
       mpos += okm ? 1u : 0u;
       opos += is_lit ? 1u : (okm ? mlen : 0u);
       run = !(done && pos >= limit) && tb < V4_STOP_EOB && pos < stop_any && !bad;
@@ -681,28 +711,25 @@ __device__ __forceinline__ uint32_t v4_write(V4Lds& L, bool active, uint32_t pos
 
 // The write loop of a segment whose output lands in the LDS window (v4_write<2>, written out: 30 vector + 14 scalar
 // instructions per step against 43 + 60 from the compiler).  `orel` is the lane's output position relative to the window's
-// first byte R; matches go to the wave's match list at byte offset mp8 (8 bytes each: position | length << 32 | distance << 44).
-// The loop has no wait but the table lookup's: the compressed bits come from LDS, the list stores are not read back before
-// the resolve.
+// first byte R; a match goes to the on-chip list (V4Lds::ml16, byte offset mp8 = 2 x its number in the mini-round).
+// The loop has no wait but the table lookup's: the compressed bits come from LDS and so does everything it writes.
 __device__ __forceinline__ uint32_t v4_write_win_asm(V4Lds& L, bool active, uint32_t pos, uint32_t tb, uint32_t st, uint32_t mlen,
-                                                     uint32_t limit, uint32_t stop_any, uint32_t orel, uint32_t R,
-                                                     unsigned long long* mlist, uint32_t mp8) {
+                                                     uint32_t limit, uint32_t stop_any, uint32_t orel, uint32_t R, uint32_t mp8) {
   const bool run0 = active && pos < stop_any;
   const uint32_t p0 = run0 ? pos : 0u;
   uint32_t d0 = L.stage[p0 >> 5], d1 = L.stage[(p0 >> 5) + 1u], nxt = L.stage[(p0 >> 5) + 2u], xc = (p0 & ~31u) + 32u;
   uint32_t w, t, a;
   const unsigned long long run = __ballot(run0);
   unsigned long long sav, s1, s2, s3, s4, sbad = 0;
-  // (said to be uniform: an "s" operand the compiler takes for divergent is handed over in vector registers)
-  const unsigned long long ml = (unsigned long long)uni2((uint32_t)(uintptr_t)mlist) | (unsigned long long)uni2((uint32_t)((uintptr_t)mlist >> 32)) << 32;
-  R = uni2(R);
+  R = uni2(R);   // (said to be uniform: an "s" operand the compiler takes for divergent is handed over in vector registers)
+  const uint32_t lit_lo = uni2(L.lit_lo);
   asm volatile(
     "s_mov_b64 %[sav], exec\n\t"
     "s_and_b64 exec, exec, %[run]\n\t"
     "s_cbranch_execz 2f\n"
     "1:\n\t"
     "v_alignbit_b32 %[w], %[d1], %[d0], %[pos]\n\t"
-    "v_cmp_gt_u32 %[s3], %[cdist], %[tb]\n\t"     // this lookup is in a literal/length table
+    "v_cmp_le_u32 %[s3], %[clo], %[tb]\n\t"       // this lookup is in a literal/length table
     "v_bfe_u32 %[t], %[w], 0, %[st]\n\t"
     "v_add_lshl_u32 %[t], %[t], %[tb], 2\n\t"
     "ds_read_b32 %[st], %[t]\n\t"
@@ -712,9 +739,9 @@ __device__ __forceinline__ uint32_t v4_write_win_asm(V4Lds& L, bool active, uint
     "v_bfe_u32 %[tb], %[st], 4, 11\n\t"
     V4_ASM_CROSS
     "v_bfe_u32 %[t], %[st], 20, 4\n\t"            // eb
-    "v_cmp_eq_u32 %[s2], %[cdist], %[tb]\n\t"     // a length symbol
+    "v_cmp_eq_u32 %[s2], 0, %[tb]\n\t"            // a length symbol
     "v_sub_u32 %[a], %[a], %[t]\n\t"              // code bits
-    "v_cmp_eq_u32 %[s4], 0, %[tb]\n\t"            // a literal or a distance symbol: back on a symbol boundary
+    "v_cmp_eq_u32 %[s4], %[clit], %[tb]\n\t"      // a literal or a distance symbol: back on a symbol boundary
     "v_bfe_u32 %[a], %[w], %[a], %[t]\n\t"        // extra bits
     "v_lshlrev_b32_sdwa %[t], %[t], %[st] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t"  // m << eb
     "v_add3_u32 %[t], %[t], %[a], 3\n\t"          // a length (a distance + 2)
@@ -727,15 +754,18 @@ __device__ __forceinline__ uint32_t v4_write_win_asm(V4Lds& L, bool active, uint
     "v_add_u32 %[orel], 1, %[orel]\n\t"
     "s_mov_b64 exec, %[s1]\n\t"
     "s_and_saveexec_b64 %[s1], %[s3]\n\t"
-    "v_add_u32 %[a], -2, %[t]\n\t"                // the distance
+    "v_add_u32 %[a], -3, %[t]\n\t"                // the distance - 1
     "v_add_u32 %[w], %[cr], %[orel]\n\t"          // the absolute output position
-    "v_cmp_gt_u32 vcc, %[a], %[w]\n\t"            // reaches before the output's start
+    "v_cmp_ge_u32 vcc, %[a], %[w]\n\t"            // reaches before the output's start
     "s_or_b64 %[sbad], %[sbad], vcc\n\t"
     "s_andn2_b64 exec, exec, vcc\n\t"
-    "v_lshl_or_b32 %[a], %[a], 12, %[mlen]\n\t"
-    "global_store_dword %[mp8], %[w], %[ml]\n\t"
-    "global_store_dword %[mp8], %[a], %[ml] offset:4\n\t"
-    "v_add_u32 %[mp8], 8, %[mp8]\n\t"
+    "v_add_u32 %[w], -3, %[mlen]\n\t"
+    "ds_write_b16 %[mp8], %[orel] offset:%[loff]\n\t"     // where the match is ...
+    "ds_write_b8 %[orel], %[w] offset:%[woff]\n\t"        // ... and what it is, in its own first three bytes
+    "v_lshrrev_b32 %[w], 8, %[a]\n\t"
+    "ds_write_b8 %[orel], %[a] offset:%[woff1]\n\t"
+    "ds_write_b8 %[orel], %[w] offset:%[woff2]\n\t"
+    "v_add_u32 %[mp8], 2, %[mp8]\n\t"
     "v_add_u32 %[orel], %[orel], %[mlen]\n\t"
     "s_mov_b64 exec, %[s1]\n\t"
     "v_cmp_ge_u32 %[s1], %[pos], %[limit]\n\t"
@@ -753,8 +783,9 @@ __device__ __forceinline__ uint32_t v4_write_win_asm(V4Lds& L, bool active, uint
     : [pos] "+v"(pos), [tb] "+v"(tb), [st] "+v"(st), [d0] "+v"(d0), [d1] "+v"(d1), [nxt] "+v"(nxt), [xc] "+v"(xc),
       [mlen] "+v"(mlen), [orel] "+v"(orel), [mp8] "+v"(mp8), [sbad] "+s"(sbad), [w] "=&v"(w), [t] "=&v"(t), [a] "=&v"(a),
       [sav] "=&s"(sav), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3), [s4] "=&s"(s4)
-    : [run] "s"(run), [limit] "v"(limit), [stopany] "v"(stop_any), [cr] "s"(R), [ml] "s"(ml), [cdist] "s"(V4_DIST_ROOT),
-      [cstop] "s"(V4_STOP_EOB), [soff] "n"(offsetof(V4Lds, stage) + 4), [woff] "n"(offsetof(V4Lds, win))
+    : [run] "s"(run), [limit] "v"(limit), [stopany] "v"(stop_any), [cr] "s"(R), [clo] "s"(lit_lo), [clit] "s"(V4_LIT_ROOT),
+      [cstop] "s"(V4_STOP_EOB), [soff] "n"(offsetof(V4Lds, stage) + 4), [woff] "n"(offsetof(V4Lds, win)),
+      [woff1] "n"(offsetof(V4Lds, win) + 1), [woff2] "n"(offsetof(V4Lds, win) + 2), [loff] "n"(offsetof(V4Lds, ml16))
     : "vcc", "scc", "memory");
   const bool bad = ((sbad >> (threadIdx.x & 63)) & 1ull) != 0ull;
   return (bad || tb == V4_STOP_BAD) ? F_BAD : 0u;
@@ -950,37 +981,46 @@ __device__ __forceinline__ void v4_near_batch(uint8_t* win, uint32_t R, int lane
 // use_win: the range lives in the LDS window (two walks, see v4_far_copy / v4_near_batch) and is flushed to HBM with
 // coalesced 16-byte stores afterwards; otherwise literals are already in HBM and the matches are copied there.
 __device__ __forceinline__ void v4_resolve(V4Lds& L, uint8_t* out, unsigned long long* mlist, int lane, uint32_t R, uint32_t tot_out,
-                                           uint32_t tot_m, bool use_win, bool dbg, uint32_t& dbg_matches, uint32_t& dbg_near) {
+                                           uint32_t tot_m, bool use_win, bool dbg, uint32_t& dbg_matches, uint32_t& dbg_near, unsigned long long* tcx) {
+  unsigned long long tr0 = dbg ? clock64() : 0;
+#define RTOCK(i) do { if (dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t1 = clock64(); tcx[i] += t1 - tr0; tr0 = t1; } } while (0)  /* (the anatomy run drains the memory pipeline at every mark: what a phase waits for is charged to it) */
   unsigned long long m_next = 0;
-  if ((uint32_t)lane < tot_m) m_next = mlist[lane];
+  if (!use_win && (uint32_t)lane < tot_m) m_next = mlist[lane];
   if (use_win) {
-    uint32_t n_near = 0;  // matches that also read this round's window, compacted to the front of the list
-    // software pipeline: batch k + 1's list entry and far source are loaded before batch k's bytes are stored
-    unsigned long long m = m_next;
-    if (WAVE + (uint32_t)lane < tot_m) m_next = mlist[WAVE + lane];
+    // entry k of the on-chip list as destination | length << 32 | distance << 44 (0 behind the end)
+    auto entry = [&](uint32_t k) -> unsigned long long {
+      if (k >= tot_m) return 0ull;
+      const uint32_t rel = L.ml16[k];
+      const uint32_t h = ((const u32p*)(L.win + rel))->v;   // length - 3 | distance - 1 << 8 (the fourth byte is somebody else's)
+      return (unsigned long long)(R + rel) | (unsigned long long)((h & 0xFFu) + 3u) << 32 | (unsigned long long)(((h >> 8) & 0x7FFFu) + 1u) << 44;
+    };
+    uint32_t n_near = 0;  // matches that also read this round's window, compacted to the front of the wave's list in global memory
+    // software pipeline: batch k + 1's far source is loaded before batch k's bytes are stored.  (Every entry is read from the
+    // window before the copy of ITS match overwrites it: a batch's entries are in registers one batch ahead.)
+    unsigned long long m = entry((uint32_t)lane);
+    m_next = entry(WAVE + (uint32_t)lane);
     uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
     uint32_t nf = v4_far_count(R, (uint32_t)lane < tot_m, md, ml, mdist);
     u32x4 fv = v4_far_issue(out, nf, md, mdist);
     for (uint32_t k = 0; k < tot_m; k += WAVE) {
       const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
       const bool valid_m = (uint32_t)lane < nmb;
-      // next batch: entry (prefetched one batch earlier), far source load issued now
       const unsigned long long m2 = m_next;
-      if (k + 2 * WAVE + (uint32_t)lane < tot_m) m_next = mlist[k + 2 * WAVE + lane];
+      m_next = entry(k + 2 * WAVE + (uint32_t)lane);
       const uint32_t md2 = (uint32_t)(m2 & 0xFFFFFFFFull), ml2 = (uint32_t)((m2 >> 32) & 0xFFFu), mdist2 = (uint32_t)(m2 >> 44);
       const uint32_t nf2 = v4_far_count(R, k + WAVE + (uint32_t)lane < tot_m, md2, ml2, mdist2);
       const u32x4 fv2 = v4_far_issue(out, nf2, md2, mdist2);
-      // this batch: store
       v4_far_finish(L.win, out, R, nf, fv, md, mdist);
       const bool near = valid_m && md - mdist + ml > R;
       const unsigned long long nmask = __ballot(near);
-      if (near) mlist[n_near + __builtin_amdgcn_mbcnt_hi((uint32_t)(nmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nmask, 0u))] = m;  // < k + 64: never a slot still to be read
+      if (near) mlist[n_near + __builtin_amdgcn_mbcnt_hi((uint32_t)(nmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nmask, 0u))] = m;
       n_near += (uint32_t)__popcll(nmask);
       if (dbg) { dbg_matches += nmb; dbg_near += (uint32_t)__popcll(nmask); }
       m = m2; md = md2; ml = ml2; mdist = mdist2; nf = nf2; fv = fv2;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    RTOCK(3);
     if ((uint32_t)lane < n_near) m_next = mlist[lane];
     for (uint32_t k = 0; k < n_near; k += WAVE) {
       const uint32_t nmb = n_near - k < WAVE ? n_near - k : WAVE;
@@ -989,6 +1029,7 @@ __device__ __forceinline__ void v4_resolve(V4Lds& L, uint8_t* out, unsigned long
       const uint32_t md = (uint32_t)(m & 0xFFFFFFFFull), ml = (uint32_t)((m >> 32) & 0xFFFu), mdist = (uint32_t)(m >> 44);
       v4_near_batch(L.win, R, lane, (int)nmb, md, ml, mdist);
     }
+    RTOCK(4);
     // coalesced flush of the window (16 B per lane; the destination may be unaligned)
     uint8_t* dstp = out + R;
     const uint32_t full = tot_out & ~15u;
@@ -1000,6 +1041,7 @@ __device__ __forceinline__ void v4_resolve(V4Lds& L, uint8_t* out, unsigned long
     }
     if ((uint32_t)lane < (tot_out & 15u)) dstp[full + lane] = L.win[full + lane];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    RTOCK(5);
   } else {
     for (uint32_t k = 0; k < tot_m; k += WAVE) {
       const uint32_t nmb = tot_m - k < WAVE ? tot_m - k : WAVE;
@@ -1012,7 +1054,7 @@ __device__ __forceinline__ void v4_resolve(V4Lds& L, uint8_t* out, unsigned long
 }
 
 #ifndef V4_WAVES_PER_EU
-#define V4_WAVES_PER_EU 5
+#define V4_WAVES_PER_EU 4
 #endif
 template <int WPW, bool BOUNDED>
 __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4(const uint8_t* __restrict__ comp,
@@ -1067,6 +1109,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
   uint32_t fs_lanes[4] = {0, 0, 0, 0}, fs_iters[4] = {0, 0, 0, 0};  // lanes re-decoded by / runs of the 1st, 2nd, 3rd, later fix pass
 #endif
   unsigned long long tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tcx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0 = 0;
 #define TICK() (t0 = dbg ? clock64() : 0)
 #define TOCK(i) do { if (dbg) { unsigned long long t1 = clock64(); tc[i] += t1 - t0; t0 = t1; } } while (0)
@@ -1286,8 +1329,17 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
         }
       }
       TOCK(5);
-      if (v4_build(L, L.b.lens, 288, L.tab, 0u, V4_LIT_BITS, V4_LIT_SUB, L.b.lit_sorted, false, lane)) { st = INF_BAD_CODE | (3u << 8); break; }
-      if (v4_build(L, L.b.lens + 288, 32, L.tab + V4_DIST_ROOT, V4_DIST_ROOT, V4_DIST_BITS, V4_DIST_SUB, L.b.dist_sorted, true, lane)) { st = INF_BAD_CODE | (4u << 8); break; }
+      {
+        // literal/length sub-tables from the pool's high end, distance sub-tables from its low end; codes that need more
+        // than the pool holds go to the wide-table kernel
+        uint32_t lit_tot, dist_tot;
+        int rc = v4_build(L, L.b.lens, 288, V4_LIT_ROOT, V4_LIT_BITS, V4_POOL_LO, V4_LIT_ROOT, L.b.lit_sorted, false, lane, lit_tot);
+        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (3u << 8); break; }
+        rc = v4_build(L, L.b.lens + 288, 32, V4_DIST_ROOT, V4_DIST_BITS, V4_POOL_LO, V4_LIT_ROOT - lit_tot, L.b.dist_sorted, true, lane, dist_tot);
+        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (4u << 8); break; }
+        if (lane == 0) L.lit_lo = V4_LIT_ROOT - lit_tot;
+        V4_SYNC();
+      }
       P = ub_bitpos(in);
       TOCK(0);
 
@@ -1416,7 +1468,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           const uint32_t o_cn = (uint32_t)__shfl((int)cn, own, WAVE);
           const uint32_t o_acc = (uint32_t)__shfl((int)acc, own, WAVE);
           const uint32_t o_limit = rel0 + (uint32_t)(own + 1) * subb;
-          uint32_t p0 = o_start, a0 = 0, st0 = (uint32_t)V4_LIT_BITS << 12, p1 = 0xFFFFFFFFu, a1 = o_acc;
+          uint32_t p0 = o_start, a0 = 0, st0 = V4_LIT_ROOT | ((uint32_t)V4_LIT_BITS << 12), p1 = 0xFFFFFFFFu, a1 = o_acc;
           if (has && k > 0) {
             const uint32_t* q = ck + k * V4_CK_ROW + (uint32_t)own;        // row k = state after k * V4_CK_STEPS steps
             p0 = q[0]; a0 = q[64]; st0 = q[128];
@@ -1434,22 +1486,24 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           // Segments are consecutive in the output, so those whose bytes end inside the LDS window are a prefix of the
           // lanes: the mini-round takes that prefix (normally all 64) and the next one starts behind it.  A single segment
           // larger than the window (forty 258-byte matches) goes through HBM on its own.
-          const uint32_t n_fit = (uint32_t)__popcll(__ballot(has && my_opos + seg_out - R <= (uint32_t)V4_WIN));
+          const uint32_t n_fit = (uint32_t)__popcll(__ballot(has && my_opos + seg_out - R <= (uint32_t)V4_WIN && my_mabs + seg_m - M0 <= V4_LCAP));
           const bool use_win = n_fit != 0u;
           n_take = use_win ? n_fit : 1u;
           has = has && (uint32_t)lane < n_take;
           const uint32_t nl = n_take - 1u;  // last lane with a segment
           const uint32_t out_s = __builtin_amdgcn_readlane(my_opos + seg_out, nl) - R;
           const uint32_t m_s = __builtin_amdgcn_readlane(my_mabs + seg_m, nl) - M0;
-          if (m_s > (uint32_t)V4_ML_ENTRIES) { st = INF_OVERRUN | (1u << 8); break; }
+          if (!use_win && m_s > (uint32_t)V4_ML_ENTRIES) { st = INF_OVERRUN | (1u << 8); break; }
           if (dbg && !use_win) dbg_hbm++;
           {
             uint32_t f2 = 0;
             const uint32_t tb0 = st0 & 0xFFFu, mb0 = (st0 >> 12) & 15u, ml0 = st0 >> 16;
 #ifndef V4_ABLATE_WRITE
+            if (dbg) { const unsigned long long t1 = clock64(); tcx[0] += t1 - t0; }
+            const unsigned long long tw0 = dbg ? clock64() : 0;
             PRIO_WRITE(1);
             if (use_win) {
-              if constexpr (WPW == 1 && !V4_NO_ASM) f2 = v4_write_win_asm(L, has, p0, tb0, mb0, ml0, o_limit, p1, my_opos - R, R, mlist, (my_mabs - M0) * 8u);
+              if constexpr (WPW == 1 && !V4_NO_ASM) f2 = v4_write_win_asm(L, has, p0, tb0, mb0, ml0, o_limit, p1, my_opos - R, R, (my_mabs - M0) * 2u);
               else f2 = v4_write<2>(L, has, p0, tb0, mb0, ml0, o_limit, p1, out, my_opos, mlist, my_mabs - M0, R, gsrc);
             }
 #ifdef V4_GUARD
@@ -1459,6 +1513,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
 #endif
 #endif
             PRIO_WRITE(0);
+            if (dbg) tcx[1] += clock64() - tw0;
             dbg_minis++;
             if (__ballot(f2 & F_BAD) != 0ull) { st = INF_BAD_DIST; break; }
           }
@@ -1466,7 +1521,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           TOCK(3);
 #ifndef V4_ABLATE_RESOLVE
           PRIO_RESOLVE(1);
-          v4_resolve(L, out, mlist, lane, R, out_s, m_s, use_win, dbg != nullptr, dbg_matches, dbg_near);
+          v4_resolve(L, out, mlist, lane, R, out_s, m_s, use_win, dbg != nullptr, dbg_matches, dbg_near, tcx);
           PRIO_RESOLVE(0);
 #endif
           TOCK(4);
@@ -1497,7 +1552,10 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
 #if defined(V4_ABLATE_WRITE) || defined(V4_ABLATE_RESOLVE)
     st = INF_OK;  // timing-only build: the bytes are wrong on purpose
 #endif
-    if (lane == 0) status[b] = st;
+    if (lane == 0) {
+      status[b] = st;
+      if (st == INF_RETRY) atomicAdd(counter + 1, 1u);   // the launch that follows (inflate_v3.hip, retry mode) looks here first
+    }
   }
   if constexpr (BOUNDED) {
     V4_SYNC();
@@ -1509,6 +1567,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
     for (int i = 0; i < 5; i++) atomicAdd((unsigned long long*)(dbg + 2) + i, tc[i]);
     atomicAdd((unsigned long long*)(dbg + 26), tc[5]);
     atomicAdd((unsigned long long*)(dbg + 28), tc[6]);
+    for (int i = 0; i < 8; i++) atomicAdd((unsigned long long*)(dbg + 32) + i, tcx[i]);
     atomicAdd(&dbg[12], dbg_matches);
     atomicAdd(&dbg[13], dbg_near);
     atomicAdd(&dbg[22], dbg_minis);

@@ -14,7 +14,8 @@ constexpr uint32_t SEG_BYTES = 65536;      // record-chain segment size (bytes o
 // per-block inflate status codes (0 = ok)
 enum InflateStatus : uint32_t {
   INF_OK = 0, INF_BAD_HEADER = 1, INF_BAD_BTYPE = 2, INF_BAD_CODE = 3, INF_BAD_DIST = 4,
-  INF_OVERRUN = 5, INF_SIZE_MISMATCH = 6, INF_BAD_STORED = 7, INF_CRC_MISMATCH = 8
+  INF_OVERRUN = 5, INF_SIZE_MISMATCH = 6, INF_BAD_STORED = 7, INF_CRC_MISMATCH = 8,
+  INF_RETRY = 9   // K1 v4: the Huffman codes of a block need more sub-table space than its LDS pool holds; the wide-table kernel decodes the member
 };
 
 // ---- K1: BGZF inflate -------------------------------------------------------------------------
@@ -32,7 +33,7 @@ int v3_resident_wg_per_cu();
 void launch_bgzf_inflate_v3(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
                             uint32_t n_blocks, uint32_t* status, uint32_t* counter, unsigned long long* scratch,
                             uint32_t grid, uint32_t* dbg, hipStream_t st, uint32_t* slots = nullptr, uint32_t n_slots = 0,
-                            uint32_t per_wave = 0, uint32_t wpw = 0, const uint32_t* pre = nullptr);
+                            uint32_t per_wave = 0, uint32_t wpw = 0, const uint32_t* pre = nullptr, bool retry_only = false);
 // K1 with the v4 decode step (inflate_v4.hip): same launch contract and scratch layout.
 int v4_resident_wg_per_cu();
 void launch_bgzf_inflate_v4(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,

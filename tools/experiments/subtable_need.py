@@ -73,4 +73,5 @@ def main():
           "dist sub max/avg %d/%.0f" % (max(n[1] for n in needs), sum(n[1] for n in needs) / len(needs)),
           "max code len lit %d dist %d" % (max(n[2] for n in needs), max(n[3] for n in needs)))
 
-main()
+if __name__ == "__main__":
+    main()
