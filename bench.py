@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 DEFAULT_BLOCKS = 655360  # config 2: ~10 GiB compressed BGZF-BAM
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak (MI355X_MICROARCH.md)
-K1_NAME = "k_bgzf_inflate_v3"
+K1_NAME = "k_bgzf_inflate_v4"
 
 
 COLL_DEVICE = "cuda"  # where the bench's own collectives (barrier, MAX of times, SUM of counts) live
@@ -373,16 +373,24 @@ def main():
     synth = os.path.join(ROOT, "tools", "_build", "synth_bam")
     if not os.path.exists(synth):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tools")])
-    # indexed mode at N > 1 (config 5): ONE file of --blocks x N members, written by rank 0 and opened by every rank;
-    # otherwise every rank writes its own file of --blocks members.
-    # The file (~26 KB per member) goes to /dev/shm when it fits there with room to spare, else to /tmp; if neither has the
-    # space the member count is reduced and reported as such.
+    # indexed mode at N > 1 (config 5): ONE file of --blocks x N members, opened by every rank and COMPRESSED BY EVERY RANK: rank
+    # k generates the k-th of N contiguous runs of the file's tiles (tools/synth_bam.c `part K N`, the file is a pure
+    # function of (members, seed) tile by tile) with its share of the box's cores, then copies its run to its place in the
+    # file (`place K N`; rank 0 adds header, EOF member and the merged BAI) -- r03 had rank 0 compress all N shares alone
+    # (~36 s per share on a 16-core grant, seven ranks waiting in a broadcast).  Otherwise every rank writes its own file.
+    # The file (~26 KB per member) goes to /dev/shm when it fits there with room to spare, else to /tmp.  If neither has the
+    # space: at N = 1 the member count is reduced and reported as such; at N > 1 the bench REFUSES (a per-GPU size that
+    # differs from the N = 1 line would make the scaling curve meaningless).
     shared = world > 1 and args.mode == "indexed"
     ncpu = os.cpu_count() or 1
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
     path, meta, t_gen = None, None, 0.0
+    need = int(args.blocks * 27000 * 1.15) * max(1, world)
+    shm = None
     if rank == 0 or not shared:
-        need = int(args.blocks * 27000 * 1.15) * max(1, world)
-        shm = None
         for cand in ("/dev/shm", "/tmp"):
             try:
                 if os.path.isdir(cand) and os.access(cand, os.W_OK):
@@ -393,21 +401,41 @@ def main():
             except OSError:
                 pass
         if shm is None:
+            if world > 1:
+                avail = {c: os.statvfs(c).f_bavail * os.statvfs(c).f_frsize for c in ("/dev/shm", "/tmp") if os.path.isdir(c)}
+                raise SystemExit(f"bench.py --gpus {world}: the input needs {need / 1e9:.0f} GB of scratch space "
+                                 f"({args.blocks} members per GPU) and neither /dev/shm nor /tmp has it ({avail}); "
+                                 f"run with a smaller --blocks on every N of the curve instead of letting N > 1 shrink alone")
             shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
             vfs = os.statvfs(shm)
-            fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / max(1, world) / (27000 * 1.15))
+            fit = int(vfs.f_bavail * vfs.f_frsize * 0.8 / (27000 * 1.15))
             args.blocks = max(4096, min(args.blocks, fit))
-        path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.bam")
-        file_blocks = args.blocks * (world if shared else 1)
-        gen_threads = max(1, min(16 * world, ncpu)) if shared else max(1, min(16, ncpu // max(1, world)))
-        t0 = time.time()
-        seed = 42 if args.mode == "indexed" else 42 + rank
-        meta = json.loads(subprocess.check_output([synth, path, str(file_blocks), str(seed), str(gen_threads)]).decode())
-        t_gen = time.time() - t0
+    t0 = time.time()
     if shared:
-        box = [path, meta, args.blocks]
+        box = [os.path.join(shm, f"bioscan_synth_{os.getpid()}_shared.bam") if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, device=torch.device(COLL_DEVICE if COLL_DEVICE == "cpu" else f"cuda:{local_rank}"))
-        path, meta, args.blocks = box
+        path = box[0]
+        gen_threads = max(1, ncpu // world)
+        common = [synth, path, str(args.blocks * world), "42", str(gen_threads), "6"]
+        subprocess.check_output(common + ["part", str(rank), str(world)])
+        dist.barrier()          # every part and its sidecar exist
+        out = subprocess.check_output(common + ["place", str(rank), str(world)]).decode()
+        dist.barrier()          # the file is whole
+        box = [json.loads(out) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, device=torch.device(COLL_DEVICE if COLL_DEVICE == "cpu" else f"cuda:{local_rank}"))
+        meta = box[0]
+        if rank == 0:
+            for k in range(world):
+                try:
+                    os.unlink(f"{path}.part{k}.idx")
+                except OSError:
+                    pass
+    else:
+        path = os.path.join(shm, f"bioscan_synth_{os.getpid()}_r{rank}.bam")
+        gen_threads = max(1, min(16, ncpu // max(1, world)))
+        seed = 42 if args.mode == "indexed" else 42 + rank
+        meta = json.loads(subprocess.check_output([synth, path, str(args.blocks), str(seed), str(gen_threads)]).decode())
+    t_gen = time.time() - t0
 
     # ---- CPU baseline sample (rank 0, N == 1 only): read now, timed after the GPU steps ----
     cpu = None
@@ -528,7 +556,7 @@ def main():
 
     def k1_source_hash():
         import hashlib
-        with open(os.path.join(ROOT, "datafusion-bio-formats_amd", "csrc", "inflate_v3.hip"), "rb") as f:
+        with open(os.path.join(ROOT, "datafusion-bio-formats_amd", "csrc", "inflate_v4.hip"), "rb") as f:
             return hashlib.sha256(f.read()).hexdigest()[:16]
 
     def pmc_traffic_per_member():

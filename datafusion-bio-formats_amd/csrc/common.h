@@ -61,6 +61,7 @@ void set_last_error(const std::string& msg);
 //   BIOSCAN_DEBUG=1            diagnostics on stderr (K1 pass counters, record-chain rounds)
 //   BIOSCAN_LAPS=1             host wall-clock laps of execute() on stderr
 //   BIOSCAN_K1_WAVES_PER_CU=n  persistent-grid size of K1 (default: the occupancy API's answer)
+//   BIOSCAN_K1=3               K1 as of r03 (inflate_v3.hip) for every member; default 4 = inflate_v4.hip, v3 only for its retries
 //   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 64)
 //   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 16384)
 //   BIOSCAN_CHUNK_MEMBERS_DEVICE=n  the same for bioscan_execute_device (default 1048576; 65536 with BIOSCAN_LOOKAHEAD=1)
@@ -68,7 +69,7 @@ void set_last_error(const std::string& msg);
 struct EnvKnobs {
   bool debug = false, laps = false;
   int k1_waves_per_cu = 0;
-  int k1_version = 3;     // BIOSCAN_K1=4: the v4 decode step (inflate_v4.hip)
+  int k1_version = 4;     // BIOSCAN_K1=3: the r02/r03 kernel (inflate_v3.hip; always the wide-table fallback of v4) for every member
   double host_pool_gb = 64.0;
   double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
   uint32_t chunk_members = 16384;          // BGZF members per pipeline chunk of a host stream (~1.3 GB of Arrow buffers for short reads)

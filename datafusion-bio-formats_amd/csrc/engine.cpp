@@ -48,7 +48,7 @@ const EnvKnobs& env_knobs() {
     if (const char* e = getenv("BIOSCAN_LOOKAHEAD")) v.lookahead = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_ONESHOT")) v.k1_oneshot = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_PREHEADERS")) v.k1_preheaders = atoi(e);
-    if (const char* e = getenv("BIOSCAN_K1")) v.k1_version = atoi(e) == 4 ? 4 : 3;
+    if (const char* e = getenv("BIOSCAN_K1")) v.k1_version = atoi(e) == 3 ? 3 : 4;
     if (v.k1_version == 4 && !getenv("BIOSCAN_K1_PREHEADERS")) v.k1_preheaders = 1;  // v4 runs 16 waves per CU: the serial header parse is worth taking out of it (-7 %)
     if (const char* e = getenv("BIOSCAN_K1_PER_WAVE")) v.k1_per_wave = atoi(e);
     if (const char* e = getenv("BIOSCAN_K1_BOUNDED_WPW")) v.k1_bounded_wpw = atoi(e);

@@ -1056,14 +1056,18 @@ __device__ __forceinline__ void v4_resolve(V4Lds& L, uint8_t* out, unsigned long
 #ifndef V4_WAVES_PER_EU
 #define V4_WAVES_PER_EU 4
 #endif
-template <int WPW, bool BOUNDED>
+// DBG: the anatomy counters (BIOSCAN_DEBUG=1) are their own instantiation -- sixteen 64-bit cycle sums and seven event
+// counters are ~45 of a wave's ~100 scalar registers, and carried as dead weight they spill (a third of the kernel's
+// static vector instructions were v_readlane / v_writelane of spilled scalars).
+template <int WPW, bool BOUNDED, bool DBG>
 __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4(const uint8_t* __restrict__ comp,
                                                            const uint64_t* __restrict__ blk_coff,
                                                            const uint64_t* __restrict__ blk_uoff, uint8_t* out_all,
                                                            uint32_t n_blocks, uint32_t* __restrict__ status,
                                                            uint32_t* counter, unsigned long long* scratch,
-                                                           uint32_t scratch_stride, uint32_t* dbg, uint32_t* slots, uint32_t n_slots,
+                                                           uint32_t scratch_stride, uint32_t* dbg_arg, uint32_t* slots, uint32_t n_slots,
                                                            uint32_t per_wave, const uint32_t* __restrict__ pre) {
+  uint32_t* const dbg = DBG ? dbg_arg : nullptr;
   __shared__ V4Lds L_all[WPW];
   V4Lds& L = L_all[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;
@@ -1591,7 +1595,7 @@ void v4_guard_report() {
 int v4_resident_wg_per_cu() {
   int n = 0;
   // resident WAVES per CU (= members decoded concurrently per CU)
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v4<V4_WAVES_PER_WG, false>, WAVE * V4_WAVES_PER_WG, 0) != hipSuccess || n < 1) n = 8;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bgzf_inflate_v4<V4_WAVES_PER_WG, false, false>, WAVE * V4_WAVES_PER_WG, 0) != hipSuccess || n < 1) n = 8;
   return n * V4_WAVES_PER_WG;
 }
 void launch_bgzf_inflate_v4(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff, uint8_t* out,
@@ -1607,16 +1611,20 @@ void launch_bgzf_inflate_v4(const uint8_t* comp, const uint64_t* blk_coff, const
     const uint32_t per_wg = wpw * per_wave;
     const uint32_t g = (n_blocks + per_wg - 1) / per_wg;
     if (wpw == 1)
-      hipLaunchKernelGGL((k_bgzf_inflate_v4<1, true>), dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+      hipLaunchKernelGGL((k_bgzf_inflate_v4<1, true, false>), dim3(g), dim3(WAVE), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
                          status, counter, scratch, (uint32_t)V4_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave, pre);
     else
-      hipLaunchKernelGGL((k_bgzf_inflate_v4<V4_BOUNDED_WPW, true>), dim3(g), dim3(WAVE * V4_BOUNDED_WPW), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+      hipLaunchKernelGGL((k_bgzf_inflate_v4<V4_BOUNDED_WPW, true, false>), dim3(g), dim3(WAVE * V4_BOUNDED_WPW), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
                          status, counter, scratch, (uint32_t)V4_SCRATCH_STRIDE, dbg, slots, n_slots, per_wave, pre);
   } else {
     uint32_t g = grid < n_blocks ? grid : n_blocks;
     g = (g + V4_WAVES_PER_WG - 1) / V4_WAVES_PER_WG;  // `grid` counts waves; the scratch holds grid + V4_WAVES_PER_WG strides
-    hipLaunchKernelGGL((k_bgzf_inflate_v4<V4_WAVES_PER_WG, false>), dim3(g), dim3(WAVE * V4_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
-                       status, counter, scratch, (uint32_t)V4_SCRATCH_STRIDE, dbg, nullptr, 0u, 0u, pre);
+    if (dbg)
+      hipLaunchKernelGGL((k_bgzf_inflate_v4<V4_WAVES_PER_WG, false, true>), dim3(g), dim3(WAVE * V4_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                         status, counter, scratch, (uint32_t)V4_SCRATCH_STRIDE, dbg, nullptr, 0u, 0u, pre);
+    else
+      hipLaunchKernelGGL((k_bgzf_inflate_v4<V4_WAVES_PER_WG, false, false>), dim3(g), dim3(WAVE * V4_WAVES_PER_WG), 0, st, comp, blk_coff, blk_uoff, out, n_blocks,
+                         status, counter, scratch, (uint32_t)V4_SCRATCH_STRIDE, nullptr, nullptr, 0u, 0u, pre);
   }
 #ifdef V4_GUARD
   v4_guard_report();

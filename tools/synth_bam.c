@@ -11,7 +11,13 @@
  * The file is a pure function of (n_blocks, seed): work is cut into tiles of TILE_BLOCKS
  * members, each generated from its own seeded PRNG, so the thread count never changes a byte.
  *
- * usage: synth_bam OUT.bam N_BLOCKS [SEED=42] [THREADS=nproc] [LEVEL=6]
+ * usage: synth_bam OUT.bam N_BLOCKS [SEED=42] [THREADS=nproc] [LEVEL=6] [part K W | place K W]
+ *
+ * The last form builds ONE file from W processes (bench.py --gpus N: every rank compresses its share): `part K W` generates
+ * the K-th of W contiguous runs of tiles into OUT.bam.partK (+ .idx: sizes and the run's share of the BAI, offsets relative
+ * to the run), `place K W` -- once every part exists -- copies part K to its offset in OUT.bam (tail first, truncating the part
+ * as it goes: no second copy of the file in /dev/shm); K = 0 also writes the header member, the EOF member and the merged BAI
+ * and prints the JSON line.  The result is byte for byte the file of the one-process form.
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
@@ -22,6 +28,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #define TILE_BLOCKS 64
@@ -93,7 +101,7 @@ static int g_level = 6;
 static uint64_t g_seed = 42;
 static tile_t* g_tiles;
 static size_t g_ntiles;
-static size_t g_next_tile;
+static size_t g_next_tile, g_end_tile;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
 static void put32(uint8_t* p, uint32_t v) { p[0] = v; p[1] = v >> 8; p[2] = v >> 16; p[3] = v >> 24; }
@@ -290,7 +298,7 @@ static void* worker(void* arg) {
     pthread_mutex_lock(&g_mu);
     size_t i = g_next_tile++;
     pthread_mutex_unlock(&g_mu);
-    if (i >= g_ntiles) break;
+    if (i >= g_end_tile) break;
     gen_tile(&g_tiles[i], i);
   }
   return NULL;
@@ -321,13 +329,136 @@ static void bin_add(refidx_t* r, uint32_t bin, uint64_t beg, uint64_t end) {
   b->c[b->n].beg = beg; b->c[b->n].end = end; b->n++;
 }
 
+/* adds the records of tiles [t0, t1) to the index; tile_coff[i - t0] = compressed offset of tile i (absolute, or relative to a part) */
+static void index_tiles(refidx_t* ri, size_t t0, size_t t1, const uint64_t* tile_coff, uint64_t* n_no_coor) {
+  for (size_t i = t0; i < t1; i++) {
+    tile_t* t = &g_tiles[i];
+    uint64_t* bc = (uint64_t*)malloc((t->n_blocks + 1) * 8);
+    bc[0] = tile_coff[i - t0];
+    for (uint32_t b = 0; b < t->n_blocks; b++) bc[b + 1] = bc[b] + t->blk_clen[b];
+    for (size_t k = 0; k < t->n_rec; k++) {
+      uint64_t v0 = (bc[t->r_blk[k]] << 16) | t->r_off[k];
+      uint64_t v1;
+      if (k + 1 < t->n_rec && t->r_blk[k + 1] == t->r_blk[k]) v1 = (bc[t->r_blk[k]] << 16) | t->r_off[k + 1];
+      else v1 = bc[t->r_blk[k] + 1] << 16; /* end of member = start of the next */
+      if (t->ref < 0) { (*n_no_coor)++; continue; }
+      refidx_t* r = &ri[t->ref];
+      int64_t beg = t->r_pos[k], end = t->r_end[k] > t->r_pos[k] ? t->r_end[k] : t->r_pos[k] + 1;
+      bin_add(r, (uint32_t)reg2bin(beg, end), v0, v1);
+      size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+      if (w1 + 1 > r->nlin) {
+        r->lin = (uint64_t*)realloc(r->lin, (w1 + 1) * 8);
+        for (size_t w = r->nlin; w <= w1; w++) r->lin[w] = 0;
+        r->nlin = w1 + 1;
+      }
+      for (size_t w = w0; w <= w1; w++) if (!r->lin[w]) r->lin[w] = v0;
+      if (!r->ref_beg) r->ref_beg = v0;
+      r->ref_end = v1;
+      if (t->r_unmapped[k]) r->n_unmapped++; else r->n_mapped++;
+    }
+    free(bc);
+  }
+}
+
+static int write_bai(const char* out_path, refidx_t* ri, uint64_t n_no_coor) {
+  char bai_path[4096];
+  snprintf(bai_path, sizeof bai_path, "%s.bai", out_path);
+  FILE* f = fopen(bai_path, "wb");
+  if (!f) { perror(bai_path); return 1; }
+  uint8_t w8[16];
+  fwrite("BAI\1", 1, 4, f);
+  put32(w8, N_REF); fwrite(w8, 1, 4, f);
+  for (int r = 0; r < N_REF; r++) {
+    refidx_t* x = &ri[r];
+    int has_meta = x->n_mapped + x->n_unmapped > 0;
+    put32(w8, (uint32_t)(x->nbins + (has_meta ? 1 : 0))); fwrite(w8, 1, 4, f);
+    for (size_t b = 0; b < x->nbins; b++) {
+      put32(w8, x->bins[b].bin); put32(w8 + 4, (uint32_t)x->bins[b].n); fwrite(w8, 1, 8, f);
+      fwrite(x->bins[b].c, sizeof(chunk_t), x->bins[b].n, f);
+    }
+    if (has_meta) {
+      put32(w8, 37450); put32(w8 + 4, 2); fwrite(w8, 1, 8, f);
+      uint64_t m[4] = {x->ref_beg, x->ref_end, x->n_mapped, x->n_unmapped};
+      fwrite(m, 8, 4, f);
+    }
+    /* backfill empty linear windows with the previous entry (htslib) */
+    for (size_t w = 1; w < x->nlin; w++) if (!x->lin[w]) x->lin[w] = x->lin[w - 1];
+    put32(w8, (uint32_t)x->nlin); fwrite(w8, 1, 4, f);
+    fwrite(x->lin, 8, x->nlin, f);
+  }
+  fwrite(&n_no_coor, 8, 1, f);
+  fclose(f);
+  return 0;
+}
+
+/* a part's sidecar: sizes, then its share of the index with offsets relative to the part's first byte */
+typedef struct { uint64_t comp_len, total_u, n_rec, n_no_coor, n_blocks; } part_hdr_t;
+static int idx_save(const char* path, const part_hdr_t* h, refidx_t* ri) {
+  FILE* f = fopen(path, "wb");
+  if (!f) { perror(path); return 1; }
+  fwrite(h, sizeof *h, 1, f);
+  for (int r = 0; r < N_REF; r++) {
+    refidx_t* x = &ri[r];
+    uint64_t m[6] = {x->nbins, x->nlin, x->ref_beg, x->ref_end, x->n_mapped, x->n_unmapped};
+    fwrite(m, 8, 6, f);
+    for (size_t b = 0; b < x->nbins; b++) {
+      uint64_t bh[2] = {x->bins[b].bin, x->bins[b].n};
+      fwrite(bh, 8, 2, f);
+      fwrite(x->bins[b].c, sizeof(chunk_t), x->bins[b].n, f);
+    }
+    fwrite(x->lin, 8, x->nlin, f);
+  }
+  return fclose(f) ? 1 : 0;
+}
+/* merges a part's index (read from `path`) behind what `ri` holds, its offsets shifted by the part's place in the file */
+static int idx_merge(const char* path, uint64_t base, refidx_t* ri) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { perror(path); return 1; }
+  part_hdr_t h;
+  if (fread(&h, sizeof h, 1, f) != 1) return 1;
+  const uint64_t sh = (base - 1) << 16;   /* (a part counts its offsets from 1) */
+  for (int r = 0; r < N_REF; r++) {
+    refidx_t* x = &ri[r];
+    uint64_t m[6];
+    if (fread(m, 8, 6, f) != 6) return 1;
+    for (uint64_t b = 0; b < m[0]; b++) {
+      uint64_t bh[2];
+      if (fread(bh, 8, 2, f) != 2) return 1;
+      chunk_t* c = (chunk_t*)malloc((size_t)(bh[1] ? bh[1] : 1) * sizeof(chunk_t));
+      if (fread(c, sizeof(chunk_t), (size_t)bh[1], f) != (size_t)bh[1]) return 1;
+      for (uint64_t k = 0; k < bh[1]; k++) bin_add(x, (uint32_t)bh[0], c[k].beg + sh, c[k].end + sh);
+      free(c);
+    }
+    uint64_t* lin = (uint64_t*)malloc((size_t)(m[1] ? m[1] : 1) * 8);
+    if (fread(lin, 8, (size_t)m[1], f) != (size_t)m[1]) return 1;
+    if (m[1] > x->nlin) {
+      x->lin = (uint64_t*)realloc(x->lin, (size_t)m[1] * 8);
+      for (size_t w = x->nlin; w < m[1]; w++) x->lin[w] = 0;
+      x->nlin = (size_t)m[1];
+    }
+    for (size_t w = 0; w < m[1]; w++) if (!x->lin[w] && lin[w]) x->lin[w] = lin[w] + sh;
+    free(lin);
+    if (!x->ref_beg && m[2]) x->ref_beg = m[2] + sh;
+    if (m[3]) x->ref_end = m[3] + sh;
+    x->n_mapped += m[4]; x->n_unmapped += m[5];
+  }
+  fclose(f);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 3) { fprintf(stderr, "usage: %s OUT.bam N_BLOCKS [SEED] [THREADS] [LEVEL]\n", argv[0]); return 1; }
+  if (argc < 3) { fprintf(stderr, "usage: %s OUT.bam N_BLOCKS [SEED] [THREADS] [LEVEL] [part K W | place K W]\n", argv[0]); return 1; }
   const char* out_path = argv[1];
   uint64_t n_blocks = strtoull(argv[2], NULL, 10);
   if (argc > 3) g_seed = strtoull(argv[3], NULL, 10);
   int threads = argc > 4 ? atoi(argv[4]) : (int)sysconf(_SC_NPROCESSORS_ONLN);
   if (argc > 5) g_level = atoi(argv[5]);
+  int mode = 0, part_k = 0, part_w = 1;  /* 0: the whole file; 1: part K of W; 2: place part K of W */
+  if (argc > 8) {
+    mode = !strcmp(argv[6], "part") ? 1 : !strcmp(argv[6], "place") ? 2 : -1;
+    part_k = atoi(argv[7]); part_w = atoi(argv[8]);
+    if (mode < 0 || part_w < 1 || part_k < 0 || part_k >= part_w) { fprintf(stderr, "bad part arguments\n"); return 1; }
+  }
   if (threads < 1) threads = 1;
   if (!getenv("SYNTH_BAM_ZLIB")) load_libdeflate();
 
@@ -367,9 +498,42 @@ int main(int argc, char** argv) {
     g_tiles[i].n_blocks = (uint32_t)nb;
     left -= nb;
   }
-  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
-  for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, NULL);
-  for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+  /* the tiles this process generates: all of them, or the K-th of W contiguous runs */
+  const size_t t0 = mode ? ntiles * (size_t)part_k / (size_t)part_w : 0;
+  const size_t t1 = mode ? ntiles * (size_t)(part_k + 1) / (size_t)part_w : ntiles;
+  char part_path[4096], idx_path[4096];
+  snprintf(part_path, sizeof part_path, "%s.part%d", out_path, part_k);
+  snprintf(idx_path, sizeof idx_path, "%s.part%d.idx", out_path, part_k);
+
+  if (mode != 2) {
+    g_next_tile = t0; g_end_tile = t1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, worker, NULL);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+  }
+
+  if (mode == 1) {
+    /* the run's members back to back, and its sidecar */
+    FILE* f = fopen(part_path, "wb");
+    if (!f) { perror(part_path); return 1; }
+    part_hdr_t h = {0, 0, 0, 0, 0};
+    uint64_t* tile_coff = (uint64_t*)malloc((t1 - t0 + 1) * 8);
+    for (size_t i = t0; i < t1; i++) {
+      tile_coff[i - t0] = h.comp_len + 1;   /* (+ 1: a virtual offset of 0 means "none" in the index structures) */
+      if (fwrite(g_tiles[i].comp, 1, g_tiles[i].comp_len, f) != g_tiles[i].comp_len) { perror(part_path); return 1; }
+      h.comp_len += g_tiles[i].comp_len;
+      h.n_rec += g_tiles[i].n_rec;
+      for (uint32_t b = 0; b < g_tiles[i].n_blocks; b++) h.total_u += g_tiles[i].blk_ulen[b];
+      h.n_blocks += g_tiles[i].n_blocks;
+    }
+    if (fclose(f)) { perror(part_path); return 1; }
+    refidx_t* ri = (refidx_t*)calloc(N_REF, sizeof(refidx_t));
+    index_tiles(ri, t0, t1, tile_coff, &h.n_no_coor);
+    if (idx_save(idx_path, &h, ri)) return 1;
+    printf("{\"part\": %d, \"of\": %d, \"compressed_bytes\": %llu, \"n_blocks\": %llu}\n", part_k, part_w,
+           (unsigned long long)h.comp_len, (unsigned long long)h.n_blocks);
+    return 0;
+  }
 
   /* ---- header member ---- */
   char text[8192];
@@ -390,6 +554,55 @@ int main(int argc, char** argv) {
   void* ldc = ld_alloc ? ld_alloc(g_level) : NULL;
   size_t hmem_len = bgzf_member(ldc, hb, hl, hmem, 70000);
   if (ldc) ld_free(ldc);
+  static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  if (mode == 2) {
+    /* every part's size -> this part's place; copy it there tail first, giving the part's pages back as they are copied */
+    part_hdr_t* ph = (part_hdr_t*)calloc((size_t)part_w, sizeof(part_hdr_t));
+    uint64_t* base = (uint64_t*)calloc((size_t)part_w + 1, 8);
+    base[0] = hmem_len;
+    for (int k = 0; k < part_w; k++) {
+      char ip[4096];
+      snprintf(ip, sizeof ip, "%s.part%d.idx", out_path, k);
+      FILE* f = fopen(ip, "rb");
+      if (!f || fread(&ph[k], sizeof(part_hdr_t), 1, f) != 1) { perror(ip); return 1; }
+      fclose(f);
+      base[k + 1] = base[k] + ph[k].comp_len;
+    }
+    int out_fd = open(out_path, O_WRONLY | O_CREAT, 0644);
+    int in_fd = open(part_path, O_RDWR);
+    if (out_fd < 0 || in_fd < 0) { perror(out_fd < 0 ? out_path : part_path); return 1; }
+    const size_t CH = 64u << 20;
+    uint8_t* buf = (uint8_t*)malloc(CH);
+    uint64_t left_b = ph[part_k].comp_len;
+    while (left_b) {
+      const size_t n = left_b < CH ? (size_t)left_b : CH;
+      const uint64_t off = left_b - n;
+      if (pread(in_fd, buf, n, (off_t)off) != (ssize_t)n || pwrite(out_fd, buf, n, (off_t)(base[part_k] + off)) != (ssize_t)n) { perror("copy"); return 1; }
+      if (ftruncate(in_fd, (off_t)off)) { perror("ftruncate"); return 1; }
+      left_b = off;
+    }
+    close(in_fd);
+    unlink(part_path);
+    if (part_k != 0) { close(out_fd); printf("{\"placed\": %d}\n", part_k); return 0; }
+    if (pwrite(out_fd, hmem, hmem_len, 0) != (ssize_t)hmem_len || pwrite(out_fd, eof, 28, (off_t)base[part_w]) != 28) { perror(out_path); return 1; }
+    close(out_fd);
+    refidx_t* ri = (refidx_t*)calloc(N_REF, sizeof(refidx_t));
+    uint64_t total_u = hl, total_rec = 0, total_blocks = 2, n_no_coor = 0;
+    for (int k = 0; k < part_w; k++) {
+      char ip[4096];
+      snprintf(ip, sizeof ip, "%s.part%d.idx", out_path, k);
+      if (idx_merge(ip, base[k], ri)) { fprintf(stderr, "cannot merge %s\n", ip); return 1; }   /* (the caller removes the sidecars: the other parts read them too) */
+      total_u += ph[k].total_u; total_rec += ph[k].n_rec; total_blocks += ph[k].n_blocks; n_no_coor += ph[k].n_no_coor;
+    }
+    if (write_bai(out_path, ri, n_no_coor)) return 1;
+    printf("{\"path\": \"%s\", \"n_blocks\": %llu, \"n_records\": %llu, \"compressed_bytes\": %llu, \"inflated_bytes\": %llu, "
+           "\"n_no_coor\": %llu, \"seed\": %llu, \"level\": %d, \"deflate\": \"%s\", \"threads\": %d}\n",
+           out_path, (unsigned long long)total_blocks, (unsigned long long)total_rec, (unsigned long long)(base[part_w] + 28),
+           (unsigned long long)total_u, (unsigned long long)n_no_coor, (unsigned long long)g_seed, g_level,
+           ld_alloc ? "libdeflate" : "zlib", threads);
+    return 0;
+  }
 
   /* ---- write BAM ---- */
   FILE* f = fopen(out_path, "wb");
@@ -405,7 +618,6 @@ int main(int argc, char** argv) {
     for (uint32_t b = 0; b < g_tiles[i].n_blocks; b++) total_u += g_tiles[i].blk_ulen[b];
     total_blocks += g_tiles[i].n_blocks;
   }
-  static const uint8_t eof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   fwrite(eof, 1, 28, f);
   total_blocks++;
   uint64_t file_len = coff + 28;
@@ -414,61 +626,8 @@ int main(int argc, char** argv) {
   /* ---- BAI ---- */
   refidx_t* ri = (refidx_t*)calloc(N_REF, sizeof(refidx_t));
   uint64_t n_no_coor = 0;
-  for (size_t i = 0; i < ntiles; i++) {
-    tile_t* t = &g_tiles[i];
-    /* block compressed offsets inside the tile */
-    uint64_t* bc = (uint64_t*)malloc((t->n_blocks + 1) * 8);
-    bc[0] = tile_coff[i];
-    for (uint32_t b = 0; b < t->n_blocks; b++) bc[b + 1] = bc[b] + t->blk_clen[b];
-    for (size_t k = 0; k < t->n_rec; k++) {
-      uint64_t v0 = (bc[t->r_blk[k]] << 16) | t->r_off[k];
-      uint64_t v1;
-      if (k + 1 < t->n_rec && t->r_blk[k + 1] == t->r_blk[k]) v1 = (bc[t->r_blk[k]] << 16) | t->r_off[k + 1];
-      else v1 = bc[t->r_blk[k] + 1] << 16; /* end of member = start of the next */
-      if (t->ref < 0) { n_no_coor++; continue; }
-      refidx_t* r = &ri[t->ref];
-      int64_t beg = t->r_pos[k], end = t->r_end[k] > t->r_pos[k] ? t->r_end[k] : t->r_pos[k] + 1;
-      bin_add(r, (uint32_t)reg2bin(beg, end), v0, v1);
-      size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
-      if (w1 + 1 > r->nlin) {
-        r->lin = (uint64_t*)realloc(r->lin, (w1 + 1) * 8);
-        for (size_t w = r->nlin; w <= w1; w++) r->lin[w] = 0;
-        r->nlin = w1 + 1;
-      }
-      for (size_t w = w0; w <= w1; w++) if (!r->lin[w]) r->lin[w] = v0;
-      if (!r->ref_beg) r->ref_beg = v0;
-      r->ref_end = v1;
-      if (t->r_unmapped[k]) r->n_unmapped++; else r->n_mapped++;
-    }
-    free(bc);
-  }
-  char bai_path[4096];
-  snprintf(bai_path, sizeof bai_path, "%s.bai", out_path);
-  f = fopen(bai_path, "wb");
-  if (!f) { perror(bai_path); return 1; }
-  uint8_t w8[16];
-  fwrite("BAI\1", 1, 4, f);
-  put32(w8, N_REF); fwrite(w8, 1, 4, f);
-  for (int r = 0; r < N_REF; r++) {
-    refidx_t* x = &ri[r];
-    int has_meta = x->n_mapped + x->n_unmapped > 0;
-    put32(w8, (uint32_t)(x->nbins + (has_meta ? 1 : 0))); fwrite(w8, 1, 4, f);
-    for (size_t b = 0; b < x->nbins; b++) {
-      put32(w8, x->bins[b].bin); put32(w8 + 4, (uint32_t)x->bins[b].n); fwrite(w8, 1, 8, f);
-      fwrite(x->bins[b].c, sizeof(chunk_t), x->bins[b].n, f);
-    }
-    if (has_meta) {
-      put32(w8, 37450); put32(w8 + 4, 2); fwrite(w8, 1, 8, f);
-      uint64_t m[4] = {x->ref_beg, x->ref_end, x->n_mapped, x->n_unmapped};
-      fwrite(m, 8, 4, f);
-    }
-    /* backfill empty linear windows with the previous entry (htslib) */
-    for (size_t w = 1; w < x->nlin; w++) if (!x->lin[w]) x->lin[w] = x->lin[w - 1];
-    put32(w8, (uint32_t)x->nlin); fwrite(w8, 1, 4, f);
-    fwrite(x->lin, 8, x->nlin, f);
-  }
-  fwrite(&n_no_coor, 8, 1, f);
-  fclose(f);
+  index_tiles(ri, 0, ntiles, tile_coff, &n_no_coor);
+  if (write_bai(out_path, ri, n_no_coor)) return 1;
   printf("{\"path\": \"%s\", \"n_blocks\": %llu, \"n_records\": %llu, \"compressed_bytes\": %llu, \"inflated_bytes\": %llu, "
          "\"n_no_coor\": %llu, \"seed\": %llu, \"level\": %d, \"deflate\": \"%s\", \"threads\": %d}\n",
          out_path, (unsigned long long)total_blocks, (unsigned long long)total_rec, (unsigned long long)file_len,
