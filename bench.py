@@ -596,7 +596,17 @@ def main():
                "projections": {},
                "what": "bioscan_execute + bioscan_next until end of stream, every batch released at once; compressed file resident in "
                        "HBM, chunks of 2048 doubling to %d BGZF members, Arrow buffers copied D2H into recycled pinned blocks "
-                       "(BIOSCAN_HOST_POOL_GB=%s)" % (int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384)), os.environ.get("BIOSCAN_HOST_POOL_GB", "64"))}
+                       "(BIOSCAN_HOST_POOL_GB=%s)" % (int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384)), os.environ.get("BIOSCAN_HOST_POOL_GB", "8")),
+               "host_pool_gb": float(os.environ.get("BIOSCAN_HOST_POOL_GB", "8"))}
+        # the same stream with room for every result block of the scan (r03's default cap): what a host with memory to spare gets
+        if "BIOSCAN_HOST_POOL_GB" not in os.environ:
+            os.environ["BIOSCAN_HOST_POOL_GB"] = "64"   # (the library reads the cap at every release)
+            try:
+                rb = [plan.execute_drain(0, args.batch_size) for _ in range(2)][-1]
+                e2e["host_pool_64gb"] = {"Mrec_s": round(rb["n_rows"] / rb["seconds"] / 1e6, 3), "seconds": round(rb["seconds"], 3),
+                                         "link_GB_s": round(float(stats["arrow_bytes"]) / rb["seconds"] / 1e9, 3)}
+            finally:
+                del os.environ["BIOSCAN_HOST_POOL_GB"]
 
     if e2e is not None and args.projection == "*":
         # the same stream for the narrow projections (what `SELECT chrom, start` and `COUNT(*)` consumers get)

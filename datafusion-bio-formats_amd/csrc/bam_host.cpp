@@ -261,7 +261,7 @@ std::string format_sam_tag_type(char sam_type, ArrowKind k) {
 bool parse_bai(const std::vector<uint8_t>& d, Bai* out, std::string* err) {
   const size_t n = d.size();
   auto need = [&](size_t o, size_t k) { return o + k <= n; };
-  if (n < 8 || memcmp(d.data(), "BAI\1", 4) != 0) { *err = "invalid BAI magic"; return false; }
+  if (n < 8 || memcmp(d.data(), "BAI\1", 4) != 0) { *err = "invalid BAI header"; return false; }
   int32_t n_ref = rd_i32(&d[4]);
   size_t o = 8;
   out->refs.clear();

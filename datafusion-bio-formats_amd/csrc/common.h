@@ -62,7 +62,7 @@ void set_last_error(const std::string& msg);
 //   BIOSCAN_LAPS=1             host wall-clock laps of execute() on stderr
 //   BIOSCAN_K1_WAVES_PER_CU=n  persistent-grid size of K1 (default: the occupancy API's answer)
 //   BIOSCAN_K1=3               K1 as of r03 (inflate_v3.hip) for every member; default 4 = inflate_v4.hip, v3 only for its retries
-//   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 64)
+//   BIOSCAN_HOST_POOL_GB=x     cap of the recycled host result blocks (default 8; read at every release)
 //   BIOSCAN_CHUNK_MEMBERS=n    BGZF members per pipeline chunk of a host stream (default 16384)
 //   BIOSCAN_CHUNK_MEMBERS_DEVICE=n  the same for bioscan_execute_device (default 1048576; 65536 with BIOSCAN_LOOKAHEAD=1)
 //   BIOSCAN_LOOKAHEAD / BIOSCAN_K1_ONESHOT / BIOSCAN_LA_PRIORITY / BIOSCAN_LA_HEAD  the look-ahead inflate (engine.cpp: BamExecState)
@@ -70,7 +70,7 @@ struct EnvKnobs {
   bool debug = false, laps = false;
   int k1_waves_per_cu = 0;
   int k1_version = 4;     // BIOSCAN_K1=3: the r02/r03 kernel (inflate_v3.hip; always the wide-table fallback of v4) for every member
-  double host_pool_gb = 64.0;
+  double host_pool_gb = 8.0;    // idle host result blocks kept for reuse (a shared host tolerates 8 GB; r03 kept 64)
   double dev_pool_gb = 200.0;   // BIOSCAN_DEV_POOL_GB: cap of the cached (idle) device blocks
   uint32_t chunk_members = 16384;          // BGZF members per pipeline chunk of a host stream (~1.3 GB of Arrow buffers for short reads)
   uint32_t chunk_members_device = 1u << 20;  // device-resident execution keeps every chunk in HBM anyway: large chunks, short K1 tails

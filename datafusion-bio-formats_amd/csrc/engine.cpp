@@ -170,7 +170,13 @@ static size_t host_class(size_t bytes) {
   const size_t step = top >> 2;                                                  // four classes per octave
   return (bytes + step - 1) / step * step;
 }
-static size_t host_pool_limit() { return (size_t)(env_knobs().host_pool_gb * (double)(1ull << 30)); }
+// (read at every free, not once: the cap is the one knob a long-lived host process may want to move while it runs, and
+// bench.py reports its end-to-end leg under two caps from one process)
+static size_t host_pool_limit() {
+  double gb = env_knobs().host_pool_gb;
+  if (const char* e = getenv("BIOSCAN_HOST_POOL_GB")) gb = atof(e);
+  return (size_t)(gb * (double)(1ull << 30));
+}
 // Two kinds of cached host blocks.  Pageable ones serve one-shot copies (a fresh pageable block takes a copy at 17 GB/s and
 // a recycled one -- its pages already touched -- at the link rate, tools/experiments/d2h_paths.cpp).  Pinned ones serve the
 // chunk pipeline of a stream: hipMemcpyAsync only overlaps with the next chunk's kernels when the destination is pinned,
@@ -273,6 +279,7 @@ struct Provider : BgzfSource {
   std::vector<std::pair<std::string, std::string>> metadata;
 
   bool has_index = false;
+  std::string index_error;  // the companion index was found but is not a BAI this reader takes (e.g. a .csi): what the first indexed execute says
   std::string index_path;
   Bai bai;
 
@@ -1824,7 +1831,15 @@ struct Stream {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [this] { return !ready.empty() || producer_done; });
       if (!ready.empty()) { r = std::move(ready.front()); ready.pop_front(); cv.notify_all(); }
-      else if (producer_error) { auto e = producer_error; producer_error = nullptr; lk.unlock(); std::rethrow_exception(e); }
+      else if (producer_error) {
+        // sticky: a consumer that polls again after an error gets the error again, never the leftover rows and a clean end
+        // of stream that would make a truncated partition look complete
+        auto e = producer_error;
+        lk.unlock();
+        pending.clear();
+        pending_rows = 0;
+        std::rethrow_exception(e);
+      }
     }
     if (!r) return false;   // end of the partition
     cur = std::move(r);
@@ -2112,13 +2127,21 @@ int bioscan_bam_open(const char* path, const bioscan_bam_options* opts, bioscan_
     std::string b = stem + ".bai";
     if (file_exists(a)) { p.index_path = a; p.has_index = true; }
     else if (file_exists(b)) { p.index_path = b; p.has_index = true; }
+    else if (file_exists(p.path + ".csi")) { p.index_path = p.path + ".csi"; p.has_index = true; }  // discover_bam_index: BAI first, then CSI
   }
   if (p.has_index) {
+    // The reference keeps the discovered path and reads it with `bam::bai::fs::read` wherever it needs the index: a file that is
+    // not a BAI (a .csi companion, a damaged index) leaves the provider open, gives `scan` unit size estimates
+    // (storage.rs:344-360) and no no-coor partition (:442-449), and fails every indexed partition when it is executed
+    // (`IndexedBamReader::new`, storage.rs:286; physical_exec.rs:879-881).
     std::ifstream f(p.index_path, std::ios::binary);
-    if (!f.good()) throw Error("Failed to open indexed BAM: cannot read " + p.index_path);
-    std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     std::string e;
-    if (!parse_bai(d, &p.bai, &e)) throw Error("Failed to open indexed BAM: " + e);
+    if (!f.good()) e = "cannot read " + p.index_path;
+    else {
+      std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+      if (!parse_bai(d, &p.bai, &e)) p.bai = Bai();
+    }
+    p.index_error = e;
   }
   *out = bp.release();
   API_END
@@ -2344,9 +2367,9 @@ int bioscan_scan(const bioscan_provider* cp, const int32_t* projection, int32_t 
     if (regions.empty())
       for (auto& n : p.hdr.ref_names) { GenomicRegion r; r.chrom = n; regions.push_back(r); }
     if (!regions.empty()) {
-      auto est = estimate_sizes_from_bai(&p.bai, regions, p.hdr.ref_names, p.hdr.ref_lengths);
+      auto est = estimate_sizes_from_bai(p.index_error.empty() ? &p.bai : nullptr, regions, p.hdr.ref_names, p.hdr.ref_lengths);
       pl.assignments = balance_partitions(est, (size_t)std::max(target_partitions, 0));
-      if (full && p.bai.has_no_coor && p.bai.n_no_coor > 0) {
+      if (full && p.index_error.empty() && p.bai.has_no_coor && p.bai.n_no_coor > 0) {
         PartitionAssignment a;
         GenomicRegion r;
         r.chrom = "*";
@@ -2418,6 +2441,8 @@ static int execute_impl(const bioscan_plan* plan, int32_t partition, int32_t bat
   Stream& sm = bs->s;
   sm.prov = plan->pl.prov;
   sm.on_host = !device_only;
+  if (plan->pl.indexed && !plan->pl.prov->index_error.empty())
+    throw Error("Failed to open indexed BAM: " + plan->pl.prov->index_error);
   if (plan->pl.prov->kind == 1) {
     sm.cur = run_partition_fastq(plan->pl, partition, (uint32_t)batch_size, !device_only);
     sm.stats = sm.cur->stats;

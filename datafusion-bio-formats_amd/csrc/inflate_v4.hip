@@ -28,7 +28,7 @@ namespace bioscan {
 #define V4_SUB_DW 11          // longest sub-stream of a round, dwords: a round's compressed bits are staged in LDS (64 x this)
 #endif
 #ifndef V4_CK_STEPS
-#define V4_CK_STEPS 24        // decode steps between two checkpoints = longest segment of the write phase
+#define V4_CK_STEPS 20        // decode steps between two checkpoints = longest segment of the write phase
 #endif
 #ifndef V4_OV_MAX
 #define V4_OV_MAX 480         // pre-roll: half a sub-stream, at least V4_OV_MIN, at most this
@@ -55,14 +55,15 @@ constexpr int V4_WIN = V4_WIN_BYTES;                    // LDS output window of 
 // lane may look at behind the last sub-stream's end (a symbol that begins before the limit, the two prefetched dwords).
 constexpr uint32_t V4_LCAP = 256;                      // matches of a mini-round (together with the window size: what a mini-round takes)
 constexpr uint32_t V4_STAGE_SLACK = 16, V4_STAGE_DW = 64u * V4_SUB_DW + V4_STAGE_SLACK;
-// One table of 1024 32-bit entries, addressed in entry units (all table starts are even):
+// One table of 1076 32-bit entries, addressed in entry units (all table starts are even):
 //   [0, 64)             distance root
-//   [64, 508)           the sub-table POOL: distance sub-tables from its low end up, literal/length sub-tables from its
-//                       high end down (zlib's worst cases are 528 and 340 entries; config 2 needs 134 + 232, htslib-written
-//                       BAM 40 + 186 -- tools/experiments/subtable_need.py).  A block whose codes do not fit is not decoded
+//   [64, 560)           the sub-table POOL: distance sub-tables from its low end up, literal/length sub-tables from its
+//                       high end down (zlib's worst cases are 528 and 340 entries; 20 000 members of config 2 need 262 in the
+//                       median, 360 at the 99th percentile and 492 at most, htslib-written BAM 40 + 186 --
+//                       tools/experiments/subtable_need.py; the pool is what 16 waves per CU leave: 10 240 B of LDS each).  A block whose codes do not fit is not decoded
 //                       here: the member is marked INF_RETRY and the wide-table kernel (inflate_v3.hip) takes it.
-//   [508, 1020)         literal/length root
-//   [1020, 1022)        STOP_EOB                       [1022, 1024)  STOP_BAD
+//   [560, 1072)         literal/length root
+//   [1072, 1074)        STOP_EOB                       [1074, 1076)  STOP_BAD
 // Entry:  nmb [3:0]   index width of the NEXT lookup
 //         ntb [14:4]  entry offset of the table the NEXT lookup goes to (even, so bit 4 is 0 and v_bfe_u32 can take the
 //                     entry itself as its width operand); V4_LIT_ROOT = "a symbol is complete", 0 = the distance root =
@@ -77,9 +78,9 @@ constexpr uint32_t V4_STAGE_SLACK = 16, V4_STAGE_DW = 64u * V4_SUB_DW + V4_STAGE
 // distance 30, 31) to STOP_BAD.  The count and write loops retire a lane that is sent to a STOP table; the sync pass, which
 // decodes garbage on purpose, follows it: the STOP entries lead back to the root without consuming anything (BAD itself
 // consumes one bit, so a lane always moves on).
-constexpr uint32_t V4_DIST_ROOT = 0, V4_POOL_LO = 1u << V4_DIST_BITS, V4_POOL = 444, V4_LIT_ROOT = V4_POOL_LO + V4_POOL,
+constexpr uint32_t V4_DIST_ROOT = 0, V4_POOL_LO = 1u << V4_DIST_BITS, V4_POOL = 496, V4_LIT_ROOT = V4_POOL_LO + V4_POOL,
                    V4_STOP_EOB = V4_LIT_ROOT + (1u << V4_LIT_BITS), V4_STOP_BAD = V4_STOP_EOB + 2u, V4_NENT = V4_STOP_BAD + 2u;
-static_assert((V4_LIT_ROOT & 1u) == 0 && (V4_STOP_EOB & 1u) == 0 && V4_NENT == 1024u, "table starts are even and the table is 4 KiB");
+static_assert((V4_LIT_ROOT & 1u) == 0 && (V4_STOP_EOB & 1u) == 0 && V4_NENT < 2048u, "table starts are even and fit the 11-bit field");
 __host__ __device__ constexpr uint32_t v4_enc(uint32_t nmb, uint32_t ntb, uint32_t adv, uint32_t eb, uint32_t m) {
   return nmb | (ntb << 4) | (adv << 15) | (eb << 20) | (m << 24);
 }

@@ -728,7 +728,7 @@ class Bai:
 
 def parse_bai(data: bytes) -> Bai:
     if data[:4] != b"BAI\x01":
-        raise ValueError("bad BAI magic")
+        raise ValueError("invalid BAI header")
     n_ref = struct.unpack_from("<i", data, 4)[0]
     o = 8
     refs = []
@@ -1186,19 +1186,26 @@ class BamOracle:
             if unknown:
                 inferred = self._discover(unknown, infer_tag_sample_size)
         self.schema = self._determine_schema(inferred, hints)
-        # index discovery (index_utils.rs:68-83): <path>.bai, then <stem>.bai (csi not handled here)
+        # index discovery (index_utils.rs:44-77): <path>.bai, then <stem>.bai, then <path>.csi
         self.index_path = None
         if index_path == "auto":
-            for cand in (path + ".bai", os.path.splitext(path)[0] + ".bai"):
+            for cand in (path + ".bai", os.path.splitext(path)[0] + ".bai", path + ".csi"):
                 if os.path.exists(cand):
                     self.index_path = cand
                     break
         else:
             self.index_path = index_path
+        # The provider only keeps the path; every use reads it with `bam::bai::fs::read`.  A file that is not a BAI (the .csi
+        # companion, a damaged index): unit size estimates in `scan` (storage.rs:344-360), no no-coor partition (:442-449),
+        # and `IndexedBamReader::new` fails when an indexed partition is executed (storage.rs:286, physical_exec.rs:879-881).
         self.bai = None
+        self.index_error = None
         if self.index_path:
-            with open(self.index_path, "rb") as f:
-                self.bai = parse_bai(f.read())
+            try:
+                with open(self.index_path, "rb") as f:
+                    self.bai = parse_bai(f.read())
+            except (OSError, ValueError, struct.error) as e:
+                self.bai, self.index_error = None, str(e)
         # block lookup for virtual offsets
         self._coff_to_uoff = {c: uo for c, uo, _ in self.block_table}
         self._coffs = [c for c, _, _ in self.block_table]
@@ -1266,7 +1273,7 @@ class BamOracle:
                 est = estimate_sizes_from_bai(self.bai, regions, self.hdr.ref_names, self.hdr.ref_lengths)
                 parts = balance_partitions(est, target_partitions)
                 if full:
-                    n = self.bai.n_no_coor or 0
+                    n = (self.bai.n_no_coor or 0) if self.bai is not None else 0
                     if n:
                         parts.append(PartitionAssignment([GenomicRegion(UNPLACED_SENTINEL, None, None, True)], max(n, 1)))
                 tag_types = {}
@@ -1405,6 +1412,8 @@ class BamOracle:
 
     def execute_partition(self, regions, projection=None, residual=(), batch_size: int = 8192):
         """get_indexed_stream (physical_exec.rs:864-1372)."""
+        if self.index_error is not None:
+            raise ValueError("Failed to open indexed BAM: " + self.index_error)
         fl = self._flags(projection)
         names = self.hdr.ref_names
         rows = []

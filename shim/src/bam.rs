@@ -179,6 +179,8 @@ impl TableProvider for BamTableProvider {
                 }
             }
         }
-        Ok(Arc::new(BamWriteExec::new(input, path, tag_fields, self.sort_on_write, *self.options.device_ids.first().unwrap_or(&0))))
+        // the coordinate system of the rows is the TABLE's (table_provider.rs:1131-1135), not the input plan's
+        let zero_based = self.schema.metadata().get("bio.coordinate_system_zero_based").and_then(|s| s.parse::<bool>().ok()).unwrap_or(true);
+        Ok(Arc::new(BamWriteExec::new(input, path, tag_fields, zero_based, self.sort_on_write, *self.options.device_ids.first().unwrap_or(&0))))
     }
 }

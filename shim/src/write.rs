@@ -40,16 +40,19 @@ pub struct BamWriteExec {
     input: Arc<dyn ExecutionPlan>,
     output_path: String,
     tag_fields: Vec<String>,
+    coordinate_system_zero_based: bool,
     sort_on_write: bool,
     device_id: i32,
     cache: Arc<PlanProperties>,
 }
 
 impl BamWriteExec {
-    /// Arguments of the reference's `BamWriteExec::new` that still mean something here: the coordinate system and the tag
-    /// columns are read from the schema by the C side (`insert_into` derives both from the schema as well,
-    /// table_provider.rs:1131-1154); `tag_fields` is kept for `Debug` / `DisplayAs` parity.
-    pub fn new(input: Arc<dyn ExecutionPlan>, output_path: String, tag_fields: Vec<String>, sort_on_write: bool, device_id: i32) -> Self {
+    /// Arguments of the reference's `BamWriteExec::new` that still mean something here.  `tag_fields` (the TABLE schema's tag
+    /// columns plus the names given to `new_for_write`) and `coordinate_system_zero_based` (the TABLE schema's flag) are what
+    /// `insert_into` resolves (table_provider.rs:1131-1154); the C writer reads both from the schema it is handed, so
+    /// `writer_layout` below turns them into that schema: the input plan's own metadata does not decide either.
+    pub fn new(input: Arc<dyn ExecutionPlan>, output_path: String, tag_fields: Vec<String>, coordinate_system_zero_based: bool, sort_on_write: bool,
+               device_id: i32) -> Self {
         let output_schema = Arc::new(Schema::new(vec![Field::new("count", DataType::UInt64, false)]));
         let cache = Arc::new(PlanProperties::new(
             EquivalenceProperties::new(output_schema),
@@ -57,7 +60,7 @@ impl BamWriteExec {
             EmissionType::Final,
             Boundedness::Bounded,
         ));
-        Self { input, output_path, tag_fields, sort_on_write, device_id, cache }
+        Self { input, output_path, tag_fields, coordinate_system_zero_based, sort_on_write, device_id, cache }
     }
     pub fn output_path(&self) -> &str {
         &self.output_path
@@ -97,7 +100,8 @@ impl ExecutionPlan for BamWriteExec {
         if children.len() != 1 {
             return Err(DataFusionError::Internal("BamWriteExec requires exactly one child".to_string()));
         }
-        Ok(Arc::new(BamWriteExec::new(children[0].clone(), self.output_path.clone(), self.tag_fields.clone(), self.sort_on_write, self.device_id)))
+        Ok(Arc::new(BamWriteExec::new(children[0].clone(), self.output_path.clone(), self.tag_fields.clone(), self.coordinate_system_zero_based,
+                                      self.sort_on_write, self.device_id)))
     }
 
     fn execute(&self, _partition: usize, context: Arc<TaskContext>) -> datafusion::common::Result<SendableRecordBatchStream> {
@@ -118,22 +122,65 @@ impl ExecutionPlan for BamWriteExec {
             self.input.execute(0, context)?
         };
         let output_schema = self.cache.eq_properties.schema().clone();
-        let stream = futures::stream::once(write_stream(input, input_schema, self.output_path.clone(), self.sort_on_write, self.device_id, output_schema.clone()));
+        let layout = writer_layout(&input_schema, &self.tag_fields, self.coordinate_system_zero_based);
+        let stream = futures::stream::once(write_stream(input, layout, self.output_path.clone(), self.sort_on_write, self.device_id, output_schema.clone()));
         Ok(Box::pin(RecordBatchStreamAdapter::new(output_schema, stream)))
     }
+}
+
+/// The columns and the schema the C writer gets.  The reference serialises exactly the columns NAMED in `tag_fields`, in
+/// that order, whatever metadata the input field carries: a column's SAM type is its `bio.bam.tag.type` metadata, `Z` when
+/// there is none, a name that is not two bytes long is skipped, and a tag column of the input that is not listed is not
+/// written (`build_tag_data`, bio-format-core/src/sam_tag_io.rs:109-147).  The C writer writes every field that carries
+/// `bio.bam.tag.tag` in schema order and takes the coordinate system from `bio.coordinate_system_zero_based`, so: listed
+/// columns get that key (value = the column name, the tag the reference writes), unlisted ones lose it, the tag columns
+/// follow the other columns in `tag_fields` order, and the schema-level flag is the table's.
+pub(crate) struct WriterLayout {
+    indices: Vec<usize>,
+    schema: SchemaRef,
+}
+pub(crate) fn writer_layout(input_schema: &SchemaRef, tag_fields: &[String], coordinate_system_zero_based: bool) -> WriterLayout {
+    const TAG_KEY: &str = "bio.bam.tag.tag";
+    let listed = |name: &str| tag_fields.iter().any(|t| t == name) && name.as_bytes().len() == 2;
+    let mut indices: Vec<usize> = Vec::with_capacity(input_schema.fields().len());
+    let mut fields: Vec<Field> = Vec::with_capacity(input_schema.fields().len());
+    for (i, f) in input_schema.fields().iter().enumerate() {
+        if listed(f.name()) {
+            continue; // placed behind the other columns, in tag_fields order
+        }
+        let mut md = f.metadata().clone();
+        md.remove(TAG_KEY); // a tag column of the input that the table does not list is not written
+        indices.push(i);
+        fields.push(f.as_ref().clone().with_metadata(md));
+    }
+    for t in tag_fields {
+        if t.as_bytes().len() != 2 {
+            continue;
+        }
+        if let Ok(i) = input_schema.index_of(t) {
+            let f = input_schema.field(i);
+            let mut md = f.metadata().clone();
+            md.insert(TAG_KEY.to_string(), t.clone()); // (the SAM type stays the field's own `bio.bam.tag.type`, `Z` when absent)
+            indices.push(i);
+            fields.push(f.clone().with_metadata(md));
+        }
+    }
+    let mut md = input_schema.metadata().clone();
+    md.insert("bio.coordinate_system_zero_based".to_string(), coordinate_system_zero_based.to_string());
+    WriterLayout { indices, schema: Arc::new(Schema::new_with_metadata(fields, md)) }
 }
 
 /// write_bam_stream (write_exec.rs:281-336): open, every batch, finish, one row with the count.
 async fn write_stream(
     mut input: SendableRecordBatchStream,
-    input_schema: SchemaRef,
+    layout: WriterLayout,
     output_path: String,
     sort_on_write: bool,
     device_id: i32,
     output_schema: SchemaRef,
 ) -> datafusion::common::Result<RecordBatch> {
     let path = cstring(&output_path)?;
-    let c_schema = FFI_ArrowSchema::try_from(input_schema.as_ref()).map_err(|e| DataFusionError::ArrowError(Box::new(e), None))?;
+    let c_schema = FFI_ArrowSchema::try_from(layout.schema.as_ref()).map_err(|e| DataFusionError::ArrowError(Box::new(e), None))?;
     let mut raw: *mut ffi::bioscan_bam_writer = std::ptr::null_mut();
     check(unsafe { ffi::bioscan_bam_writer_open_schema(path.as_ptr(), &c_schema, sort_on_write as i32, device_id, &mut raw) })?;
     let writer = WriterHandle(raw);
@@ -142,6 +189,8 @@ async fn write_stream(
         if batch.num_rows() == 0 {
             continue;
         }
+        // the writer's columns under the writer's schema (see writer_layout)
+        let batch = batch.project(&layout.indices).and_then(|b| b.with_schema(layout.schema.clone())).map_err(|e| DataFusionError::ArrowError(Box::new(e), None))?;
         // a RecordBatch crosses the C Data Interface as a struct array (what bioscan_next hands out in the other direction)
         let data = StructArray::from(batch).into_data();
         let (c_array, c_batch_schema) = to_ffi(&data).map_err(|e| DataFusionError::ArrowError(Box::new(e), None))?;

@@ -2,6 +2,7 @@
 bam/src/physical_exec.rs:412-540): empty sequence, odd / long sequences, no CIGAR, every CIGAR op, unmapped reads,
 missing mates, read names of length 1 and 254, quality bytes >= 95 (two UTF-8 bytes each), records that span BGZF
 members, negative template lengths, records with many aux fields, tiny and single-record files."""
+import os
 import random
 import struct
 
@@ -142,3 +143,31 @@ def test_reference_names_of_every_length(pkg, oracle, tmp_path):
             got = list(prov.scan().execute(0, bs))
             _, want = orc.execute_sequential(None, bs)
             _cmp_batches(got, want, ("ref names", binary, bs))
+
+
+def test_csi_only_companion_plans_and_then_fails_like_the_reference(pkg, oracle, tmp_path):
+    """`discover_bam_index` (bio-format-core/src/index_utils.rs:68-77) finds `<bam>.csi` when there is no `.bai`; the BAM
+    provider then reads it with `bam::bai::fs::read` everywhere: `scan` gets unit size estimates (storage.rs:344-360) and no
+    no-coor partition (:442-449), and every indexed partition fails at `IndexedBamReader::new` (storage.rs:286,
+    physical_exec.rs:879-881: "Failed to open indexed BAM: ...").  r03 looked for `.bai` only and scanned sequentially."""
+    import shutil
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "multi_chrom.bam")
+    bam = str(tmp_path / "only_csi.bam")
+    shutil.copy(src, bam)
+    with open(bam + ".csi", "wb") as f:
+        f.write(b"CSI\x01" + bytes(64))
+    prov = pkg.BamTableProvider(bam)
+    orc = oracle.BamOracle(bam)
+    assert orc.index_path == bam + ".csi" and orc.index_error is not None
+    for target in (1, 2, 4):
+        plan = prov.scan(target_partitions=target)
+        parts, residual = orc.scan(target_partitions=target)
+        assert plan.num_partitions() == len(parts), target
+        for p in range(plan.num_partitions()):
+            with pytest.raises(pkg.BioscanError, match="Failed to open indexed BAM"):
+                list(plan.execute(p, 64))
+            with pytest.raises(ValueError, match="Failed to open indexed BAM"):
+                orc.execute_partition(parts[p].regions, None, residual, 64)
+    # a scan without the index (index_path="") still reads the file
+    seq = pkg.BamTableProvider(bam, index_path="")
+    assert sum(b.num_rows for b in seq.scan().execute(0, 8192)) == 421

@@ -178,3 +178,50 @@ def test_unmapped_tails_do_not_decode_the_rest_of_the_file(pkg, oracle, tmp_path
             inflated += plan.execute_device(p, 500)["n_blocks"]
         assert rows == (4 * 603 if index_unmapped else 4 * 600), rows   # (reads the index does not list and that have a position: no scan of the reference returns them)
         assert inflated <= n_members + 8 * len(parts) + 16, (inflated, n_members)
+
+
+def test_an_error_stays_an_error_when_the_stream_is_polled_again(pkg, tmp_path):
+    """after a failed chunk (here: a member whose CRC32 does not match) every later poll of the same stream
+    fails again -- never the rows that were pending and then a clean end of stream, which would make a truncated partition
+    look complete."""
+    import ctypes as C
+    rng = random.Random(11)
+    good = bytearray(bb.bam(REFS, _records(rng, 400), member=2048))
+    o, starts = 0, []
+    while o < len(good):
+        starts.append(o)
+        o += (good[o + 16] | (good[o + 17] << 8)) + 1
+    assert len(starts) > 12
+    m = starts[len(starts) - 4]                       # a late data member: the chunks in front of it are fine
+    end = m + (good[m + 16] | (good[m + 17] << 8)) + 1
+    good[end - 8] ^= 0x5A                             # its CRC32 field
+    path = str(tmp_path / "badcrc.bam")
+    open(path, "wb").write(bytes(good))
+    prov = pkg.BamTableProvider(path, None, True, None, index_path="", chunk_members=2)
+    plan = prov.scan()
+    lib = pkg.load_library()
+    st = C.c_void_p()
+    assert lib.bioscan_execute(plan._h, 0, 7, C.byref(st)) == 0
+    try:
+        import sys
+        tp = sys.modules[pkg.__name__ + ".table_provider"]
+        ok, failed = 0, 0
+        for _ in range(10000):
+            arr = tp._ArrowArray()
+            has = C.c_int32()
+            rc = lib.bioscan_next(st, C.addressof(arr), C.byref(has))
+            if rc != 0:
+                failed += 1
+                if failed == 3:
+                    break
+                continue
+            assert failed == 0, "a poll succeeded after the stream had failed"
+            if not has.value:
+                break
+            ok += 1
+            if arr.release:
+                rel = C.CFUNCTYPE(None, C.c_void_p)(arr.release)
+                rel(C.addressof(arr))
+        assert ok > 0 and failed == 3, (ok, failed)
+    finally:
+        lib.bioscan_stream_close(st)

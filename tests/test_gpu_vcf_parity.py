@@ -618,13 +618,19 @@ def test_gt_with_leading_zero_allele_is_refused(pkg, tmp_path):
 
 
 def test_large_file_properties(pkg, tmp_path):
-    """Size-independent properties on files too large for a value-by-value comparison (BIOSCAN_TEST_LARGE_LINES overrides
-    the 4 M-site default; 60 000 000 is BASELINE config 3): CRC32 + ISIZE of every member (a failure raises), every
+    """Size-independent properties on files too large for a value-by-value comparison (60 000 000 sites = BASELINE config 3 and
+    200 000 x 1000 samples = config 4 when the box allows, else 4 M sites and 20 000 x 500): CRC32 + ISIZE of every member (a failure raises), every
     generated line comes back, `chrom = 'chr1'` returns exactly the generator's count, a second run gives the same
     totals, and the tabix plans of 8 and 16 partitions return the same number of rows in total; the multi-sample form
     returns lines x samples list cells and the same UDF checksum on a second run."""
-    n_lines = int(os.environ.get("BIOSCAN_TEST_LARGE_LINES", "4000000"))
-    from conftest import scratch_dir
+    from conftest import scratch_dir, full_size_blocks
+    # BASELINE configs 3 and 4 at their own size (60 M sites; 200 000 lines x 1000 samples) when the box has the scratch space
+    # and the cores to write them in seconds, as the BAM twin does for config 2; BIOSCAN_TEST_LARGE_LINES overrides
+    if os.environ.get("BIOSCAN_TEST_LARGE_LINES"):
+        n_lines = int(os.environ["BIOSCAN_TEST_LARGE_LINES"])
+    else:
+        n_lines = full_size_blocks(60_000_000, 4_000_000, 45)
+    full = n_lines >= 60_000_000
     base = scratch_dir(n_lines * 45)
     path = os.path.join(base, f"bioscan_large_{os.getpid()}.vcf.gz")
     spath = os.path.join(base, f"bioscan_large_{os.getpid()}_s.vcf.gz")
@@ -635,7 +641,7 @@ def test_large_file_properties(pkg, tmp_path):
         first = plan.execute_device(0, 8192)
         from conftest import report_size
         report_size("test_large_file_properties[vcf]", lines=n_lines, members=first["n_blocks"],
-                    inflated_GB=round(first["inflated_bytes"] / 1e9, 2), multisample_lines=max(2000, n_lines // 200), samples=500)
+                    inflated_GB=round(first["inflated_bytes"] / 1e9, 2))
         assert first["n_rows"] == n_lines
         again = plan.execute_device(0, 8192)
         for k in ("n_rows", "n_blocks", "inflated_bytes", "arrow_bytes"):
@@ -649,7 +655,8 @@ def test_large_file_properties(pkg, tmp_path):
         assert sum(p.execute_device(i, 8192)["n_rows"] for i in range(p.num_partitions())) == meta["n_lines_chr1"]
         del prov, p
 
-        lines, samples = max(2000, n_lines // 200), 500
+        lines, samples = (200_000, 1000) if full else (max(2000, n_lines // 200), 500)
+        report_size("test_large_file_properties[vcf multi-sample]", lines=lines, samples=samples)
         _synth(tmp_path, "samples", spath, lines, samples, 19, min(16, os.cpu_count() or 1))
         ms = pkg.VcfTableProvider(spath, index_path="")
         mplan = ms.scan(target_partitions=1)

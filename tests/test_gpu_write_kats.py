@@ -380,3 +380,47 @@ def test_sliced_batches_and_columns_with_their_own_offsets(pkg, oracle, tmp_path
     path = write(pkg, tmp_path, mixed, name="mixed.bam")
     _, t = both(pkg, oracle, path, ["NM"])
     assert t["name"].to_pylist() == names and t["start"].to_pylist() == starts and t["NM"].to_pylist() == nm
+
+
+def shim_writer_layout(batch, tag_fields, table_zero_based):
+    """What shim/src/write.rs `writer_layout` hands to bioscan_bam_writer_*: the reference serialises exactly the columns
+    NAMED in the table's resolved `tag_fields` (its schema's tag columns + the names given to `new_for_write`,
+    table_provider.rs:1139-1154), in that order, SAM type = the field's `bio.bam.tag.type` or `Z` (`build_tag_data`,
+    bio-format-core/src/sam_tag_io.rs:109-147), and takes the coordinate system from the TABLE schema (:1131-1135)."""
+    sch = batch.schema
+    listed = lambda n: n in tag_fields and len(n.encode()) == 2  # noqa: E731
+    idx, fields = [], []
+    for i, f in enumerate(sch):
+        if listed(f.name):
+            continue
+        md = {k: v for k, v in (f.metadata or {}).items() if k != b"bio.bam.tag.tag"}
+        idx.append(i)
+        fields.append(f.with_metadata(md))
+    for t in tag_fields:
+        if len(t.encode()) == 2 and t in sch.names:
+            f = sch.field(t)
+            md = dict(f.metadata or {})
+            md[b"bio.bam.tag.tag"] = t.encode()
+            idx.append(sch.names.index(t))
+            fields.append(f.with_metadata(md))
+    md = dict(sch.metadata or {})
+    md[b"bio.coordinate_system_zero_based"] = b"true" if table_zero_based else b"false"
+    return pa.RecordBatch.from_arrays([batch.column(i) for i in idx], schema=pa.schema(fields, metadata=md))
+
+
+def test_insert_writes_the_tables_tag_fields_and_coordinate_system(pkg, oracle, tmp_path):
+    """an explicit tag without field metadata is written as type Z, a tag column of the INPUT that the table does
+    not list is not written, the aux fields follow the table's tag order, and a 1-based table shifts POS whatever the input
+    plan's schema says."""
+    md = {"bio.bam.reference_sequences": '[{"name":"chr1","length":1000}]', "bio.coordinate_system_zero_based": "true"}
+    xt = pa.field("XT", pa.string(), True)                                   # listed by new_for_write, no metadata at all
+    nm = tag_field("NM", pa.int32(), "i", "edit distance")                   # carries tag metadata, the table does not list it
+    as_ = tag_field("AS", pa.int32(), "i", "score")                          # the table schema's own tag column
+    b = make_batch([xt, nm, as_], [pa.array(["abc", None], pa.string()), pa.array([1, 2], pa.int32()), pa.array([7, 8], pa.int32())],
+                   2, metadata=md, starts=[100, 200])
+    laid = shim_writer_layout(b, ["AS", "XT", "toolong"], table_zero_based=False)
+    path = write(pkg, tmp_path, laid, name="layout.bam")
+    recs = aux_fields(path)
+    assert [list(r.items()) for r in recs] == [[("AS", ("i", 7)), ("XT", ("Z", "abc"))], [("AS", ("i", 8))]]
+    o = oracle.BamOracle(path, index_path=None)
+    assert [r.pos for r in oracle.iter_records(o.u, o.hdr.first_record_offset)] == [99, 199]   # 1-based rows -> 0-based BAM

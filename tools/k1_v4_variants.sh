@@ -5,6 +5,8 @@ C=$R/datafusion-bio-formats_amd/csrc
 O=$R/gpurun_out/k1_v4_variants.txt
 mkdir -p $R/gpurun_out; : > $O
 export BIOSCAN_K1=4
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/inflate_v4.hip; make -C $C >/dev/null 2>&1' EXIT
 IFS=';' read -ra CFGS <<< "${CFGS_STR:-}"
 for cfg0 in "${CFGS[@]}"; do
   # "@NAME=VALUE flags": an environment setting for the runs of this configuration
@@ -18,5 +20,4 @@ for cfg0 in "${CFGS[@]}"; do
   [ -n "$ANATOMY" ] && grep -E "of wave cycles" /tmp/k1.err | tail -14 >> $O
   timeout -k 10 300 python $R/bench.py --blocks 262144 --steps 4 --warmup 2 --no-cpu-baseline --no-end-to-end 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('cfg [$cfg0] 262144 blocks: inflate_ms', d['stage_ms']['inflate'], 'step', d['ms_per_step'])" >> $O 2>&1
 done
-touch $C/inflate_v4.hip; make -C $C >/dev/null 2>&1
 cat $O
