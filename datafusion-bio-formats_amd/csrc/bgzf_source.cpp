@@ -116,7 +116,9 @@ void BgzfSource::make_resident() {
     d_k1_scratch.alloc(((size_t)k1_grid + 8) * stride);
   }
   HIP_CHECK(hipStreamSynchronize(stream));
-  file.reset();  // the compressed bytes now live in HBM; the host image is not read again
+  // the compressed bytes now live in HBM.  A mapped file stays mapped (it costs address space, not memory): a later execute
+  // that streams a partition in chunks uploads its own range from it (image_for); a read copy is given back.
+  if (!file.mapped) file.reset();
   images.clear();  // (the header image of the open call)
   resident = true;
 }

@@ -729,7 +729,13 @@ static void copy_result_to_host(Result& res, hipStream_t st) {  // one-shot form
 // stream while the next chunk runs.  HBM footprint: two inflated chunk buffers + one chunk of Arrow buffers per result
 // in flight -- O(chunk), independent of the file size.
 // -------------------------------------------------------------------------------------------------
-struct BamExecState {
+// what a Stream polls: the next chunk of rows of a partition (never an empty one), nullptr at its end
+struct ChunkProducer {
+  bioscan_scan_stats total{};
+  virtual std::shared_ptr<Result> next_chunk() = 0;
+  virtual ~ChunkProducer() {}
+};
+struct BamExecState : ChunkProducer {
   const Plan& plan;
   Provider& p;
   const uint32_t batch_size;
@@ -777,7 +783,6 @@ struct BamExecState {
   std::vector<FilterTerm> terms;
   DevBuf<FilterTerm> d_terms;
   DevBuf<uint16_t> d_tags;
-  bioscan_scan_stats total{};
   std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
 
   BamExecState(const Plan& pl, int partition, uint32_t bs, bool host)
@@ -819,7 +824,7 @@ struct BamExecState {
     }
     HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above go out of scope
   }
-  ~BamExecState() {
+  ~BamExecState() override {
     // every stream of this execute is idle before any of its buffers (members declared after `k1` are destroyed first)
     // goes back to the shared pool -- also when an exception ended a chunk between a launch and its sync
     int prev = 0;
@@ -855,7 +860,7 @@ struct BamExecState {
   }
 
   // Next chunk of rows of the partition (never an empty one), or nullptr when the partition is exhausted.
-  std::shared_ptr<Result> next_chunk() {
+  std::shared_ptr<Result> next_chunk() override {
     if (dead) throw Error("the stream ended with an error");
     HIP_CHECK(hipSetDevice(img->device));
     struct Guard { bool* d; bool ok = false; ~Guard() { if (!ok) *d = true; } } guard{&dead};
@@ -1477,7 +1482,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       fc.val[k] = col.d_values.p; fc.off32[k] = col.d_off32.p; fc.base[k] = col.d_base.p;
       arrow_bytes += totals[k] + nb * ((uint64_t)batch_size + 1) * 4;
     }
-    launch_fastq_pass2(u, x0, hi - base, nl.p, n_nl, n, fc, batch_size, tile_sums.p, st);
+    launch_fastq_pass2(u, x0, hi - base, nl.p, n_nl, n, fc, batch_size, 0, tile_sums.p, st);
     HIP_CHECK(hipStreamSynchronize(st));
   }
   res->stats.ms_extract = t.stop();
@@ -1487,6 +1492,276 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
   if (to_host) copy_result_to_host(*res, st);
   return res;
 }
+
+// -------------------------------------------------------------------------------------------------
+// FastqExecState: the chunk pipeline of a BGZF FASTQ partition (bio-format-fastq/src/physical_exec.rs:393-465: the
+// reference reads record by record and never holds a partition).  Members are inflated `chunk_members` at a time; a
+// chunk's rows are its complete records that start before the partition's ownership threshold; the record cut by the
+// chunk's end is carried, as bytes, to the head of the next chunk's buffer; batches continue across chunks (`phase`).
+// HBM: two inflated chunk buffers + the newline index and Arrow buffers of one chunk -- O(chunk), not O(partition).
+// -------------------------------------------------------------------------------------------------
+struct FastqExecState : ChunkProducer {
+  const Plan& plan;
+  Provider& p;
+  const uint32_t batch_size;
+  const bool to_host;
+  const uint32_t chunk_members;
+  const bool ramp;
+  std::shared_ptr<DeviceImage> img;
+  K1Ctx k1;
+  hipStream_t st = nullptr, copy_st = nullptr;
+  uint64_t start = 0, end = ~0ull, T = 0;   // decoded offset the partition starts at; GZI end (compressed); ownership threshold
+  uint32_t b_start = 0;
+  uint32_t next_member = 0;
+  bool first = true, done = false, dead = false;
+  uint64_t carry_len = 0;
+  DevBuf<uint8_t> ubuf[2];
+  int cur = 0;
+  uint32_t chunks_done = 0, phase = 0;
+  uint64_t rows_emitted = 0;
+  std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
+
+  FastqExecState(const Plan& pl, int partition, uint32_t bs, bool host)
+      : plan(pl), p(*pl.prov), batch_size(bs), to_host(host),
+        chunk_members(pl.prov->chunk_members ? pl.prov->chunk_members : host ? env_knobs().chunk_members : env_knobs().chunk_members_device),
+        ramp(host && !pl.prov->chunk_members) {
+    if (plan.fq_strategy != 0) { start = plan.fq_parts[partition].first; end = plan.fq_parts[partition].second; }
+    uint32_t b_T = p.n_blocks();
+    T = p.ulen;
+    if (plan.fq_strategy == 1) {
+      auto it = std::lower_bound(p.blk_uoff.begin(), p.blk_uoff.end(), start);
+      if (it == p.blk_uoff.end() || *it != start) throw Error("GZI start offset does not address a block start");
+      b_start = (uint32_t)(it - p.blk_uoff.begin());
+      if (end != ~0ull) {
+        auto jt = std::lower_bound(p.blk_coff.begin(), p.blk_coff.end(), end);
+        b_T = (uint32_t)std::min<size_t>(jt - p.blk_coff.begin(), p.n_blocks());
+        T = p.blk_uoff[b_T];
+      }
+    }
+    next_member = b_start;
+    // (the record that starts just before the threshold may end a few members behind it; a partition's image is widened
+    // when that happens: BgzfSource::image_for)
+    img = p.device_image(plan.device_of(partition), b_start, std::min<uint32_t>(p.n_blocks(), b_T + 4));
+    HIP_CHECK(hipSetDevice(img->device));
+    p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(p.n_blocks() - b_start, 1)), false);
+    st = k1.stream;
+    if (to_host) HIP_CHECK(hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking));
+  }
+  ~FastqExecState() override {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (img) (void)hipSetDevice(img->device);
+    if (k1.stream) (void)hipStreamSynchronize(k1.stream);
+    if (copy_st) { (void)hipStreamSynchronize(copy_st); (void)hipStreamDestroy(copy_st); }
+    (void)hipSetDevice(prev);
+  }
+  uint32_t chunk_len(uint32_t k) const {
+    uint64_t c = chunk_members;
+    if (ramp) c = std::min<uint64_t>(c, 2048ull << std::min<uint32_t>(k, 16));
+    return (uint32_t)std::max<uint64_t>(c, 1);
+  }
+  void accumulate(const bioscan_scan_stats& s) {
+    total.n_blocks += s.n_blocks; total.compressed_bytes += s.compressed_bytes; total.inflated_bytes += s.inflated_bytes;
+    total.arrow_bytes += s.arrow_bytes; total.n_records += s.n_records; total.n_rows += s.n_rows;
+    total.ms_inflate += s.ms_inflate; total.ms_crc += s.ms_crc; total.ms_chain += s.ms_chain; total.ms_extract += s.ms_extract;
+    total.ms_total_gpu += s.ms_total_gpu;
+    total.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  }
+
+  std::shared_ptr<Result> next_chunk() override {
+    if (dead) throw Error("the stream ended with an error");
+    HIP_CHECK(hipSetDevice(img->device));
+    struct Guard { bool* d; bool ok = false; ~Guard() { if (!ok) *d = true; } } guard{&dead};
+    std::shared_ptr<Result> r;
+    while (!done && !(r = run_chunk())) {}
+    guard.ok = true;
+    return (r && r->n_rows) ? r : nullptr;
+  }
+
+  // one chunk; nullptr = it held no complete owned record (the next call takes more members behind the carried bytes)
+  std::shared_ptr<Result> run_chunk() {
+    StageTimer t(st);
+    bioscan_scan_stats s{};
+    uint32_t grow = 1;
+    for (;;) {   // (repeated with more members only while the FIRST chunk cannot be synchronised)
+      const uint32_t m0 = next_member;
+      const uint32_t m1 = (uint32_t)std::min<uint64_t>(p.n_blocks(), (uint64_t)m0 + (uint64_t)chunk_len(chunks_done) * grow);
+      if (m1 > img->m_hi || m0 < img->m_lo) { img = p.device_image(img->device, std::min(m0, img->m_lo), std::max(m1, img->m_hi)); }
+      const uint64_t bytes = p.blk_uoff[m1] - p.blk_uoff[m0];
+      const uint64_t L = carry_len + bytes;                 // decoded bytes in ubuf[cur]
+      const uint64_t origin = p.blk_uoff[m0] - carry_len;   // decoded offset of ubuf[cur][0]
+      if (ubuf[cur].n < L + 64) {
+        DevBuf<uint8_t> g(L + 64);
+        if (carry_len) HIP_CHECK(hipMemcpyAsync(g.p, ubuf[cur].p, carry_len, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        ubuf[cur] = std::move(g);
+      }
+      uint8_t* u = ubuf[cur].p;
+      const bool at_eof = m1 == p.n_blocks();
+      if (m1 > m0) {
+        if (k1.status.n < m1 - m0) p.init_ctx(k1, *img, m1 - m0, false);
+        t.start();
+        p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
+        s.ms_inflate += t.stop();
+        t.start();
+        p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
+        s.ms_crc += t.stop();
+        p.check_inflate_status(k1, m0, m1 - m0);
+      }
+      s.n_blocks = m1 - m0;
+      s.compressed_bytes = p.blk_coff[m1] - p.blk_coff[m0];
+      s.inflated_bytes = bytes;
+      t.start();
+      // ---- first record of the chunk: the carried record's first byte, or (first chunk of a split) the resynchronisation ----
+      uint64_t x0 = 0;
+      bool none = false;
+      DevBuf<unsigned long long> d_res(2);
+      if (first) {
+        x0 = start - origin;
+        if (start > 0) {
+          std::vector<uint64_t> we, wc, wn;
+          for (uint32_t b = m0; b < m1; b++) {
+            we.push_back(p.blk_uoff[b + 1] - origin);
+            wc.push_back(p.blk_coff[b]);
+            wn.push_back(p.blk_coff[b + 1]);
+          }
+          DevBuf<uint64_t> d_we(we.size() + 1), d_wc(wc.size() + 1), d_wn(wn.size() + 1);
+          if (!we.empty()) {
+            HIP_CHECK(hipMemcpyAsync(d_we.p, we.data(), we.size() * 8, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(d_wc.p, wc.data(), wc.size() * 8, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(d_wn.p, wn.data(), wn.size() * 8, hipMemcpyHostToDevice, st));
+          }
+          launch_fastq_sync(u, start - origin, L, d_we.p, d_wc.p, d_wn.p, (uint32_t)we.size(), end, end != ~0ull ? 1 : 0, d_res.p, st);
+          unsigned long long r = 0;
+          HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+          if (r == ~0ull || (r >= L && !at_eof)) {
+            if (!at_eof) { grow *= 4; s.ms_chain += t.stop(); continue; }  // ran out of decoded bytes while resynchronising
+            none = true;
+          } else x0 = r;
+        }
+      }
+      uint64_t n_nl = 0, owned = 0;
+      DevBuf<uint64_t> nl, nl_base, tmp;
+      DevBuf<uint32_t> nl_cnt;
+      if (!none && x0 < L) {
+        const uint64_t nch = nl_chunks(x0, L);
+        nl_cnt.alloc(nch + 1);
+        nl_base.alloc(nch + 2);
+        tmp.alloc(scan_tmp_elems(nch));
+        launch_nl_count(u, x0, L, nl_cnt.p, st);
+        launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
+        HIP_CHECK(hipMemcpyAsync(&n_nl, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        nl.alloc(n_nl + 1);
+        launch_nl_write(u, x0, L, nl_base.p, nl.p, st);
+        const uint64_t T_rel = T > origin ? T - origin : 0;
+        launch_fastq_count_owned(nl.p, n_nl, x0, L, T_rel, d_res.p, st);
+        unsigned long long r = 0;
+        HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        owned = r;
+      }
+      // records whose four lines are all here (the file's last line may lack its newline)
+      const uint64_t complete = (n_nl + (at_eof ? 1 : 0)) / 4;
+      uint64_t n = std::min<uint64_t>(owned, complete);
+      // first byte behind the last complete record = where the next record starts (the carried bytes begin there)
+      uint64_t cs = none ? L : x0;
+      if (complete && 4 * complete - 1 < n_nl) {
+        uint64_t v = 0;
+        HIP_CHECK(hipMemcpyAsync(&v, nl.p + 4 * complete - 1, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        cs = (v & ((1ull << 48) - 1)) + 1;   // (fastq_kernels.hip NL_POS: the low 48 bits are the position)
+      } else if (complete) cs = L;           // (the file's last record, without its final newline)
+      // the partition is over when a record that starts at or behind the threshold has been seen, or the data has
+      if (owned > complete && at_eof) throw Error("FASTQ read error: unexpected end of file inside a record");
+      bool finished = none || owned < complete || origin + cs >= T || (at_eof && cs >= L);
+      if (plan.limit >= 0 && rows_emitted + n >= (uint64_t)plan.limit) { n = (uint64_t)plan.limit - rows_emitted; finished = true; }
+      s.ms_chain += t.stop();
+      s.n_records = n;
+      s.n_rows = n;
+      // ---- the chunk's rows ----
+      std::shared_ptr<Result> res;
+      t.start();
+      if (n) res = extract(u, x0, L, nl.p, n_nl, n, &s);
+      s.ms_extract = t.stop();
+      s.ms_total_gpu = s.ms_inflate + s.ms_crc + s.ms_chain + s.ms_extract;
+      accumulate(s);
+      if (res) {
+        res->stats = s;
+        if (to_host) start_copy_to_host(*res, st, copy_st);
+      }
+      rows_emitted += n;
+      phase = (uint32_t)((phase + n) % batch_size);
+      // ---- carry the cut record ----
+      first = false;
+      next_member = m1;
+      chunks_done++;
+      if (finished) done = true;
+      else {
+        const uint64_t c = L - cs;
+        const int nxt = cur ^ 1;
+        const uint64_t next_bytes = p.blk_uoff[std::min<uint64_t>(p.n_blocks(), (uint64_t)m1 + chunk_len(chunks_done))] - p.blk_uoff[m1];
+        if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
+        if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + cs, c, hipMemcpyDeviceToDevice, st));
+        carry_len = c;
+        cur = nxt;
+      }
+      HIP_CHECK(hipStreamSynchronize(st));   // the chunk's scratch (newline index) goes out of scope
+      return res;
+    }
+  }
+
+  std::shared_ptr<Result> extract(const uint8_t* u, uint64_t x0, uint64_t L, const uint64_t* nl, uint64_t n_nl, uint64_t n, bioscan_scan_stats* s) {
+    auto res = std::make_shared<Result>();
+    res->batch_size = batch_size;
+    res->phase = phase;
+    res->device = img->device;
+    res->n_rows = n;
+    res->cols.resize(plan.out_fields.size());
+    for (size_t c = 0; c < plan.out_fields.size(); c++) res->cols[c].fd = plan.out_fields[c];
+    const uint64_t nwords = (n + 63) / 64, nb = res->n_batches();
+    DevBuf<uint32_t> err(1);
+    HIP_CHECK(hipMemsetAsync(err.p, 0, 4, st));
+    int col_of[4] = {-1, -1, -1, -1};
+    for (size_t c = 0; c < plan.out_fields.size(); c++) {
+      int src = plan.has_projection ? plan.projection[c] : (int)c;
+      if (col_of[src] < 0) col_of[src] = (int)c;
+    }
+    uint64_t arrow_bytes = 0;
+    FqCols fc{};
+    for (int k = 0; k < 4; k++) {
+      if (col_of[k] < 0) continue;
+      Column& col = res->cols[col_of[k]];
+      col.n_rows = n;
+      fc.want |= 1u << k;
+      if (k == 1) { col.d_valid.alloc(nwords); fc.v_desc = col.d_valid.p; arrow_bytes += nwords * 8; }
+    }
+    const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
+    DevBuf<uint64_t> tile_sums(bam_rows_scratch_elems(n));
+    launch_fastq_pass1(u, x0, L, nl, n_nl, n, fc, tile_sums.p, err.p, st);
+    uint64_t totals[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; k++)
+      if ((fc.want >> k) & 1u) HIP_CHECK(hipMemcpyAsync(&totals[k], tile_sums.p + (uint64_t)k * (n_tiles + 1) + n_tiles, 8, hipMemcpyDeviceToHost, st));
+    uint32_t e = read_err(err, st);  // synchronises: the totals are here as well
+    if (e == 1) throw Error("FASTQ read error: invalid name prefix");
+    if (e == 2) throw Error("FASTQ read error: invalid description prefix");
+    for (int k = 0; k < 4; k++) {
+      if (col_of[k] < 0) continue;
+      Column& col = res->cols[col_of[k]];
+      col.total_bytes = totals[k];
+      col.d_values.alloc(std::max<uint64_t>(totals[k], 1));
+      col.d_off32.alloc(nb * ((uint64_t)batch_size + 1));
+      col.d_base.alloc(nb);
+      fc.val[k] = col.d_values.p; fc.off32[k] = col.d_off32.p; fc.base[k] = col.d_base.p;
+      arrow_bytes += totals[k] + nb * ((uint64_t)batch_size + 1) * 4;
+    }
+    launch_fastq_pass2(u, x0, L, nl, n_nl, n, fc, batch_size, phase, tile_sums.p, st);
+    HIP_CHECK(hipStreamSynchronize(st));
+    s->arrow_bytes = arrow_bytes;
+    return res;
+  }
+};
 
 // -------------------------------------------------------------------------------------------------
 // Arrow C Data export
@@ -1765,7 +2040,7 @@ static void export_pieces(const std::vector<Piece>& pieces, ArrowArray* out) {
 // been in flight since before that.
 struct Stream {
   Provider* prov = nullptr;
-  std::unique_ptr<BamExecState> exec;   // BAM: chunk producer; null for a FASTQ stream (one result) or once exhausted
+  std::unique_ptr<ChunkProducer> exec;   // the partition's chunk pipeline (BAM, BGZF FASTQ); null for a plain-text FASTQ stream (one result) or once exhausted
   std::shared_ptr<Result> cur;
   bool on_host = true;
   uint64_t cur_batch = 0;
@@ -2443,12 +2718,14 @@ static int execute_impl(const bioscan_plan* plan, int32_t partition, int32_t bat
   sm.on_host = !device_only;
   if (plan->pl.indexed && !plan->pl.prov->index_error.empty())
     throw Error("Failed to open indexed BAM: " + plan->pl.prov->index_error);
-  if (plan->pl.prov->kind == 1) {
+  if (plan->pl.prov->kind == 1 && (plan->pl.prov->fq_compression != 1 || device_only)) {
+    // plain text (the whole file is the resident image) and device-resident executions: one result
     sm.cur = run_partition_fastq(plan->pl, partition, (uint32_t)batch_size, !device_only);
     sm.stats = sm.cur->stats;
     if (device_only) { sm.device_results.push_back(sm.cur); sm.cur.reset(); }
   } else {
-    sm.exec.reset(new BamExecState(plan->pl, partition, (uint32_t)batch_size, !device_only));
+    if (plan->pl.prov->kind == 1) sm.exec.reset(new FastqExecState(plan->pl, partition, (uint32_t)batch_size, true));
+    else sm.exec.reset(new BamExecState(plan->pl, partition, (uint32_t)batch_size, !device_only));
     if (device_only) {
       // the whole partition now, every chunk's Arrow buffers left in HBM
       while (auto r = sm.exec->next_chunk()) sm.device_results.push_back(std::move(r));
@@ -2491,6 +2768,14 @@ void bioscan_provider_close(bioscan_provider* p) {
     dev_pool_trim();
     host_pool_trim();
   }
+}
+
+int bioscan_provider_set_chunk_members(bioscan_provider* p, int32_t chunk_members) {
+  API_BEGIN
+  if (chunk_members < 0) throw Error("chunk_members must not be negative");
+  if (p->vcf) p->vcf->set_chunk_members((uint32_t)chunk_members);
+  else p->p.chunk_members = (uint32_t)chunk_members;
+  API_END
 }
 
 int bioscan_provider_make_resident(bioscan_provider* p) {

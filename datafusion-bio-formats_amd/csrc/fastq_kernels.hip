@@ -291,11 +291,12 @@ __global__ __launch_bounds__(ROWS_TILE) void k_fastq_pass1(const uint8_t* __rest
 
 // first byte of every batch: base of the tile that holds the batch's first row + the rows of that tile in front of it
 __global__ __launch_bounds__(ROWS_TILE) void k_fastq_batch_bases(const uint8_t* __restrict__ u, uint64_t x0, uint64_t eof, const uint64_t* __restrict__ nl,
-                                                                 uint64_t n_nl, uint64_t n, FqCols c, uint32_t bs, uint64_t n_tiles,
+                                                                 uint64_t n_nl, uint64_t n, FqCols c, uint32_t bs, uint32_t phase, uint64_t n_tiles,
                                                                  const uint64_t* __restrict__ tile_sums) {
   __shared__ uint64_t s_w[4][ROWS_TILE / WAVE];
   const uint64_t b = blockIdx.x;
-  const uint64_t s = b * (uint64_t)bs;
+  // (`phase` rows of the chunk's first batch were delivered by the previous chunk: batch 0 holds bs - phase rows)
+  const uint64_t s = b ? b * (uint64_t)bs - phase : 0;
   const uint64_t tile = s / ROWS_TILE, part = s % ROWS_TILE;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint64_t r = tile * ROWS_TILE + threadIdx.x;
@@ -325,7 +326,7 @@ struct __attribute__((packed, aligned(1))) fq_u16 { uint16_t v; };
 #define FQ_UNROLL 2
 #endif
 __global__ __launch_bounds__(ROWS_TILE) void k_fastq_pass2(const uint8_t* __restrict__ u, uint64_t x0, uint64_t eof, const uint64_t* __restrict__ nl,
-                                                           uint64_t n_nl, uint64_t n, FqCols c, uint32_t bs, uint64_t n_tiles,
+                                                           uint64_t n_nl, uint64_t n, FqCols c, uint32_t bs, uint32_t phase, uint64_t n_tiles,
                                                            const uint64_t* __restrict__ tile_sums) {
   __shared__ uint64_t s_w[4][ROWS_TILE / WAVE];
   __shared__ uint64_t s_src[4][ROWS_TILE], s_dst[4][ROWS_TILE];
@@ -356,8 +357,9 @@ __global__ __launch_bounds__(ROWS_TILE) void k_fastq_pass2(const uint8_t* __rest
   }
   if (act) {
     // per-batch int32 offsets: entry j of batch b, and the closing entry when this is the batch's (or the scan's) last row
-    const uint64_t b = r / bs, j = r - b * (uint64_t)bs;
-    const bool closes = (r + 1) % bs == 0 || r + 1 == n;
+    const uint64_t v = r + phase;
+    const uint64_t b = v / bs, j = b ? v - b * (uint64_t)bs : r;
+    const bool closes = (v + 1) % bs == 0 || r + 1 == n;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (!((c.want >> k) & 1u)) continue;
@@ -465,12 +467,12 @@ void launch_fastq_pass1(const uint8_t* u, uint64_t x0, uint64_t eof, const uint6
   if (c.want) launch_tile_scan(tile_sums, n_tiles, c.want, st);
 }
 void launch_fastq_pass2(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec, FqCols c,
-                        uint32_t batch_size, const uint64_t* tile_sums, hipStream_t st) {
+                        uint32_t batch_size, uint32_t phase, const uint64_t* tile_sums, hipStream_t st) {
   if (!n_rec || !c.want) return;
   const uint64_t n_tiles = (n_rec + ROWS_TILE - 1) / ROWS_TILE;
-  const uint64_t nb = (n_rec + batch_size - 1) / batch_size;
-  hipLaunchKernelGGL(k_fastq_batch_bases, dim3((uint32_t)nb), dim3(ROWS_TILE), 0, st, u, x0, eof, nl, n_nl, n_rec, c, batch_size, n_tiles, tile_sums);
-  hipLaunchKernelGGL(k_fastq_pass2, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, x0, eof, nl, n_nl, n_rec, c, batch_size, n_tiles, tile_sums);
+  const uint64_t nb = (n_rec + phase + batch_size - 1) / batch_size;
+  hipLaunchKernelGGL(k_fastq_batch_bases, dim3((uint32_t)nb), dim3(ROWS_TILE), 0, st, u, x0, eof, nl, n_nl, n_rec, c, batch_size, phase, n_tiles, tile_sums);
+  hipLaunchKernelGGL(k_fastq_pass2, dim3((uint32_t)n_tiles), dim3(ROWS_TILE), 0, st, u, x0, eof, nl, n_nl, n_rec, c, batch_size, phase, n_tiles, tile_sums);
 }
 
 // number of records whose first byte lies before `limit_off` (ownership threshold): record r starts at

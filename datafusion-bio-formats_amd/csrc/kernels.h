@@ -237,7 +237,7 @@ void launch_tile_scan(uint64_t* tile_sums, uint64_t n_tiles, uint32_t want, hipS
 void launch_fastq_pass1(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec, FqCols c,
                         uint64_t* tile_sums, uint32_t* err, hipStream_t st);
 void launch_fastq_pass2(const uint8_t* u, uint64_t x0, uint64_t eof, const uint64_t* nl, uint64_t n_nl, uint64_t n_rec, FqCols c,
-                        uint32_t batch_size, const uint64_t* tile_sums, hipStream_t st);
+                        uint32_t batch_size, uint32_t phase, const uint64_t* tile_sums, hipStream_t st);
 // total_bytes = off64[n] (the caller has just read it): the average row length picks the kernel shape
 void launch_scatter_ranges(const uint8_t* u, const uint64_t* src, uint64_t n, const uint64_t* off64, uint8_t* dst, uint64_t total_bytes,
                            hipStream_t st);

@@ -27,6 +27,7 @@ struct VcfProviderI {
   virtual VcfPlanI* scan(const int32_t* projection, int32_t n_projection, const bioscan_filter* filters, int32_t n_filters,
                          int64_t limit, int32_t target_partitions) = 0;
   virtual void make_resident() = 0;
+  virtual void set_chunk_members(uint32_t n) = 0;  // BGZF members per pipeline chunk of a stream (0 = default)
 };
 VcfProviderI* vcf_open(const char* path, const bioscan_vcf_options* opts);
 

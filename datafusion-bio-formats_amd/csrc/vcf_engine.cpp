@@ -111,6 +111,8 @@ struct VcfProvider : BgzfSource, VcfProviderI {
   VcfPlanI* scan(const int32_t* projection, int32_t n_projection, const bioscan_filter* filters, int32_t n_filters, int64_t limit,
                  int32_t target_partitions) override;
   void make_resident() override { BgzfSource::make_resident(); }
+  uint32_t chunk_members = 0;
+  void set_chunk_members(uint32_t n) override { chunk_members = n; }
   const uint8_t* text_base() const { return bgzf ? d_u.p : d_comp.p; }
   uint64_t text_len() const { return bgzf ? ulen : file_len; }
 };

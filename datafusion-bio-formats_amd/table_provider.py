@@ -76,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "bioscan_bam_options_default", "bioscan_bam_open", "bioscan_schema", "bioscan_supports_filters_pushdown",
     "bioscan_scan", "bioscan_plan_num_partitions", "bioscan_plan_schema", "bioscan_plan_display",
     "bioscan_plan_partition_desc", "bioscan_execute", "bioscan_next", "bioscan_stream_close", "bioscan_plan_close",
-    "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_execute_device",
+    "bioscan_provider_close", "bioscan_last_error", "bioscan_provider_make_resident", "bioscan_provider_set_chunk_members", "bioscan_execute_device",
     "bioscan_bgzf_inflate", "bioscan_free", "bioscan_device_check",
     "bioscan_debug_balance_partitions", "bioscan_debug_plan_full_scan", "bioscan_fastq_open",
     "bioscan_vcf_options_default", "bioscan_vcf_open", "bioscan_udf_list_avg", "bioscan_udf_list_cmp", "bioscan_stream_list_udf", "bioscan_udf_list_and", "bioscan_udf_vcf_set_gts", "bioscan_udf_vcf_allele_stats",
@@ -130,6 +130,7 @@ def load_library():
     lib.bioscan_plan_close.argtypes = [C.c_void_p]
     lib.bioscan_provider_close.argtypes = [C.c_void_p]
     lib.bioscan_provider_make_resident.argtypes = [C.c_void_p]
+    lib.bioscan_provider_set_chunk_members.argtypes = [C.c_void_p, C.c_int32]
     lib.bioscan_bgzf_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_double)]
     lib.bioscan_free.argtypes = [C.c_void_p]
@@ -455,11 +456,17 @@ class FastqTableProvider:
     """Mirror of FastqTableProvider::new(file_path, object_storage_options)
     (bio-format-fastq/src/table_provider.rs:49-66); local files only."""
 
-    def __init__(self, file_path: str, object_storage_options=None, device_id: int = 0):
+    def __init__(self, file_path: str, object_storage_options=None, device_id: int = 0, chunk_members: int = 0):
         lib = load_library()
         self._h = C.c_void_p()
         _check(lib.bioscan_fastq_open(file_path.encode(), device_id, C.byref(self._h)))
         self.file_path = file_path
+        if chunk_members:
+            self.set_chunk_members(chunk_members)
+
+    def set_chunk_members(self, n: int):
+        """BGZF members per pipeline chunk of the streams executed from now on (0 = default)."""
+        _check(load_library().bioscan_provider_set_chunk_members(self._h, n))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -590,6 +597,10 @@ class VcfTableProvider:
 
     def make_resident(self):
         _check(load_library().bioscan_provider_make_resident(self._h))
+
+    def set_chunk_members(self, n: int):
+        """BGZF members per pipeline chunk of the streams executed from now on (0 = default)."""
+        _check(load_library().bioscan_provider_set_chunk_members(self._h, n))
 
     def scan(self, projection: Optional[Sequence[int]] = None, filters=(), limit: Optional[int] = None,
              target_partitions: int = 1) -> VcfExec:

@@ -223,6 +223,13 @@ typedef struct bioscan_scan_stats {
 /* Make the file's compressed bytes resident in HBM (idempotent); later executes reuse them. */
 int bioscan_provider_make_resident(bioscan_provider* p);
 
+/* BGZF members per pipeline chunk of the streams this provider's plans execute from now on (0 = the default: 16 384, or
+ * BIOSCAN_CHUNK_MEMBERS).  A stream inflates, frames and extracts one chunk at a time and carries the record / line cut by a
+ * chunk's end to the next: its HBM and host footprint is O(chunk), as the reference's record-at-a-time readers are O(batch)
+ * (bio-format-fastq/src/physical_exec.rs:393-465, bio-format-vcf/src/physical_exec.rs:912-1198).  bioscan_bam_options has the
+ * same knob at open; this one also reaches FASTQ and VCF providers, whose constructors take no such option. */
+int bioscan_provider_set_chunk_members(bioscan_provider* p, int32_t chunk_members);
+
 /* ---- several GPUs of one node behind ONE plan (DataFusion calls execute(partition) for every partition
  * of one ExecutionPlan object).  Like bioscan_scan, and the plan's partitions are dealt to `device_ids` in contiguous runs
  * in plan order, balanced by PartitionAssignment.total_estimated_bytes -- the rule of partition_byte_ranges_in_order

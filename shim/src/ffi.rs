@@ -159,6 +159,7 @@ unsafe extern "C" {
     pub fn bioscan_last_error() -> *const c_char;
 
     pub fn bioscan_provider_make_resident(p: *mut bioscan_provider) -> c_int;
+    pub fn bioscan_provider_set_chunk_members(p: *mut bioscan_provider, chunk_members: i32) -> c_int;
     pub fn bioscan_scan_devices(p: *const bioscan_provider, projection: *const i32, n_projection: i32,
                                 filters: *const bioscan_filter, n_filters: i32, limit: i64, target_partitions: i32,
                                 device_ids: *const i32, n_devices: i32, out: *mut *mut bioscan_plan) -> c_int;

@@ -259,3 +259,45 @@ def test_large_file_properties(pkg):
                 os.unlink(p)
             except OSError:
                 pass
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3, 7, 64, 1000])
+def test_chunked_stream_any_chunk_size(pkg, fo, tmp_path, chunk):
+    """The chunk pipeline of a BGZF FASTQ stream (csrc/engine.cpp FastqExecState): members are inflated `chunk` at a time,
+    the record cut by a chunk's end is carried to the next chunk and batches continue across chunks -- none of which may
+    change a batch.  GZI partitions of the reference's fixture (1 .. 8) and a file whose records straddle small members,
+    every batch against the oracle (the reference reads record by record in constant memory,
+    bio-format-fastq/src/physical_exec.rs:393-465)."""
+    path = os.path.join(G, "sample.fastq.bgz")
+    orc = fo.FastqOracle(path)
+    for target in (1, 3, 8):
+        strat, parts = orc.scan(target)
+        prov = pkg.FastqTableProvider(path, chunk_members=chunk)
+        plan = prov.scan(target_partitions=target)
+        assert plan.num_partitions() == len(parts)
+        for p, part in enumerate(parts):
+            _, want = orc.execute(strat, part, batch_size=37)
+            _cmp(list(plan.execute(p, 37)), want, (chunk, target, p))
+    # records of random shapes over 700-byte members: a record spans several members, a chunk of one member may hold no
+    # complete record at all
+    import random
+    rng = random.Random(77 + chunk)
+    recs = []
+    for i in range(1500):
+        ln = rng.choice([1, 30, 101, 150, 700, rng.randint(1, 2000)])
+        eol = rng.choice(["\n", "\r\n"])
+        recs.append(f"@r{i} d{i % 7}{eol}{'ACGT' * (ln // 4 + 1)}{eol}+{eol}{'I' * (4 * (ln // 4 + 1))}{eol}")
+    text = "".join(recs).encode()
+    small = str(tmp_path / "small.fastq.bgz")
+    open(small, "wb").write(_bgzf([text[o:o + 700] for o in range(0, len(text), 700)]))
+    orc = fo.FastqOracle(small)
+    strat, parts = orc.scan(1)
+    _, want = orc.execute(strat, parts[0], batch_size=64)
+    prov = pkg.FastqTableProvider(small, chunk_members=chunk)
+    for limit in (None, 100):
+        got = list(prov.scan(limit=limit).execute(0, 64))
+        if limit is None:
+            _cmp(got, want, (chunk, "small members"))
+        else:
+            assert sum(b.num_rows for b in got) == 100
+            assert pa.Table.from_batches(got).equals(pa.Table.from_batches(want).slice(0, 100))
