@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <fstream>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
@@ -534,60 +535,89 @@ bool VcfStream::next(ArrowArray* out) {
 // ---- partition execution -------------------------------------------------------------------------------------
 struct RegionQuery {
   GenomicRegion region;
-  std::vector<std::pair<uint64_t, uint64_t>> chunks_abs;  // absolute inflated offsets
+  std::vector<std::pair<uint64_t, uint64_t>> chunks_abs;  // merged tabix chunks as absolute inflated offsets
 };
-
 static uint64_t voff_to_abs(const VcfProvider& p, uint64_t voff) {
-  const uint64_t c = voff >> 16, w = voff & 0xFFFF;
-  auto it = std::lower_bound(p.blk_coff.begin(), p.blk_coff.end(), c);
-  if (it == p.blk_coff.end() || *it != c) throw Error("tabix index does not match the file: virtual offset does not address a block start");
-  const size_t b = (size_t)(it - p.blk_coff.begin());
-  return p.blk_uoff[std::min(b, p.blk_uoff.size() - 1)] + w;
+  const uint64_t coff = voff >> 16, uo = voff & 0xFFFF;
+  if (!p.bgzf) return coff + uo;
+  auto it = std::lower_bound(p.blk_coff.begin(), p.blk_coff.end(), coff);
+  if (it == p.blk_coff.end() || *it != coff) throw Error("tabix virtual offset does not address a BGZF member");
+  return p.blk_uoff[(size_t)(it - p.blk_coff.begin())] + uo;
 }
 static uint32_t block_of_abs(const VcfProvider& p, uint64_t a) {  // block holding inflated byte a
   auto it = std::upper_bound(p.blk_uoff.begin(), p.blk_uoff.end(), a);
-  size_t b = (size_t)(it - p.blk_uoff.begin());
-  return (uint32_t)(b ? b - 1 : 0);
+  size_t i = (size_t)(it - p.blk_uoff.begin());
+  return (uint32_t)(i ? i - 1 : 0);
 }
 
-VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool device_only, bioscan_scan_stats* stats_out) const {
-  VcfProvider& p = *prov;
-  if (partition < 0 || partition >= n_partitions()) throw Error("partition index out of range");
-  if (batch_size_in <= 0) throw Error("batch_size must be positive");
-  std::lock_guard<std::mutex> lk(p.mu);
-  const auto wall0 = std::chrono::steady_clock::now();
-  const bool dbg_wall = env_knobs().laps;
-  auto lap = [&](const char* what) {
-    if (dbg_wall) fprintf(stderr, "[bioscan] vcf execute: %-22s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
-  };
-  p.make_resident();
-  p.set_device();
-  hipStream_t st = p.stream;
-  auto res = std::make_shared<VResult>();
-  res->device = p.device;
-  res->stream = st;
-  const VcfSchema& sch = p.sch;
-  const int n_info = (int)sch.info_fields.size();
+// A stretch of decoded text on the device: u[0] is the byte at absolute decoded offset `base`, the lines of interest start at
+// u[x0] and the decoded bytes end at u[hi]; at_eof: they end with the file.
+struct TextSpan {
+  const uint8_t* u = nullptr;
+  uint64_t base = 0, x0 = 0, hi = 0;
+  bool at_eof = false;
+};
+// delimiter index + per-line keys of a span
+struct LineIndex {
+  DevBuf<uint64_t> nl, nl_tabs, tab, base_nl, base_tab, scan_tmp;
+  DevBuf<uint32_t> cnt_nl, cnt_tab;
+  DevBuf<uint32_t> k_pos, k_vend;
+  DevBuf<uint8_t> k_flags;
+  VcfLines L{};
+  uint64_t first_open = 0;   // span offset of the first byte behind the last newline (= x0 when the span holds none)
+  bool open_tail = false;    // the span does not end with a newline
+};
 
-  // projection flags (physical_exec.rs:257-281)
-  std::vector<int> col_src(out_fields.size());
-  for (size_t c = 0; c < out_fields.size(); c++) col_src[c] = has_projection ? projection[c] : (int)c;
-  bool any_format = false;
-  for (int s : col_src) if (s >= 8 + n_info) any_format = true;
-  const bool multi = sch.multi;
-  const uint64_t NS = sch.samples.size();
-  // effective batch size (choose_effective_batch_size; the adaptive re-tune is not restated)
-  res->batch_size = choose_effective_batch_size((uint64_t)batch_size_in, any_format && sch.has_format, sch.format_fields.size(), NS,
-                                                p.hdr.samples.size());
-
-  // ---- byte range ----
+// What one execute() works with, whatever the size of the pieces it works in: the projection, the residual filter program, the
+// regions of the partition, the limit.  run_rows() turns a stretch of decoded text into the Arrow nodes of its rows; the
+// one-shot form (device-resident executions, plain-text files) calls it once for the partition's whole span, a host stream
+// calls it once per chunk of BGZF members (VcfChunkStream below).
+struct VcfRun {
+  const VcfPlan& plan;
+  VcfProvider& p;
+  hipStream_t st = nullptr;
+  const VcfSchema& sch;
+  int n_info = 0;
+  std::vector<int> col_src;
+  bool any_format = false, multi = false, want_end = false;
+  uint64_t NS = 0, batch_size = 8192;
   std::vector<RegionQuery> queries;
-  uint64_t lo_abs = p.hdr.header_bytes, E_abs = p.text_len();
-  bool nothing = false;
-  if (indexed && !p.index_readable) throw Error("Failed to open indexed VCF: " + p.index_error);  // physical_exec.rs:2766-2768
-  if (indexed) {
+  bool nothing = false, never = false;
+  uint64_t lo_abs = 0, E_abs = 0;     // span of the partition (all its regions)
+  // residual filter program + the region names, on the device (indexed plans)
+  std::vector<VcfFilterTerm> terms;
+  std::vector<uint32_t> chrom_off;
+  DevBuf<uint8_t> d_blob;
+  DevBuf<VcfFilterTerm> d_terms;
+  DevBuf<uint32_t> err;               // error word + the queue of float cells to be rounded exactly (vcf_kernels.h)
+  uint64_t rows_left = ~0ull;         // what the plan's limit still allows
+
+  VcfRun(const VcfPlan& pl, int32_t partition, int32_t batch_size_in) : plan(pl), p(*pl.prov), sch(pl.prov->sch) {
+    n_info = (int)sch.info_fields.size();
+    // projection flags (physical_exec.rs:257-281)
+    col_src.resize(plan.out_fields.size());
+    for (size_t c = 0; c < plan.out_fields.size(); c++) col_src[c] = plan.has_projection ? plan.projection[c] : (int)c;
+    for (int s : col_src) if (s >= 8 + n_info) any_format = true;
+    multi = sch.multi;
+    NS = sch.samples.size();
+    // effective batch size (choose_effective_batch_size; the adaptive re-tune is not restated)
+    batch_size = choose_effective_batch_size((uint64_t)batch_size_in, any_format && sch.has_format, sch.format_fields.size(), NS,
+                                             p.hdr.samples.size());
+    want_end = plan.indexed;
+    for (int s : col_src) if (s == 2) want_end = true;
+    if (plan.limit >= 0) rows_left = (uint64_t)plan.limit;
+    lo_abs = p.hdr.header_bytes;
+    E_abs = p.text_len();
+    if (plan.indexed && !p.index_readable) throw Error("Failed to open indexed VCF: " + p.index_error);  // physical_exec.rs:2766-2768
+    if (plan.indexed) plan_regions(partition);
+    if (lo_abs >= p.text_len()) nothing = true;
+  }
+
+  // ---- byte range of every region of the partition (tabix query, storage.rs / noodles `Query`) ----
+  void plan_regions(int32_t partition) {
+    std::lock_guard<std::mutex> lk(p.mu);   // (the per-contig chunk cache)
     uint64_t mn = ~0ull, mx = 0;
-    for (auto& r : assignments[(size_t)partition].regions) {
+    for (auto& r : plan.assignments[(size_t)partition].regions) {
       if (r.unmapped_tail) continue;
       if (r.has_start && r.has_end && r.end < r.start)
         throw Error("Invalid region '" + r.chrom + "': end (" + std::to_string(r.end) + ") is less than start (" + std::to_string(r.start) + ")");
@@ -634,38 +664,439 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
           if (b > a) { q.chunks_abs.emplace_back(a, b); mn = std::min(mn, a); mx = std::max(mx, b); }
         }
       }
+      if (q.chunks_abs.size() > 4096) throw Error("region query expands to more than 4096 index chunks");
       queries.push_back(std::move(q));
     }
     if (mn == ~0ull) nothing = true;
     else { lo_abs = mn; E_abs = mx; }
   }
-  if (lo_abs >= p.text_len()) nothing = true;
 
+  // ---- the residual filter program (record_filter.rs over VcfRecordFields) and the region names, uploaded once ----
+  void upload_filters(hipStream_t stream) {
+    st = stream;
+    err.alloc(VCF_ERR_DWORDS);
+    HIP_CHECK(hipMemsetAsync(err.p, 0, 16, st));
+    if (!plan.indexed) return;
+    std::string blob;
+    for (auto& f : plan.residual) {
+      int field;
+      if (f.column == "chrom") field = 0;
+      else if (f.column == "start") field = 1;
+      else if (f.column == "end") field = 2;
+      else if (f.column == "id") field = 3;
+      else continue;  // VcfRecordFields knows no other field: the term passes (storage.rs:1000-1024)
+      const bool is_str = field == 0 || field == 3;
+      VcfFilterTerm tm{};
+      tm.field = field;
+      tm.op = f.op;
+      auto num = [&](const Literal& l, double* v) {
+        if (l.kind == BIOSCAN_LIT_INT) { *v = (double)l.i; return true; }
+        if (l.kind == BIOSCAN_LIT_FLOAT) { *v = l.f; return true; }
+        return false;
+      };
+      auto put_str = [&](int k, const std::string& s) {
+        tm.str_off[k] = (uint32_t)blob.size();
+        tm.str_len[k] = (uint32_t)s.size();
+        blob += s;
+      };
+      if (f.op <= BIOSCAN_OP_GE) {
+        if (f.values.size() != 1) continue;
+        const Literal& l = f.values[0];
+        if (l.kind == BIOSCAN_LIT_NULL) { never = true; break; }
+        if (is_str) {
+          if (l.kind != BIOSCAN_LIT_STR) continue;
+          if (f.op != BIOSCAN_OP_EQ && f.op != BIOSCAN_OP_NE) continue;
+          put_str(0, l.s);
+        } else if (!num(l, &tm.vals[0])) continue;
+        tm.n_vals = 1;
+      } else if (f.op == BIOSCAN_OP_BETWEEN || f.op == BIOSCAN_OP_NOT_BETWEEN) {
+        if (f.values.size() != 2) continue;
+        if (f.values[0].kind == BIOSCAN_LIT_NULL || f.values[1].kind == BIOSCAN_LIT_NULL) { never = true; break; }
+        if (is_str) continue;
+        if (!num(f.values[0], &tm.vals[0]) || !num(f.values[1], &tm.vals[1])) continue;
+        tm.n_vals = 2;
+      } else {
+        // eight literals per term; a longer list continues in the following terms (`more`)
+        int k = 0;
+        for (auto& l : f.values) {
+          if (k == 8) { tm.n_vals = 8; tm.more = 1; terms.push_back(tm); tm.has_null = 0; tm.more = 0; k = 0; }
+          if (is_str) {
+            if (l.kind == BIOSCAN_LIT_NULL) tm.has_null = 1;
+            else if (l.kind == BIOSCAN_LIT_STR) put_str(k++, l.s);
+          } else {
+            double v;
+            if (num(l, &v)) tm.vals[k++] = v; else tm.has_null = 1;
+          }
+        }
+        tm.n_vals = k;
+      }
+      terms.push_back(tm);
+    }
+    for (auto& q : queries) { chrom_off.push_back((uint32_t)blob.size()); blob += q.region.chrom; }
+    d_blob.alloc(blob.size() + 1);
+    if (!blob.empty()) HIP_CHECK(hipMemcpyAsync(d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    d_terms.alloc(terms.size() + 1);
+    if (!terms.empty()) HIP_CHECK(hipMemcpyAsync(d_terms.p, terms.data(), terms.size() * sizeof(VcfFilterTerm), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // (pageable sources)
+  }
+
+  // ---- delimiter index and keys of a span; a last line without its newline is a line only at the end of the file ----
+  void index_lines(const TextSpan& t, LineIndex& li) {
+    const uint64_t x0 = t.x0, hi = t.hi;
+    const uint64_t nch = vcf_delim_chunks(x0, hi);
+    li.cnt_nl.alloc(nch + 1); li.cnt_tab.alloc(nch + 1);
+    li.base_nl.alloc(nch + 2); li.base_tab.alloc(nch + 2);
+    li.scan_tmp.alloc(scan_tmp_elems(nch));
+    launch_vcf_delim_count(t.u, x0, hi, li.cnt_nl.p, li.cnt_tab.p, st);
+    launch_exclusive_scan_u32_to_u64(li.cnt_nl.p, li.base_nl.p, nch, li.scan_tmp.p, st);
+    launch_exclusive_scan_u32_to_u64(li.cnt_tab.p, li.base_tab.p, nch, li.scan_tmp.p, st);
+    uint64_t n_nl = 0, n_tab = 0;
+    uint8_t last = '\n';
+    HIP_CHECK(hipMemcpyAsync(&n_nl, li.base_nl.p + nch, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(&n_tab, li.base_tab.p + nch, 8, hipMemcpyDeviceToHost, st));
+    if (hi > x0) HIP_CHECK(hipMemcpyAsync(&last, t.u + hi - 1, 1, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    li.nl.alloc(n_nl + 1); li.nl_tabs.alloc(n_nl + 1); li.tab.alloc(n_tab + 1);
+    launch_vcf_delim_write(t.u, x0, hi, li.base_nl.p, li.base_tab.p, li.nl.p, li.nl_tabs.p, li.tab.p, st);
+    VcfLines& L = li.L;
+    L.nl = li.nl.p; L.nl_tabs = li.nl_tabs.p; L.tab = li.tab.p;
+    L.n_nl = n_nl; L.n_tab = n_tab; L.x0 = x0; L.hi = hi;
+    li.open_tail = hi > x0 && last != '\n';
+    L.n_lines = n_nl + (li.open_tail && t.at_eof ? 1 : 0);
+    li.first_open = x0;
+    if (n_nl) {
+      uint64_t lastnl = 0;
+      HIP_CHECK(hipMemcpyAsync(&lastnl, li.nl.p + n_nl - 1, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      li.first_open = lastnl + 1;
+    }
+  }
+  void line_keys(const TextSpan& t, LineIndex& li) {
+    const VcfLines& L = li.L;
+    li.k_pos.alloc(L.n_lines + 1); li.k_vend.alloc(L.n_lines + 1); li.k_flags.alloc(L.n_lines + 1);
+    launch_vcf_keys(t.u, L, li.k_pos.p, li.k_vend.p, li.k_flags.p, want_end ? 1 : 0, err.p, st);
+  }
+  void check_err() {
+    uint32_t e = 0;
+    HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    // sequential scan: an error in a line beyond `limit` is never reached by the reference; lines are
+    // validated as a whole here, which only matters for malformed files
+    throw_vcf_err(e);
+  }
+
+  // ---- row selection: the lines of the span that queries [q0, q1) return, region after region, at most `cap` ----
+  uint64_t select_rows(const TextSpan& t, LineIndex& li, size_t q0, size_t q1, uint64_t cap, DevBuf<uint64_t>& rows) {
+    const VcfLines& L = li.L;
+    uint64_t n = 0;
+    if (!plan.indexed) {
+      n = std::min<uint64_t>(L.n_lines, cap);
+      rows.alloc(std::max<uint64_t>(n, 1));
+      launch_vcf_iota_rows(rows.p, n, st);
+      check_err();
+      return n;
+    }
+    check_err();
+    const uint64_t base = t.base;
+    // per region: keep flags over the lines its chunks span, scan, compact
+    const size_t nq = q1 - q0;
+    std::vector<DevBuf<uint32_t>> keeps(nq);
+    std::vector<DevBuf<uint64_t>> scans(nq);
+    std::vector<uint64_t> totals(nq, 0), i_los(nq, 0), i_ns(nq, 0);
+    // two host round trips for all regions together: the line ranges of the regions' chunk spans first, then -- after every
+    // region's flags and scan have been queued -- the totals.  A region's chunks are clipped to the span (a stream's chunk
+    // holds a part of them): positions relative to the span's first byte.
+    auto rel = [&](uint64_t a) { return a <= base ? 0ull : std::min<uint64_t>(a - base, t.hi); };
+    DevBuf<unsigned long long> lb(2 * nq + 2);
+    std::vector<unsigned long long> h_lb(2 * nq + 2, 0);
+    for (size_t k = 0; k < nq && !never; k++) {
+      auto& q = queries[q0 + k];
+      if (q.chunks_abs.empty()) continue;
+      launch_vcf_line_lower_bound(L, rel(q.chunks_abs.front().first), lb.p + 2 * k, st);
+      launch_vcf_line_lower_bound(L, rel(q.chunks_abs.back().second), lb.p + 2 * k + 1, st);
+    }
+    if (nq && !never) {
+      HIP_CHECK(hipMemcpyAsync(h_lb.data(), lb.p, (2 * nq) * 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::vector<DevBuf<uint64_t>> d_chs(nq);
+    uint64_t max_cnt = 0;
+    for (size_t k = 0; k < nq && !never; k++)
+      if (!queries[q0 + k].chunks_abs.empty() && h_lb[2 * k + 1] > h_lb[2 * k]) max_cnt = std::max<uint64_t>(max_cnt, h_lb[2 * k + 1] - h_lb[2 * k]);
+    DevBuf<uint64_t> tmp2(scan_tmp_elems(std::max<uint64_t>(max_cnt, 1)));  // the scans run one after the other on the stream
+    bool queued = false;
+    for (size_t k = 0; k < nq && !never; k++) {
+      auto& q = queries[q0 + k];
+      if (q.chunks_abs.empty()) continue;
+      const unsigned long long i_lo = h_lb[2 * k], i_hi = std::min<unsigned long long>(h_lb[2 * k + 1], L.n_lines);
+      if (i_hi <= i_lo) continue;
+      std::vector<uint64_t> ch;
+      for (auto& c : q.chunks_abs) {
+        if (c.second <= base || c.first >= base + t.hi) continue;   // (not in this span)
+        ch.push_back(rel(c.first)); ch.push_back(rel(c.second));
+      }
+      if (ch.empty()) continue;
+      d_chs[k].alloc(ch.size());
+      HIP_CHECK(hipMemcpyAsync(d_chs[k].p, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, st));  // pageable source: copied before the call returns
+      VcfRowSelect S{};
+      S.mode = 1;
+      S.n_chunks = (int32_t)(ch.size() / 2);
+      S.i_lo = i_lo; S.i_hi = i_hi;
+      S.chrom_off = chrom_off[q0 + k];
+      S.chrom_len = (uint32_t)q.region.chrom.size();
+      S.q_start1 = q.region.has_start ? (int64_t)q.region.start : 1;
+      S.q_end1 = q.region.has_end ? (int64_t)std::min<uint64_t>(q.region.end, 1ull << 29) : (int64_t)(1ull << 29);
+      S.start1 = q.region.has_start ? (int64_t)q.region.start : 0;
+      S.end1 = q.region.has_end ? (int64_t)q.region.end : 0;
+      S.zero_based = p.zero_based ? 1 : 0;
+      S.n_terms = (int32_t)terms.size();
+      const uint64_t cntl = i_hi - i_lo;
+      keeps[k].alloc(cntl + 1);
+      scans[k].alloc(cntl + 2);
+      launch_vcf_row_flags(t.u, L, li.k_pos.p, li.k_vend.p, li.k_flags.p, S, d_chs[k].p, d_terms.p, d_blob.p, keeps[k].p, st);
+      launch_exclusive_scan_u32_to_u64(keeps[k].p, scans[k].p, cntl, tmp2.p, st);
+      HIP_CHECK(hipMemcpyAsync(&totals[k], scans[k].p + cntl, 8, hipMemcpyDeviceToHost, st));
+      queued = true;
+      i_los[k] = i_lo;
+      i_ns[k] = cntl;
+    }
+    if (queued) HIP_CHECK(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    for (auto v : totals) total += v;
+    n = std::min<uint64_t>(total, cap);
+    rows.alloc(std::max<uint64_t>(n, 1));
+    uint64_t rb = 0;
+    for (size_t k = 0; k < nq && rb < n; k++) {
+      if (!totals[k]) continue;
+      launch_vcf_compact(keeps[k].p, scans[k].p, i_ns[k], i_los[k], rows.p, rb, n - rb, st);
+      rb += std::min<uint64_t>(totals[k], n - rb);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    return n;
+  }
+
+  // ---- the Arrow nodes of `n` selected lines ----
+  void build_columns(const TextSpan& t, LineIndex& li, const DevBuf<uint64_t>& rows, uint64_t n, VResult& R) {
+    VResult* res = &R;
+    const uint8_t* u = t.u;
+    const VcfLines& L = li.L;
+    DevBuf<uint32_t>& k_pos = li.k_pos; DevBuf<uint32_t>& k_vend = li.k_vend; DevBuf<uint8_t>& k_flags = li.k_flags;
+    const std::vector<VField>& out_fields = plan.out_fields;
+    res->n_rows = n;
+    res->cols.resize(out_fields.size());
+    for (size_t c = 0; c < out_fields.size(); c++) { res->cols[c].fd = out_fields[c]; res->cols[c].n = n; }
+    Ctx cx{p, st, u, {}, 0, err.p, 0, {}};
+    if (n) {
+      int core_col[8];
+      for (int k = 0; k < 8; k++) core_col[k] = -1;
+      std::vector<std::pair<int, int>> info_cols, fmt_cols;  // (output column, field index)
+      int geno_col = -1;
+      for (size_t c = 0; c < out_fields.size(); c++) {
+        const int s = col_src[c];
+        if (s < 8) core_col[s] = (int)c;
+        else if (s < 8 + n_info) info_cols.emplace_back((int)c, s - 8);
+        else if (multi) geno_col = (int)c;
+        else fmt_cols.emplace_back((int)c, s - 8 - n_info);
+      }
+      // core
+      {
+        VcfCoreCols C{};
+        DevBuf<uint64_t> src[5];
+        DevBuf<uint32_t> len[5];
+        const int sidx[5] = {0, 3, 4, 5, 7};
+        uint64_t** sp[5] = {&C.src_chrom, &C.src_id, &C.src_ref, &C.src_alt, &C.src_filter};
+        uint32_t** lp[5] = {&C.len_chrom, &C.len_id, &C.len_ref, &C.len_alt, &C.len_filter};
+        for (int k = 0; k < 5; k++)
+          if (core_col[sidx[k]] >= 0) { src[k].alloc(n); len[k].alloc(n); *sp[k] = src[k].p; *lp[k] = len[k].p; }
+        if (core_col[1] >= 0) { auto& nd = res->cols[core_col[1]]; nd.d_values.alloc(n * 4); C.start = (uint32_t*)nd.d_values.p; cx.arrow_bytes += n * 4; }
+        if (core_col[2] >= 0) { auto& nd = res->cols[core_col[2]]; nd.d_values.alloc(n * 4); C.end = (uint32_t*)nd.d_values.p; cx.arrow_bytes += n * 4; }
+        if (core_col[6] >= 0) {
+          auto& nd = res->cols[core_col[6]];
+          nd.d_values.alloc(n * 8);
+          nd.d_valid.alloc((n + 63) / 64);
+          nd.all_valid = false;
+          C.qual = (double*)nd.d_values.p;
+          C.v_qual = nd.d_valid.p;
+          cx.arrow_bytes += n * 8 + (n + 63) / 64 * 8;
+        }
+        launch_vcf_core(u, L, rows.p, n, k_pos.p, k_vend.p, k_flags.p, C, p.zero_based ? 1 : 0, err.p, st);
+        for (int k = 0; k < 5; k++)
+          if (core_col[sidx[k]] >= 0) {
+            VNode& nd = res->cols[core_col[sidx[k]]];
+            finish_utf8(cx, nd, src[k].p, len[k].p, n);
+            if (sidx[k] == 5) launch_replace_byte(nd.d_values.p, nd.total, ',', '|', st);  // alleles re-joined with '|'
+          }
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+      // INFO
+      if (!info_cols.empty()) {
+        std::string blob;
+        std::vector<uint32_t> koff{0};
+        for (auto& ic : info_cols) { blob += sch.info_fields[ic.second]; koff.push_back((uint32_t)blob.size()); }
+        const int K = (int)info_cols.size();
+        DevBuf<uint8_t> d_keys(blob.size() + 1);
+        DevBuf<uint32_t> d_koff(koff.size());
+        HIP_CHECK(hipMemcpyAsync(d_keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_koff.p, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, st));
+        DevBuf<uint64_t> sp_off((uint64_t)K * n);
+        DevBuf<uint32_t> sp_len((uint64_t)K * n);
+        DevBuf<uint8_t> sp_state((uint64_t)K * n);
+        launch_vcf_info_locate(u, L, rows.p, n, d_keys.p, d_koff.p, K, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+        for (int k = 0; k < K; k++) {
+          VNode& nd = res->cols[info_cols[k].first];
+          build_from_spans(cx, nd, sp_off.p + (uint64_t)k * n, sp_len.p + (uint64_t)k * n, sp_state.p + (uint64_t)k * n, n);
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+      // FORMAT
+      if (sch.has_format && (geno_col >= 0 || !fmt_cols.empty())) {
+        std::vector<int> sel;  // FORMAT field indices to extract
+        if (geno_col >= 0) for (size_t k = 0; k < sch.format_fields.size(); k++) sel.push_back((int)k);
+        else for (auto& fc : fmt_cols) sel.push_back(fc.second);
+        const int S = (int)sel.size();
+        std::string blob;
+        std::vector<uint32_t> koff{0};
+        int gt_field = -1;
+        for (int s = 0; s < S; s++) {
+          const std::string& tag = sch.format_fields[sel[s]];
+          if (tag == "GT") gt_field = s;
+          blob += tag;
+          koff.push_back((uint32_t)blob.size());
+        }
+        DevBuf<uint8_t> d_keys(blob.size() + 1);
+        DevBuf<uint32_t> d_koff(koff.size());
+        HIP_CHECK(hipMemcpyAsync(d_keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_koff.p, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, st));
+        // single-sample source: the one sample (load_formats_single_pass takes `sample_count` leading samples)
+        std::vector<int32_t> scol = multi ? sch.sample_header_index : std::vector<int32_t>{0};
+        const uint64_t ns = scol.size();
+        DevBuf<int32_t> d_scol(ns);
+        HIP_CHECK(hipMemcpyAsync(d_scol.p, scol.data(), ns * 4, hipMemcpyHostToDevice, st));
+        DevBuf<int16_t> fpos(n * (uint64_t)S);
+        launch_vcf_format_keys(u, L, rows.p, n, d_keys.p, d_koff.p, S, fpos.p, st);
+        const uint64_t N = n * ns;
+        DevBuf<uint64_t> sp_off((uint64_t)S * N);
+        DevBuf<uint32_t> sp_len((uint64_t)S * N);
+        DevBuf<uint8_t> sp_state((uint64_t)S * N);
+        // shape of the output nodes first: scalar Int32 / Float32 keys are parsed inside the cell kernel straight into
+        // their value buffers; strings and lists go through spans
+        std::vector<VNode*> leaf((size_t)S);
+        if (geno_col >= 0) {
+          VNode& g = res->cols[geno_col];
+          g.kids.resize((size_t)S);
+          for (int s = 0; s < S; s++) {
+            VNode& lst = g.kids[s];
+            lst.fd = g.fd.children.at((size_t)s);
+            lst.n = n;
+            lst.total = N;
+            lst.d_off.alloc(n + 1);
+            launch_stride_offsets(lst.d_off.p, n, ns, st);
+            lst.kids.resize(1);
+            lst.kids[0].fd = lst.fd.children.at(0);
+            leaf[s] = &lst.kids[0];
+            cx.arrow_bytes += (n + 1) * 4;
+          }
+        } else {
+          for (int s = 0; s < S; s++) leaf[s] = &res->cols[fmt_cols[s].first];
+        }
+        VcfCellDirect D{};
+        const uint64_t nwN = (N + 63) / 64;
+        DevBuf<uint64_t> gt_src;
+        DevBuf<uint32_t> gt_len;
+        for (int s = 0; s < S && s < VCF_MAX_DIRECT; s++) {
+          VNode& nd = *leaf[s];
+          if (s == gt_field && nd.fd.kind == VK_UTF8) {   // GT: length + source + validity straight from the cell kernel
+            nd.n = N;
+            nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
+            nd.all_valid = false;
+            gt_src.alloc(std::max<uint64_t>(N, 1));
+            gt_len.alloc(std::max<uint64_t>(N, 1));
+            D.kind[s] = 3;
+            D.values[s] = gt_len.p;
+            D.src[s] = gt_src.p;
+            D.valid[s] = nd.d_valid.p;
+            cx.arrow_bytes += nwN * 8;
+            continue;
+          }
+          if (nd.fd.kind != VK_INT32 && nd.fd.kind != VK_FLOAT32) continue;
+          nd.n = N;
+          nd.d_values.alloc(std::max<uint64_t>(N, 1) * 4);
+          nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
+          nd.all_valid = false;
+          D.kind[s] = nd.fd.kind == VK_INT32 ? 1 : 2;
+          D.values[s] = (uint32_t*)nd.d_values.p;
+          D.valid[s] = nd.d_valid.p;
+          cx.arrow_bytes += N * 4 + nwN * 8;
+        }
+        launch_vcf_format_cells(u, L, rows.p, n, d_scol.p, (int)ns, fpos.p, S, gt_field, D, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+        for (int s = 0; s < S; s++) {
+          if (s < VCF_MAX_DIRECT && D.kind[s] == 3) { finish_utf8(cx, *leaf[s], gt_src.p, gt_len.p, N); continue; }
+          if (s < VCF_MAX_DIRECT && D.kind[s] != 0) continue;
+          build_from_spans(cx, *leaf[s], sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
+        }
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+      uint32_t e2[2] = {0, 0};
+      HIP_CHECK(hipMemcpyAsync(e2, err.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      throw_vcf_err(e2[0]);
+      if (e2[1]) {  // float literals within 2^-52 of a rounding boundary: decided by exact integer comparison
+        launch_f32_fix(err.p, e2[1], st);
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
+    } else {
+      // zero rows: struct / list kids still need their (empty) shape for export
+      std::function<void(VNode&)> shape = [&](VNode& nd) {
+        nd.n = 0;
+        for (auto& cf : nd.fd.children) {
+          nd.kids.emplace_back();
+          nd.kids.back().fd = cf;
+          shape(nd.kids.back());
+        }
+      };
+      for (auto& col : res->cols) shape(col);
+    }
+    res->stats.arrow_bytes = cx.arrow_bytes;
+  }
+};
+
+// ---- one-shot execution: the partition's whole span at once, the result left in HBM or copied to the host in one piece
+//      (device-resident executions and their list UDFs; plain-text files, whose text is the resident image) ----
+static std::shared_ptr<VResult> execute_oneshot(const VcfPlan& plan, int32_t partition, int32_t batch_size_in, bool device_only) {
+  VcfProvider& p = *plan.prov;
+  VcfRun run(plan, partition, batch_size_in);
+  std::lock_guard<std::mutex> lk(p.mu);
+  const auto wall0 = std::chrono::steady_clock::now();
+  const bool dbg_wall = env_knobs().laps;
+  auto lap = [&](const char* what) {
+    if (dbg_wall) fprintf(stderr, "[bioscan] vcf execute: %-22s at %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+  };
+  p.make_resident();
+  p.set_device();
+  hipStream_t st = p.stream;
+  auto res = std::make_shared<VResult>();
+  res->device = p.device;
+  res->stream = st;
+  res->batch_size = run.batch_size;
   lap("planning done");
   Timer t(st);
-  DevBuf<uint32_t> err(VCF_ERR_DWORDS);  // error word + the queue of float cells to be rounded exactly (vcf_kernels.h)
-  HIP_CHECK(hipMemsetAsync(err.p, 0, 16, st));
+  run.upload_filters(st);
   lap("timer+err ready");
-  DevBuf<uint64_t> nl, nl_tabs, tab, base_nl, base_tab, scan_tmp;
-  DevBuf<uint32_t> cnt_nl, cnt_tab;
-  DevBuf<uint32_t> k_pos, k_vend;
-  DevBuf<uint8_t> k_flags;
+  LineIndex li;
   DevBuf<uint64_t> rows;
-  VcfLines L{};
-  uint64_t base = 0, n = 0;
-  const uint8_t* u = nullptr;
-
-  if (!nothing) {
+  TextSpan ts;
+  uint64_t n = 0;
+  if (!run.nothing) {
     uint32_t extra = 1;
     for (;;) {
       uint64_t hi_abs;
       if (p.bgzf) {
-        const uint32_t b_lo = block_of_abs(p, lo_abs);
-        uint32_t b_hi = std::min<uint32_t>(p.n_blocks(), block_of_abs(p, E_abs ? E_abs - 1 : 0) + 1 + (indexed ? extra : 0));
-        if (!indexed) b_hi = p.n_blocks();
-        base = p.blk_uoff[b_lo];
+        const uint32_t b_lo = block_of_abs(p, run.lo_abs);
+        uint32_t b_hi = std::min<uint32_t>(p.n_blocks(), block_of_abs(p, run.E_abs ? run.E_abs - 1 : 0) + 1 + (plan.indexed ? extra : 0));
+        if (!plan.indexed) b_hi = p.n_blocks();
+        ts.base = p.blk_uoff[b_lo];
         hi_abs = p.blk_uoff[b_hi];
-        const uint64_t bytes = hi_abs - base;
+        const uint64_t bytes = hi_abs - ts.base;
         if (p.d_u.n < bytes + 64) p.d_u.alloc(bytes + 64);
         t.start();
         p.launch_inflate(p.d_u.p, b_hi - b_lo, b_lo);
@@ -678,399 +1109,43 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
         lap("inflate+crc done");
         p.check_inflate_status(b_lo, b_hi - b_lo);
         lap("status checked");
-        u = p.d_u.p;
+        ts.u = p.d_u.p;
         res->stats.n_blocks = b_hi - b_lo;
         res->stats.compressed_bytes = p.blk_coff[b_hi] - p.blk_coff[b_lo];
         res->stats.inflated_bytes = bytes;
       } else {
-        base = 0;
+        ts.base = 0;
         hi_abs = p.file_len;
-        u = p.d_comp.p;
-        res->stats.inflated_bytes = hi_abs - lo_abs;
+        ts.u = p.d_comp.p;
+        res->stats.inflated_bytes = hi_abs - run.lo_abs;
       }
-      const bool at_eof = hi_abs == p.text_len();
+      ts.at_eof = hi_abs == p.text_len();
+      ts.x0 = run.lo_abs - ts.base;
+      ts.hi = hi_abs - ts.base;
       t.start();
-      // ---- delimiter index over [x0, hi) ----
-      const uint64_t x0 = lo_abs - base, hi = hi_abs - base;
-      const uint64_t nch = vcf_delim_chunks(x0, hi);
-      cnt_nl.alloc(nch + 1); cnt_tab.alloc(nch + 1);
-      base_nl.alloc(nch + 2); base_tab.alloc(nch + 2);
-      scan_tmp.alloc(scan_tmp_elems(nch));
-      launch_vcf_delim_count(u, x0, hi, cnt_nl.p, cnt_tab.p, st);
-      launch_exclusive_scan_u32_to_u64(cnt_nl.p, base_nl.p, nch, scan_tmp.p, st);
-      launch_exclusive_scan_u32_to_u64(cnt_tab.p, base_tab.p, nch, scan_tmp.p, st);
-      uint64_t n_nl = 0, n_tab = 0;
-      uint8_t last = '\n';
-      HIP_CHECK(hipMemcpyAsync(&n_nl, base_nl.p + nch, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(&n_tab, base_tab.p + nch, 8, hipMemcpyDeviceToHost, st));
-      if (hi > x0) HIP_CHECK(hipMemcpyAsync(&last, u + hi - 1, 1, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      nl.alloc(n_nl + 1); nl_tabs.alloc(n_nl + 1); tab.alloc(n_tab + 1);
-      launch_vcf_delim_write(u, x0, hi, base_nl.p, base_tab.p, nl.p, nl_tabs.p, tab.p, st);
-      L.nl = nl.p; L.nl_tabs = nl_tabs.p; L.tab = tab.p;
-      L.n_nl = n_nl; L.n_tab = n_tab; L.x0 = x0; L.hi = hi;
-      const bool open_tail = hi > x0 && last != '\n';
-      L.n_lines = n_nl + (open_tail && at_eof ? 1 : 0);
-      if (indexed && !at_eof) {
+      run.index_lines(ts, li);
+      if (plan.indexed && !ts.at_eof) {
         // every line that starts before the last chunk end must be complete in the decoded bytes
-        uint64_t first_open = x0;
-        if (n_nl) {
-          uint64_t lastnl = 0;
-          HIP_CHECK(hipMemcpyAsync(&lastnl, nl.p + n_nl - 1, 8, hipMemcpyDeviceToHost, st));
-          HIP_CHECK(hipStreamSynchronize(st));
-          first_open = lastnl + 1;
-        }
-        if (first_open < E_abs - base) { extra *= 4; res->stats.ms_chain += t.stop(); continue; }
-      } else if (!at_eof && open_tail) {
+        if (li.first_open < run.E_abs - ts.base) { extra *= 4; res->stats.ms_chain += t.stop(); continue; }
+      } else if (!ts.at_eof && li.open_tail) {
         throw Error("VCF read error: decoded range ends inside a record");
       }
-      // ---- keys ----
-      k_pos.alloc(L.n_lines + 1); k_vend.alloc(L.n_lines + 1); k_flags.alloc(L.n_lines + 1);
-      bool want_end = indexed;
-      for (int s : col_src) if (s == 2) want_end = true;
-      launch_vcf_keys(u, L, k_pos.p, k_vend.p, k_flags.p, want_end ? 1 : 0, err.p, st);
+      run.line_keys(ts, li);
       res->stats.ms_chain += t.stop();
       lap("index+keys done");
       break;
     }
-    res->stats.n_records = L.n_lines;
-
-    // ---- row selection ----
+    res->stats.n_records = li.L.n_lines;
     t.start();
-    const uint64_t cap = limit >= 0 ? (uint64_t)limit : ~0ull;
-    if (!indexed) {
-      n = std::min<uint64_t>(L.n_lines, cap);
-      rows.alloc(std::max<uint64_t>(n, 1));
-      launch_vcf_iota_rows(rows.p, n, st);
-      uint32_t e = 0;
-      HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      // sequential scan: an error in a line beyond `limit` is never reached by the reference; lines are
-      // validated as a whole here, which only matters for malformed files
-      throw_vcf_err(e);
-    } else {
-      // string blob: region chroms + string literals of the residual terms
-      std::string blob;
-      std::vector<VcfFilterTerm> terms;
-      bool never = false;
-      for (auto& f : residual) {
-        int field;
-        if (f.column == "chrom") field = 0;
-        else if (f.column == "start") field = 1;
-        else if (f.column == "end") field = 2;
-        else if (f.column == "id") field = 3;
-        else continue;  // VcfRecordFields knows no other field: the term passes (storage.rs:1000-1024)
-        const bool is_str = field == 0 || field == 3;
-        VcfFilterTerm tm{};
-        tm.field = field;
-        tm.op = f.op;
-        auto num = [&](const Literal& l, double* v) {
-          if (l.kind == BIOSCAN_LIT_INT) { *v = (double)l.i; return true; }
-          if (l.kind == BIOSCAN_LIT_FLOAT) { *v = l.f; return true; }
-          return false;
-        };
-        auto put_str = [&](int k, const std::string& s) {
-          tm.str_off[k] = (uint32_t)blob.size();
-          tm.str_len[k] = (uint32_t)s.size();
-          blob += s;
-        };
-        if (f.op <= BIOSCAN_OP_GE) {
-          if (f.values.size() != 1) continue;
-          const Literal& l = f.values[0];
-          if (l.kind == BIOSCAN_LIT_NULL) { never = true; break; }
-          if (is_str) {
-            if (l.kind != BIOSCAN_LIT_STR) continue;
-            if (f.op != BIOSCAN_OP_EQ && f.op != BIOSCAN_OP_NE) continue;
-            put_str(0, l.s);
-          } else if (!num(l, &tm.vals[0])) continue;
-          tm.n_vals = 1;
-        } else if (f.op == BIOSCAN_OP_BETWEEN || f.op == BIOSCAN_OP_NOT_BETWEEN) {
-          if (f.values.size() != 2) continue;
-          if (f.values[0].kind == BIOSCAN_LIT_NULL || f.values[1].kind == BIOSCAN_LIT_NULL) { never = true; break; }
-          if (is_str) continue;
-          if (!num(f.values[0], &tm.vals[0]) || !num(f.values[1], &tm.vals[1])) continue;
-          tm.n_vals = 2;
-        } else {
-          // eight literals per term; a longer list continues in the following terms (`more`)
-          int k = 0;
-          for (auto& l : f.values) {
-            if (k == 8) { tm.n_vals = 8; tm.more = 1; terms.push_back(tm); tm.has_null = 0; tm.more = 0; k = 0; }
-            if (is_str) {
-              if (l.kind == BIOSCAN_LIT_NULL) tm.has_null = 1;
-              else if (l.kind == BIOSCAN_LIT_STR) put_str(k++, l.s);
-            } else {
-              double v;
-              if (num(l, &v)) tm.vals[k++] = v; else tm.has_null = 1;
-            }
-          }
-          tm.n_vals = k;
-        }
-        terms.push_back(tm);
-      }
-      std::vector<uint32_t> chrom_off;
-      for (auto& q : queries) { chrom_off.push_back((uint32_t)blob.size()); blob += q.region.chrom; }
-      DevBuf<uint8_t> d_blob(blob.size() + 1);
-      if (!blob.empty()) HIP_CHECK(hipMemcpyAsync(d_blob.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-      DevBuf<VcfFilterTerm> d_terms(terms.size() + 1);
-      if (!terms.empty()) HIP_CHECK(hipMemcpyAsync(d_terms.p, terms.data(), terms.size() * sizeof(VcfFilterTerm), hipMemcpyHostToDevice, st));
-      uint32_t e = 0;
-      HIP_CHECK(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      throw_vcf_err(e);
-      // per region: keep flags over the lines its chunks span, scan, compact
-      std::vector<DevBuf<uint32_t>> keeps(queries.size());
-      std::vector<DevBuf<uint64_t>> scans(queries.size());
-      std::vector<uint64_t> totals(queries.size(), 0), i_los(queries.size(), 0), i_ns(queries.size(), 0);
-      // two host round trips for all regions together (they used to cost two each): the line ranges of the regions'
-      // chunk spans first, then -- after every region's flags and scan have been queued -- the totals
-      const size_t nq = queries.size();
-      DevBuf<unsigned long long> lb(2 * nq + 2);
-      std::vector<unsigned long long> h_lb(2 * nq + 2, 0);
-      for (size_t qi = 0; qi < nq && !never; qi++) {
-        auto& q = queries[qi];
-        if (q.chunks_abs.empty()) continue;
-        if (q.chunks_abs.size() > 4096) throw Error("region query expands to more than 4096 index chunks");
-        launch_vcf_line_lower_bound(L, q.chunks_abs.front().first - base, lb.p + 2 * qi, st);
-        launch_vcf_line_lower_bound(L, q.chunks_abs.back().second - base, lb.p + 2 * qi + 1, st);
-      }
-      if (nq && !never) {
-        HIP_CHECK(hipMemcpyAsync(h_lb.data(), lb.p, (2 * nq) * 8, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipStreamSynchronize(st));
-      }
-      std::vector<DevBuf<uint64_t>> d_chs(nq);
-      uint64_t max_cnt = 0;
-      for (size_t qi = 0; qi < nq && !never; qi++)
-        if (!queries[qi].chunks_abs.empty() && h_lb[2 * qi + 1] > h_lb[2 * qi]) max_cnt = std::max<uint64_t>(max_cnt, h_lb[2 * qi + 1] - h_lb[2 * qi]);
-      DevBuf<uint64_t> tmp2(scan_tmp_elems(std::max<uint64_t>(max_cnt, 1)));  // the scans run one after the other on the stream
-      bool queued = false;
-      for (size_t qi = 0; qi < nq && !never; qi++) {
-        auto& q = queries[qi];
-        if (q.chunks_abs.empty()) continue;
-        const unsigned long long i_lo = h_lb[2 * qi], i_hi = h_lb[2 * qi + 1];
-        if (i_hi <= i_lo) continue;
-        std::vector<uint64_t> ch;
-        for (auto& c : q.chunks_abs) { ch.push_back(c.first - base); ch.push_back(c.second - base); }
-        d_chs[qi].alloc(ch.size());
-        HIP_CHECK(hipMemcpyAsync(d_chs[qi].p, ch.data(), ch.size() * 8, hipMemcpyHostToDevice, st));  // pageable source: copied before the call returns
-        VcfRowSelect S{};
-        S.mode = 1;
-        S.n_chunks = (int32_t)q.chunks_abs.size();
-        S.i_lo = i_lo; S.i_hi = i_hi;
-        S.chrom_off = chrom_off[qi];
-        S.chrom_len = (uint32_t)q.region.chrom.size();
-        S.q_start1 = q.region.has_start ? (int64_t)q.region.start : 1;
-        S.q_end1 = q.region.has_end ? (int64_t)std::min<uint64_t>(q.region.end, 1ull << 29) : (int64_t)(1ull << 29);
-        S.start1 = q.region.has_start ? (int64_t)q.region.start : 0;
-        S.end1 = q.region.has_end ? (int64_t)q.region.end : 0;
-        S.zero_based = p.zero_based ? 1 : 0;
-        S.n_terms = (int32_t)terms.size();
-        const uint64_t cntl = i_hi - i_lo;
-        keeps[qi].alloc(cntl + 1);
-        scans[qi].alloc(cntl + 2);
-        launch_vcf_row_flags(u, L, k_pos.p, k_vend.p, k_flags.p, S, d_chs[qi].p, d_terms.p, d_blob.p, keeps[qi].p, st);
-        launch_exclusive_scan_u32_to_u64(keeps[qi].p, scans[qi].p, cntl, tmp2.p, st);
-        HIP_CHECK(hipMemcpyAsync(&totals[qi], scans[qi].p + cntl, 8, hipMemcpyDeviceToHost, st));
-        queued = true;
-        i_los[qi] = i_lo;
-        i_ns[qi] = cntl;
-      }
-      if (queued) HIP_CHECK(hipStreamSynchronize(st));
-      uint64_t total = 0;
-      for (auto v : totals) total += v;
-      n = std::min<uint64_t>(total, cap);
-      rows.alloc(std::max<uint64_t>(n, 1));
-      uint64_t rb = 0;
-      for (size_t qi = 0; qi < queries.size() && rb < n; qi++) {
-        if (!totals[qi]) continue;
-        launch_vcf_compact(keeps[qi].p, scans[qi].p, i_ns[qi], i_los[qi], rows.p, rb, n - rb, st);
-        rb += std::min<uint64_t>(totals[qi], n - rb);
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
+    n = run.select_rows(ts, li, 0, run.queries.size(), run.rows_left, rows);
     res->stats.ms_select = t.stop();
     lap("select done");
   }
-  res->n_rows = n;
   res->stats.n_rows = n;
-
-  // ---- columns ----
   t.start();
-  res->cols.resize(out_fields.size());
-  for (size_t c = 0; c < out_fields.size(); c++) { res->cols[c].fd = out_fields[c]; res->cols[c].n = n; }
-  Ctx cx{p, st, u, {}, 0, err.p, 0, {}};
-  if (n) {
-    int core_col[8];
-    for (int k = 0; k < 8; k++) core_col[k] = -1;
-    std::vector<std::pair<int, int>> info_cols, fmt_cols;  // (output column, field index)
-    int geno_col = -1;
-    for (size_t c = 0; c < out_fields.size(); c++) {
-      const int s = col_src[c];
-      if (s < 8) core_col[s] = (int)c;
-      else if (s < 8 + n_info) info_cols.emplace_back((int)c, s - 8);
-      else if (multi) geno_col = (int)c;
-      else fmt_cols.emplace_back((int)c, s - 8 - n_info);
-    }
-    // core
-    {
-      VcfCoreCols C{};
-      DevBuf<uint64_t> src[5];
-      DevBuf<uint32_t> len[5];
-      const int sidx[5] = {0, 3, 4, 5, 7};
-      uint64_t** sp[5] = {&C.src_chrom, &C.src_id, &C.src_ref, &C.src_alt, &C.src_filter};
-      uint32_t** lp[5] = {&C.len_chrom, &C.len_id, &C.len_ref, &C.len_alt, &C.len_filter};
-      for (int k = 0; k < 5; k++)
-        if (core_col[sidx[k]] >= 0) { src[k].alloc(n); len[k].alloc(n); *sp[k] = src[k].p; *lp[k] = len[k].p; }
-      if (core_col[1] >= 0) { auto& nd = res->cols[core_col[1]]; nd.d_values.alloc(n * 4); C.start = (uint32_t*)nd.d_values.p; cx.arrow_bytes += n * 4; }
-      if (core_col[2] >= 0) { auto& nd = res->cols[core_col[2]]; nd.d_values.alloc(n * 4); C.end = (uint32_t*)nd.d_values.p; cx.arrow_bytes += n * 4; }
-      if (core_col[6] >= 0) {
-        auto& nd = res->cols[core_col[6]];
-        nd.d_values.alloc(n * 8);
-        nd.d_valid.alloc((n + 63) / 64);
-        nd.all_valid = false;
-        C.qual = (double*)nd.d_values.p;
-        C.v_qual = nd.d_valid.p;
-        cx.arrow_bytes += n * 8 + (n + 63) / 64 * 8;
-      }
-      launch_vcf_core(u, L, rows.p, n, k_pos.p, k_vend.p, k_flags.p, C, p.zero_based ? 1 : 0, err.p, st);
-      for (int k = 0; k < 5; k++)
-        if (core_col[sidx[k]] >= 0) {
-          VNode& nd = res->cols[core_col[sidx[k]]];
-          finish_utf8(cx, nd, src[k].p, len[k].p, n);
-          if (sidx[k] == 5) launch_replace_byte(nd.d_values.p, nd.total, ',', '|', st);  // alleles re-joined with '|'
-        }
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
-    // INFO
-    if (!info_cols.empty()) {
-      std::string blob;
-      std::vector<uint32_t> koff{0};
-      for (auto& ic : info_cols) { blob += sch.info_fields[ic.second]; koff.push_back((uint32_t)blob.size()); }
-      const int K = (int)info_cols.size();
-      DevBuf<uint8_t> d_keys(blob.size() + 1);
-      DevBuf<uint32_t> d_koff(koff.size());
-      HIP_CHECK(hipMemcpyAsync(d_keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(d_koff.p, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, st));
-      DevBuf<uint64_t> sp_off((uint64_t)K * n);
-      DevBuf<uint32_t> sp_len((uint64_t)K * n);
-      DevBuf<uint8_t> sp_state((uint64_t)K * n);
-      launch_vcf_info_locate(u, L, rows.p, n, d_keys.p, d_koff.p, K, sp_off.p, sp_len.p, sp_state.p, err.p, st);
-      for (int k = 0; k < K; k++) {
-        VNode& nd = res->cols[info_cols[k].first];
-        build_from_spans(cx, nd, sp_off.p + (uint64_t)k * n, sp_len.p + (uint64_t)k * n, sp_state.p + (uint64_t)k * n, n);
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
-    // FORMAT
-    if (sch.has_format && (geno_col >= 0 || !fmt_cols.empty())) {
-      std::vector<int> sel;  // FORMAT field indices to extract
-      if (geno_col >= 0) for (size_t k = 0; k < sch.format_fields.size(); k++) sel.push_back((int)k);
-      else for (auto& fc : fmt_cols) sel.push_back(fc.second);
-      const int S = (int)sel.size();
-      std::string blob;
-      std::vector<uint32_t> koff{0};
-      int gt_field = -1;
-      for (int s = 0; s < S; s++) {
-        const std::string& tag = sch.format_fields[sel[s]];
-        if (tag == "GT") gt_field = s;
-        blob += tag;
-        koff.push_back((uint32_t)blob.size());
-      }
-      DevBuf<uint8_t> d_keys(blob.size() + 1);
-      DevBuf<uint32_t> d_koff(koff.size());
-      HIP_CHECK(hipMemcpyAsync(d_keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(d_koff.p, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, st));
-      // single-sample source: the one sample (load_formats_single_pass takes `sample_count` leading samples)
-      std::vector<int32_t> scol = multi ? sch.sample_header_index : std::vector<int32_t>{0};
-      const uint64_t ns = scol.size();
-      DevBuf<int32_t> d_scol(ns);
-      HIP_CHECK(hipMemcpyAsync(d_scol.p, scol.data(), ns * 4, hipMemcpyHostToDevice, st));
-      DevBuf<int16_t> fpos(n * (uint64_t)S);
-      launch_vcf_format_keys(u, L, rows.p, n, d_keys.p, d_koff.p, S, fpos.p, st);
-      const uint64_t N = n * ns;
-      DevBuf<uint64_t> sp_off((uint64_t)S * N);
-      DevBuf<uint32_t> sp_len((uint64_t)S * N);
-      DevBuf<uint8_t> sp_state((uint64_t)S * N);
-      // shape of the output nodes first: scalar Int32 / Float32 keys are parsed inside the cell kernel straight into
-      // their value buffers; strings and lists go through spans
-      std::vector<VNode*> leaf((size_t)S);
-      if (geno_col >= 0) {
-        VNode& g = res->cols[geno_col];
-        g.kids.resize((size_t)S);
-        for (int s = 0; s < S; s++) {
-          VNode& lst = g.kids[s];
-          lst.fd = g.fd.children.at((size_t)s);
-          lst.n = n;
-          lst.total = N;
-          lst.d_off.alloc(n + 1);
-          launch_stride_offsets(lst.d_off.p, n, ns, st);
-          lst.kids.resize(1);
-          lst.kids[0].fd = lst.fd.children.at(0);
-          leaf[s] = &lst.kids[0];
-          cx.arrow_bytes += (n + 1) * 4;
-        }
-      } else {
-        for (int s = 0; s < S; s++) leaf[s] = &res->cols[fmt_cols[s].first];
-      }
-      VcfCellDirect D{};
-      const uint64_t nwN = (N + 63) / 64;
-      DevBuf<uint64_t> gt_src;
-      DevBuf<uint32_t> gt_len;
-      for (int s = 0; s < S && s < VCF_MAX_DIRECT; s++) {
-        VNode& nd = *leaf[s];
-        if (s == gt_field && nd.fd.kind == VK_UTF8) {   // GT: length + source + validity straight from the cell kernel
-          nd.n = N;
-          nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
-          nd.all_valid = false;
-          gt_src.alloc(std::max<uint64_t>(N, 1));
-          gt_len.alloc(std::max<uint64_t>(N, 1));
-          D.kind[s] = 3;
-          D.values[s] = gt_len.p;
-          D.src[s] = gt_src.p;
-          D.valid[s] = nd.d_valid.p;
-          cx.arrow_bytes += nwN * 8;
-          continue;
-        }
-        if (nd.fd.kind != VK_INT32 && nd.fd.kind != VK_FLOAT32) continue;
-        nd.n = N;
-        nd.d_values.alloc(std::max<uint64_t>(N, 1) * 4);
-        nd.d_valid.alloc(std::max<uint64_t>(nwN, 1));
-        nd.all_valid = false;
-        D.kind[s] = nd.fd.kind == VK_INT32 ? 1 : 2;
-        D.values[s] = (uint32_t*)nd.d_values.p;
-        D.valid[s] = nd.d_valid.p;
-        cx.arrow_bytes += N * 4 + nwN * 8;
-      }
-      launch_vcf_format_cells(u, L, rows.p, n, d_scol.p, (int)ns, fpos.p, S, gt_field, D, sp_off.p, sp_len.p, sp_state.p, err.p, st);
-      for (int s = 0; s < S; s++) {
-        if (s < VCF_MAX_DIRECT && D.kind[s] == 3) { finish_utf8(cx, *leaf[s], gt_src.p, gt_len.p, N); continue; }
-        if (s < VCF_MAX_DIRECT && D.kind[s] != 0) continue;
-        build_from_spans(cx, *leaf[s], sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
-    uint32_t e2[2] = {0, 0};
-    HIP_CHECK(hipMemcpyAsync(e2, err.p, 8, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    throw_vcf_err(e2[0]);
-    if (e2[1]) {  // float literals within 2^-52 of a rounding boundary: decided by exact integer comparison
-      launch_f32_fix(err.p, e2[1], st);
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
-  } else {
-    // zero rows: struct / list kids still need their (empty) shape for export
-    std::function<void(VNode&)> shape = [&](VNode& nd) {
-      nd.n = 0;
-      for (auto& cf : nd.fd.children) {
-        nd.kids.emplace_back();
-        nd.kids.back().fd = cf;
-        shape(nd.kids.back());
-      }
-    };
-    for (auto& col : res->cols) shape(col);
-  }
+  run.build_columns(ts, li, rows, n, *res);
   res->stats.ms_extract = t.stop();
   lap("extract done");
-  res->stats.arrow_bytes = cx.arrow_bytes;
   res->stats.ms_total_gpu = res->stats.ms_inflate + res->stats.ms_crc + res->stats.ms_chain + res->stats.ms_select + res->stats.ms_extract;
   res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   if (!device_only) {
@@ -1080,6 +1155,352 @@ VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool devi
     res->on_host = true;
   }
   lap("end");
+  return res;
+}
+
+// ---- the chunk pipeline of a host stream (bio-format-vcf/src/physical_exec.rs:66-232, 912-1198: the reference reads line by
+//      line and hands out a batch at a time, `EmissionType::Incremental`) ----
+// The partition's work is a list of items -- the whole data section of a sequential plan, or one item per region of an
+// indexed one, in assignment order (rows come region after region, as the reference's queries do).  An item's members are
+// inflated `chunk_members` at a time; a chunk's rows are its complete lines that the item's predicate keeps; the line cut
+// by the chunk's end is carried, as bytes, to the head of the next chunk's buffer.  HBM and host memory: O(chunk).
+struct VcfChunkStream : VcfStreamI {
+  VcfRun run;
+  VcfProvider& p;
+  const uint32_t chunk_members;
+  const bool ramp;
+  std::shared_ptr<DeviceImage> img;
+  K1Ctx k1;
+  hipStream_t st = nullptr;
+  struct Item { size_t q0, q1; uint64_t lo_abs, E_abs; };
+  std::vector<Item> items;
+  size_t item = 0;
+  bool item_open = false, dead = false;
+  uint32_t next_member = 0, chunks_done = 0, ext = 1;
+  uint64_t carry_len = 0, skip = 0;
+  DevBuf<uint8_t> ubuf[2];
+  int cur = 0;
+  bioscan_scan_stats total{};
+  // batches are cut from the chunks' rows in order; one that straddles two chunks is concatenated on the host
+  std::deque<std::shared_ptr<VResult>> ready;
+  uint64_t ready_off = 0;   // rows of ready.front() already handed out
+  bool exhausted = false;
+
+  VcfChunkStream(const VcfPlan& plan, int32_t partition, int32_t batch_size_in)
+      : run(plan, partition, batch_size_in), p(*plan.prov),
+        chunk_members(p.chunk_members ? p.chunk_members : env_knobs().chunk_members), ramp(!p.chunk_members) {
+    if (!run.nothing) {
+      if (!plan.indexed) items.push_back(Item{0, 0, run.lo_abs, p.text_len()});
+      else
+        for (size_t q = 0; q < run.queries.size(); q++) {
+          auto& c = run.queries[q].chunks_abs;
+          if (c.empty()) continue;
+          uint64_t mn = ~0ull, mx = 0;
+          for (auto& ch : c) { mn = std::min(mn, ch.first); mx = std::max(mx, ch.second); }
+          items.push_back(Item{q, q + 1, mn, mx});
+        }
+    }
+    uint32_t m_lo = p.n_blocks(), m_hi = 0;
+    for (auto& it : items) {
+      m_lo = std::min(m_lo, block_of_abs(p, it.lo_abs));
+      m_hi = std::max<uint32_t>(m_hi, std::min<uint32_t>(p.n_blocks(), block_of_abs(p, it.E_abs ? it.E_abs - 1 : 0) + 2));
+    }
+    if (m_hi < m_lo) m_lo = m_hi = 0;
+    img = p.image_for(p.device, m_lo, m_hi);
+    HIP_CHECK(hipSetDevice(img->device));
+    p.init_ctx(k1, *img, std::min<uint32_t>(chunk_members, std::max<uint32_t>(m_hi - m_lo, 1)), false);
+    st = k1.stream;
+    run.upload_filters(st);
+  }
+  ~VcfChunkStream() override {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (img) (void)hipSetDevice(img->device);
+    if (k1.stream) (void)hipStreamSynchronize(k1.stream);
+    (void)hipSetDevice(prev);
+  }
+  uint32_t chunk_len(uint32_t k) const {
+    uint64_t c = chunk_members;
+    if (ramp) c = std::min<uint64_t>(c, 2048ull << std::min<uint32_t>(k, 16));
+    return (uint32_t)std::max<uint64_t>(c, 1);
+  }
+
+  // the next chunk that has rows (on the host), or nullptr at the end of the partition
+  std::shared_ptr<VResult> next_chunk() {
+    for (;;) {
+      if (run.rows_left == 0) return nullptr;
+      if (!item_open) {
+        if (item >= items.size()) return nullptr;
+        const Item& it = items[item];
+        next_member = block_of_abs(p, it.lo_abs);
+        skip = it.lo_abs - p.blk_uoff[next_member];
+        carry_len = 0;
+        ext = 1;
+        item_open = true;
+      }
+      auto res = run_chunk(items[item]);
+      if (!item_open) item++;
+      if (res && res->n_rows) return res;
+    }
+  }
+
+  std::shared_ptr<VResult> run_chunk(const Item& it) {
+    Timer t(st);
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto res = std::make_shared<VResult>();
+    res->device = img->device;
+    res->stream = st;
+    res->batch_size = run.batch_size;
+    const uint32_t m0 = next_member;
+    const uint32_t m_end = std::min<uint32_t>(p.n_blocks(), block_of_abs(p, it.E_abs ? it.E_abs - 1 : 0) + 1);  // members that hold the item's span
+    uint32_t m1 = std::min<uint32_t>(p.n_blocks(), m0 + chunk_len(chunks_done));
+    if (m0 < m_end) m1 = std::min(m1, std::max(m_end, m0 + 1));   // a chunk ends with the item's span at the latest ...
+    else { m1 = (uint32_t)std::min<uint64_t>(p.n_blocks(), (uint64_t)m0 + ext); ext *= 2; }  // ... behind it: 1, 2, 4, ... members until the span's last line is whole
+    if (m1 > img->m_hi || m0 < img->m_lo) img = p.image_for(img->device, std::min(m0, img->m_lo), std::max(m1, img->m_hi));
+    const uint64_t bytes = p.blk_uoff[m1] - p.blk_uoff[m0];
+    const uint64_t L = carry_len + bytes;
+    if (ubuf[cur].n < L + 64) {
+      DevBuf<uint8_t> g(L + 64);
+      if (carry_len) HIP_CHECK(hipMemcpyAsync(g.p, ubuf[cur].p, carry_len, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      ubuf[cur] = std::move(g);
+    }
+    uint8_t* u = ubuf[cur].p;
+    if (m1 > m0) {
+      if (k1.status.n < m1 - m0) p.init_ctx(k1, *img, m1 - m0, false);
+      t.start();
+      p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
+      res->stats.ms_inflate = t.stop();
+      t.start();
+      p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
+      res->stats.ms_crc = t.stop();
+      p.check_inflate_status(k1, m0, m1 - m0);
+    }
+    res->stats.n_blocks = m1 - m0;
+    res->stats.compressed_bytes = p.blk_coff[m1] - p.blk_coff[m0];
+    res->stats.inflated_bytes = bytes;
+    TextSpan ts;
+    ts.u = u;
+    ts.base = p.blk_uoff[m0] - carry_len;
+    ts.x0 = carry_len ? 0 : skip;    // (the carried bytes begin with a line; the item's first chunk begins at its first byte)
+    ts.hi = L;
+    ts.at_eof = m1 == p.n_blocks();
+    skip = 0;
+    t.start();
+    LineIndex li;
+    run.index_lines(ts, li);
+    if (!ts.at_eof) li.L.n_lines = li.L.n_nl;   // the open tail is the next chunk's first line
+    run.line_keys(ts, li);
+    res->stats.ms_chain = t.stop();
+    res->stats.n_records = li.L.n_lines;
+    t.start();
+    DevBuf<uint64_t> rows;
+    const uint64_t n = run.select_rows(ts, li, it.q0, it.q1, run.rows_left, rows);
+    res->stats.ms_select = t.stop();
+    res->stats.n_rows = n;
+    t.start();
+    if (n) run.build_columns(ts, li, rows, n, *res);
+    res->stats.ms_extract = t.stop();
+    if (run.rows_left != ~0ull) run.rows_left -= n;
+    // ---- is the item over?  every line that starts in front of the span's end has been seen whole ----
+    const bool over = ts.at_eof || ts.base + li.first_open >= it.E_abs || run.rows_left == 0;
+    if (!over && m1 == p.n_blocks() && li.open_tail) throw Error("VCF read error: decoded range ends inside a record");
+    next_member = m1;
+    chunks_done++;
+    if (over) { item_open = false; carry_len = 0; }
+    else {
+      const uint64_t c = L - li.first_open;
+      const int nxt = cur ^ 1;
+      const uint64_t next_bytes = p.blk_uoff[std::min<uint64_t>(p.n_blocks(), (uint64_t)m1 + chunk_len(chunks_done))] - p.blk_uoff[m1];
+      if (ubuf[nxt].n < c + next_bytes + 64) ubuf[nxt].alloc(c + next_bytes + 64);
+      if (c) HIP_CHECK(hipMemcpyAsync(ubuf[nxt].p, u + li.first_open, c, hipMemcpyDeviceToDevice, st));
+      carry_len = c;
+      cur = nxt;
+    }
+    if (n) {
+      for (auto& col : res->cols) copy_node_to_host(col, st);
+      HIP_CHECK(hipStreamSynchronize(st));
+      for (auto& col : res->cols) free_node_device(col);
+      res->on_host = true;
+    } else HIP_CHECK(hipStreamSynchronize(st));
+    res->stats.ms_total_gpu = res->stats.ms_inflate + res->stats.ms_crc + res->stats.ms_chain + res->stats.ms_select + res->stats.ms_extract;
+    res->stats.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return n ? res : nullptr;
+  }
+
+  bool next(ArrowArray* out) override;
+  void list_udf(const char*, int32_t, double, bioscan_udf_stats*) override {
+    throw Error("list UDFs on a stream need a device-resident execution (bioscan_execute_device)");
+  }
+};
+
+// ---- a batch out of several chunks' rows: concatenation on the host (one batch per chunk boundary at most) ----
+struct NodePiece { const VNode* nd; uint64_t lo, hi; };
+static void append_bits(uint8_t* dst, uint64_t pos, const uint8_t* src, uint64_t lo, uint64_t n) {  // dst is zero-initialised
+  for (uint64_t k = 0; k < n; k++) {   // (at most one batch of rows per chunk boundary goes through here)
+    const uint64_t s = lo + k;
+    if ((src[s >> 3] >> (s & 7)) & 1u) dst[(pos + k) >> 3] |= (uint8_t)(1u << ((pos + k) & 7));
+  }
+}
+static void concat_nodes(VNode& dst, const std::vector<NodePiece>& ps) {
+  dst.fd = ps[0].nd->fd;
+  uint64_t n = 0;
+  bool nullable = false;
+  for (auto& q : ps) { n += q.hi - q.lo; if (!q.nd->all_valid && q.nd->h_valid.p) nullable = true; }
+  dst.n = n;
+  const uint64_t nw = (n + 63) / 64;
+  if (nullable) {
+    dst.all_valid = false;
+    dst.h_valid.alloc(nw * 8 + 16);
+    memset(dst.h_valid.p, 0, nw * 8 + 16);
+    uint64_t pos = 0;
+    for (auto& q : ps) {
+      const uint64_t len = q.hi - q.lo;
+      if (!q.nd->all_valid && q.nd->h_valid.p) append_bits(dst.h_valid.p, pos, q.nd->h_valid.p, q.lo, len);
+      else for (uint64_t k = 0; k < len; k++) dst.h_valid.p[(pos + k) >> 3] |= (uint8_t)(1u << ((pos + k) & 7));
+      pos += len;
+    }
+  }
+  switch (dst.fd.kind) {
+    case VK_INT32: case VK_UINT32: case VK_FLOAT32: case VK_FLOAT64: {
+      const uint32_t w = fixed_width(dst.fd.kind);
+      dst.h_values.alloc(n * w + 16);
+      uint64_t pos = 0;
+      for (auto& q : ps) {
+        const uint64_t len = q.hi - q.lo;
+        if (len && q.nd->h_values.p) memcpy(dst.h_values.p + pos * w, q.nd->h_values.p + q.lo * w, len * w);
+        pos += len;
+      }
+      break;
+    }
+    case VK_BOOL: {
+      dst.h_values.alloc(nw * 8 + 16);
+      memset(dst.h_values.p, 0, nw * 8 + 16);
+      uint64_t pos = 0;
+      for (auto& q : ps) {
+        const uint64_t len = q.hi - q.lo;
+        if (len && q.nd->h_values.p) append_bits(dst.h_values.p, pos, q.nd->h_values.p, q.lo, len);
+        pos += len;
+      }
+      break;
+    }
+    case VK_UTF8: {
+      uint64_t bytes = 0;
+      for (auto& q : ps) if (q.hi > q.lo) { const uint64_t* o = (const uint64_t*)q.nd->h_off.p; bytes += o[q.hi] - o[q.lo]; }
+      dst.total = bytes;
+      dst.h_off.alloc((n + 1) * 8 + 16);
+      dst.h_values.alloc(bytes + 16);
+      uint64_t* d = (uint64_t*)dst.h_off.p;
+      uint64_t pos = 0, b = 0;
+      d[0] = 0;
+      for (auto& q : ps) {
+        if (q.hi <= q.lo) continue;
+        const uint64_t* o = (const uint64_t*)q.nd->h_off.p;
+        const uint64_t b0 = o[q.lo];
+        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (o[k + 1] - b0);
+        if (o[q.hi] > b0) memcpy(dst.h_values.p + b, q.nd->h_values.p + b0, o[q.hi] - b0);
+        b += o[q.hi] - b0;
+      }
+      break;
+    }
+    case VK_LIST: {
+      dst.h_off.alloc((n + 1) * 8 + 16);
+      uint64_t* d = (uint64_t*)dst.h_off.p;
+      uint64_t pos = 0, b = 0;
+      d[0] = 0;
+      std::vector<NodePiece> kid;
+      for (auto& q : ps) {
+        if (q.hi <= q.lo) continue;
+        const uint64_t* o = (const uint64_t*)q.nd->h_off.p;
+        const uint64_t b0 = o[q.lo];
+        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (o[k + 1] - b0);
+        b += o[q.hi] - b0;
+        kid.push_back(NodePiece{&q.nd->kids.at(0), b0, o[q.hi]});
+      }
+      dst.total = b;
+      dst.kids.resize(1);
+      if (kid.empty()) kid.push_back(NodePiece{&ps[0].nd->kids.at(0), 0, 0});
+      concat_nodes(dst.kids[0], kid);
+      break;
+    }
+    case VK_STRUCT: {
+      const size_t nk = ps[0].nd->kids.size();
+      dst.kids.resize(nk);
+      for (size_t c = 0; c < nk; c++) {
+        std::vector<NodePiece> kid;
+        for (auto& q : ps) kid.push_back(NodePiece{&q.nd->kids.at(c), q.lo, q.hi});
+        concat_nodes(dst.kids[c], kid);
+      }
+      break;
+    }
+  }
+}
+
+static void export_rows(const std::shared_ptr<VResult>& res, uint64_t lo, uint64_t hi, ArrowArray* out) {
+  ArrayPriv* top = init_array(out, res, (int64_t)(hi - lo));
+  top->buffers.push_back(nullptr);
+  for (auto& col : res->cols) {
+    std::unique_ptr<ArrowArray> ca(new ArrowArray);
+    export_node(res, col, lo, hi, ca.get());
+    top->children.push_back(ca.get());
+    top->owned.push_back(std::move(ca));
+  }
+  finish_array(out);
+}
+
+bool VcfChunkStream::next(ArrowArray* out) {
+  if (dead) throw Error("the stream ended with an error");
+  struct Guard { bool* d; bool ok = false; ~Guard() { if (!ok) *d = true; } } guard{&dead};
+  HIP_CHECK(hipSetDevice(img->device));
+  const uint64_t bs = run.batch_size;
+  uint64_t have = 0;
+  for (auto& r : ready) have += r->n_rows;
+  have -= ready_off;
+  while (have < bs && !exhausted) {
+    auto r = next_chunk();
+    if (!r) { exhausted = true; break; }
+    have += r->n_rows;
+    ready.push_back(std::move(r));
+  }
+  guard.ok = true;
+  if (!have) return false;
+  const uint64_t take = std::min(bs, have);
+  if (ready.front()->n_rows - ready_off >= take) {
+    export_rows(ready.front(), ready_off, ready_off + take, out);
+    ready_off += take;
+  } else {
+    // the batch straddles chunks: its rows are copied into a result of their own
+    auto merged = std::make_shared<VResult>();
+    merged->batch_size = bs;
+    merged->on_host = true;
+    merged->n_rows = take;
+    const size_t nc = ready.front()->cols.size();
+    merged->cols.resize(nc);
+    std::vector<std::vector<NodePiece>> pieces(nc);
+    uint64_t left = take, off = ready_off;
+    for (auto& r : ready) {
+      if (!left) break;
+      const uint64_t len = std::min(left, r->n_rows - off);
+      for (size_t c = 0; c < nc; c++) pieces[c].push_back(NodePiece{&r->cols[c], off, off + len});
+      left -= len;
+      off = 0;
+    }
+    for (size_t c = 0; c < nc; c++) concat_nodes(merged->cols[c], pieces[c]);
+    export_rows(merged, 0, take, out);
+    ready_off += take;
+  }
+  while (!ready.empty() && ready_off >= ready.front()->n_rows) { ready_off -= ready.front()->n_rows; ready.pop_front(); }
+  return true;
+}
+
+VcfStreamI* VcfPlan::execute(int32_t partition, int32_t batch_size_in, bool device_only, bioscan_scan_stats* stats_out) const {
+  if (partition < 0 || partition >= n_partitions()) throw Error("partition index out of range");
+  if (batch_size_in <= 0) throw Error("batch_size must be positive");
+  if (!device_only && prov->bgzf) {
+    if (stats_out) *stats_out = bioscan_scan_stats{};
+    return new VcfChunkStream(*this, partition, batch_size_in);
+  }
+  auto res = execute_oneshot(*this, partition, batch_size_in, device_only);
   if (stats_out) *stats_out = res->stats;
   auto* s = new VcfStream();
   s->res = res;
