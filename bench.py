@@ -257,6 +257,18 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
             # the UDF checksums of the two implementations must agree
             assert int(r["avg_gq_valid"]) == us[0]["count_a"] and int(r["gq_gte_true"]) == us[2]["count_a"], (r, us)
             assert int(r["dp_gte_true"]) == us[3]["count_a"] and int(r["dp_lte_true"]) == us[4]["count_a"], (r, us)
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        # file resident in HBM -> Arrow buffers in host memory through the chunk pipeline (VcfChunkStream); never part of `value`
+        runs = [plan.execute_drain(0, args.batch_size) for _ in range(2)]
+        r = runs[-1]
+        if int(r["n_rows"]) != int(st["n_rows"]):
+            raise SystemExit(f"end-to-end stream returned {r['n_rows']} rows, the device-resident scan {st['n_rows']}")
+        e2e = {"Mrows_s": round(r["n_rows"] / r["seconds"] / 1e6, 4), "seconds": round(r["seconds"], 3),
+               "ms_to_first_batch": round(r["seconds_to_first_batch"] * 1e3, 2), "n_batches": r["n_batches"],
+               "first_run_seconds": round(runs[0]["seconds"], 3),
+               "what": "bioscan_execute + bioscan_next until end of stream, every batch released at once; chunks of 2048 doubling to "
+                       "%d BGZF members, HBM and host footprint O(chunk)" % int(os.environ.get("BIOSCAN_CHUNK_MEMBERS", 16384))}
     if rank == 0:
         per_step = elapsed / args.steps
         # algorithmic bytes of the text stage: decoded text read once by the delimiter index + once by the
@@ -285,6 +297,7 @@ def bench_vcf(args, pkg, rank, local_rank, world, torch, dist):
             "roofline": {"bound": "hbm", "kernel": "VCF pipeline (inflate + text kernels)", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
             "cpu_baseline": cpu,
+            "end_to_end": e2e,
             "setup_s": {"generate": round(t_gen, 1)}}
         print(json.dumps(out))
     if world > 1:

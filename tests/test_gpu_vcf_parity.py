@@ -93,10 +93,12 @@ def _cmp_partition(got, want, ctx, exact_batches=True):
             assert a.type == b.type, (ctx, n, a.type, b.type)
 
 
-def _parity(pkg, vo, path, kw, names=None, filters=(), target=1, limit=None, bs=8192, exact_batches=True):
+def _parity(pkg, vo, path, kw, names=None, filters=(), target=1, limit=None, bs=8192, exact_batches=True, chunk_members=0):
     okw = dict(kw)
     o = vo.VcfOracle(path, **okw)
     g = pkg.VcfTableProvider(path, kw.get("info_fields"), kw.get("format_fields"), None, kw.get("zero_based", True), kw.get("samples"))
+    if chunk_members:
+        g.set_chunk_members(chunk_members)   # BGZF members per pipeline chunk of the streams below
     _schema_equal(g.schema(), o.schema)
     proj = None if names is None else [o.schema.get_field_index(n) for n in names]
     oplan = o.scan(projection=proj, filters=list(filters), limit=limit, target_partitions=target)
@@ -693,3 +695,35 @@ def test_differential_fuzz_of_whole_files(pkg, vo):
     assert tot["rows"] > 10000 and tot["refused_by_both"] > 5, tot
     from conftest import report_size
     report_size("test_differential_fuzz_of_whole_files", **tot)
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 7, 1000])
+def test_chunked_stream_any_chunk_size(pkg, vo, tmp_path, chunk):
+    """The chunk pipeline of a VCF stream (csrc/vcf_engine.cpp VcfChunkStream): members are inflated `chunk` at a time, the
+    line cut by a chunk's end is carried to the next chunk, an indexed partition streams region after region and a batch
+    that straddles chunks is concatenated on the host -- none of which may change a batch (the reference reads line by
+    line in constant memory, bio-format-vcf/src/physical_exec.rs:912-1198).  Sites with every INFO column, indexed
+    partitions and region filters on the reference's fixture, a limit, and a 1000-sample file whose lines span members."""
+    path = os.path.join(G, "multi_chrom_large.vcf.gz")
+    for tp in (1, 3, 8):
+        assert _parity(pkg, vo, path, {}, target=tp, bs=77, chunk_members=chunk) == 10000
+    assert _parity(pkg, vo, path, {}, names=["chrom", "start", "AF"], filters=[("chrom", "in", ["21", "22"])], target=4, bs=100,
+                   chunk_members=chunk) == 10000
+    n = _parity(pkg, vo, path, {}, names=["chrom", "id"], target=2, bs=13, chunk_members=chunk,
+                filters=[("chrom", "=", "21"), ("start", ">=", 5009999), ("start", "<=", 5029999)])
+    assert 0 < n < 5000
+    assert _parity(pkg, vo, path, {}, names=["chrom"], filters=[("chrom", "=", "22")], limit=4100, bs=1000, chunk_members=chunk) == 4100
+    # no index: one sequential partition
+    dst = tmp_path / "noindex.vcf.gz"
+    dst.write_bytes(open(path, "rb").read())
+    assert _parity(pkg, vo, str(dst), {}, bs=333, chunk_members=chunk) == 10000
+    assert _parity(pkg, vo, str(dst), {}, names=["qual", "filter", "DP"], limit=2500, bs=1000, chunk_members=chunk) == 2500
+    # 1000 samples: a line is ~8 KB, the members 4 KB -- every line spans members, most chunks of one member hold no line end
+    rng = random.Random(5 + chunk)
+    rows = [[f"{rng.choice(['0/1', '1|1', './.', '0/0'])}:{rng.choice(['.', '7', '99', '30'])}:{rng.choice(['.', '12', '250'])}"
+             for _ in range(1000)] for _ in range(25)]
+    ms = tmp_path / "ms.vcf.gz"
+    ms.write_bytes(bgzf_compress(_ms_vcf(rows).encode(), 4096))
+    assert _parity(pkg, vo, str(ms), {"format_fields": ["GT", "GQ", "DP"]}, exact_batches=False, chunk_members=chunk) == 25
+    assert _parity(pkg, vo, str(ms), {"format_fields": ["GT", "DP"], "samples": ["S3", "S999", "S0"]}, names=["start", "genotypes"],
+                   exact_batches=False, chunk_members=chunk) == 25
