@@ -60,6 +60,8 @@ static void throw_vcf_err(uint32_t e) {
     case VERR_INVALID_FLAG: throw Error("Error reading INFO field: invalid flag");
     case VERR_PERCENT: throw Error("VCF read error: invalid UTF-8 after percent-decoding a string value");
     case VERR_BAD_GT: throw Error("Error reading FORMAT field 'GT': invalid genotype");
+    case VERR_BAD_CHAR: throw Error("Error reading INFO / FORMAT field: invalid character");
+    case VERR_UNSUPPORTED_INFO: throw Error("Unsupported INFO value type for a Character field");
     default: throw Error("VCF read error: device error " + std::to_string(e));
   }
 }
@@ -572,6 +574,51 @@ struct LineIndex {
 // regions of the partition, the limit.  run_rows() turns a stretch of decoded text into the Arrow nodes of its rows; the
 // one-shot form (device-resident executions, plain-text files) calls it once for the partition's whole span, a host stream
 // calls it once per chunk of BGZF members (VcfChunkStream below).
+// ---- the header's declarations as the kernels look them up (VcfCheckKind, vcf_kernels.h) --------------------------------
+struct DevTypeTable {
+  DevBuf<uint8_t> keys;
+  DevBuf<VcfTypeSlot> slots;
+  VcfTypeTable T{nullptr, nullptr, 0, CK_STR};
+  void build(const std::vector<std::pair<std::string, uint32_t>>& ents) {
+    T = VcfTypeTable{nullptr, nullptr, 0, CK_STR};
+    if (ents.empty()) return;
+    uint32_t cap = 8;
+    while (cap < 2 * ents.size()) cap *= 2;
+    std::vector<VcfTypeSlot> h(cap, VcfTypeSlot{0, 0});
+    std::string blob;
+    for (auto& e : ents) {
+      uint32_t i = vcf_key_hash((const uint8_t*)e.first.data(), (uint32_t)e.first.size()) & (cap - 1);
+      bool dup = false;
+      for (; h[i].len_kind; i = (i + 1) & (cap - 1))
+        if ((h[i].len_kind & 0xFFFFFFu) == e.first.size() && blob.compare(h[i].off, e.first.size(), e.first) == 0) { dup = true; break; }
+      if (dup) continue;   // (the first declaration of an id counts)
+      h[i] = VcfTypeSlot{(uint32_t)blob.size(), (uint32_t)e.first.size() | ((e.second + 1u) << 24)};
+      blob += e.first;
+    }
+    keys.alloc(blob.size() + 1);
+    slots.alloc(cap);
+    HIP_CHECK(hipMemcpy(keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(slots.p, h.data(), cap * sizeof(VcfTypeSlot), hipMemcpyHostToDevice));
+    T = VcfTypeTable{keys.p, slots.p, cap - 1, CK_STR};
+  }
+};
+static uint32_t scalar_check_kind(const std::string& type) {
+  return type == "Integer" ? CK_INT : type == "Float" ? CK_FLOAT : type == "Character" ? CK_CHAR : type == "Flag" ? CK_FLAG : CK_STR;
+}
+// INFO: `builders` = the keys load_infos_single_pass has a builder for (every INFO field of the table, projected or not)
+static uint32_t info_check_kind(const VcfFieldDefn& d, bool has_builder) {
+  if (d.type == "Flag") return CK_FLAG;
+  if (d.type == "Character" && has_builder) return CK_UNSUPPORTED;
+  if (d.number == "1") return scalar_check_kind(d.type);
+  return has_builder ? (CK_LIST | scalar_check_kind(d.type)) : CK_NONE;
+}
+static uint32_t format_check_kind(const VcfFieldDefn& d, bool has_builder) {
+  if (d.id == "GT") return has_builder ? CK_GT : CK_NONE;
+  const uint32_t sc = d.type == "Integer" ? CK_INT : d.type == "Float" ? CK_FLOAT : d.type == "Character" ? CK_CHAR : CK_STR;
+  if (d.number == "1") return sc;
+  return has_builder ? (CK_LIST | (sc == CK_CHAR ? (uint32_t)CK_STR : sc)) : CK_NONE;
+}
+
 struct VcfRun {
   const VcfPlan& plan;
   VcfProvider& p;
@@ -590,6 +637,8 @@ struct VcfRun {
   DevBuf<uint8_t> d_blob;
   DevBuf<VcfFilterTerm> d_terms;
   DevBuf<uint32_t> err;               // error word + the queue of float cells to be rounded exactly (vcf_kernels.h)
+  DevTypeTable tt_end, tt_info, tt_format;   // INFO as `Info::get` types it / as load_infos_single_pass does / FORMAT
+  int need_end = 0;                   // launch_vcf_keys' argument
   uint64_t rows_left = ~0ull;         // what the plan's limit still allows
 
   VcfRun(const VcfPlan& pl, int32_t partition, int32_t batch_size_in) : plan(pl), p(*pl.prov), sch(pl.prov->sch) {
@@ -676,6 +725,7 @@ struct VcfRun {
     st = stream;
     err.alloc(VCF_ERR_DWORDS);
     HIP_CHECK(hipMemsetAsync(err.p, 0, 16, st));
+    build_type_tables();
     if (!plan.indexed) return;
     std::string blob;
     for (auto& f : plan.residual) {
@@ -771,10 +821,33 @@ struct VcfRun {
       li.first_open = lastnl + 1;
     }
   }
+  // (called once the run's device is current)
+  void build_type_tables() {
+    auto in = [](const std::vector<std::string>& v, const std::string& k) { return std::find(v.begin(), v.end(), k) != v.end(); };
+    std::vector<std::pair<std::string, uint32_t>> e_end, e_info, e_fmt;
+    uint32_t end_kind = CK_STR;
+    bool seen_end = false;
+    for (auto& d : p.hdr.infos) {
+      e_end.emplace_back(d.id, info_check_kind(d, false));
+      e_info.emplace_back(d.id, info_check_kind(d, in(sch.info_fields, d.id)));
+      if (d.id == "END" && !seen_end) { seen_end = true; end_kind = info_check_kind(d, false); }
+    }
+    bool seen_gt = false;
+    for (auto& d : p.hdr.formats) {
+      e_fmt.emplace_back(d.id, format_check_kind(d, sch.has_format && in(sch.format_fields, d.id)));
+      seen_gt |= d.id == "GT";
+    }
+    if (!seen_gt) {   // a genotype is a genotype whatever the header says
+      VcfFieldDefn gt; gt.id = "GT"; gt.number = "1"; gt.type = "String";
+      e_fmt.emplace_back(gt.id, format_check_kind(gt, sch.has_format && in(sch.format_fields, gt.id)));
+    }
+    tt_end.build(e_end); tt_info.build(e_info); tt_format.build(e_fmt);
+    need_end = want_end ? (int)(1u + end_kind) | (plan.indexed ? 0x100 : 0) : 0;
+  }
   void line_keys(const TextSpan& t, LineIndex& li) {
     const VcfLines& L = li.L;
     li.k_pos.alloc(L.n_lines + 1); li.k_vend.alloc(L.n_lines + 1); li.k_flags.alloc(L.n_lines + 1);
-    launch_vcf_keys(t.u, L, li.k_pos.p, li.k_vend.p, li.k_flags.p, want_end ? 1 : 0, err.p, st);
+    launch_vcf_keys(t.u, L, li.k_pos.p, li.k_vend.p, li.k_flags.p, need_end, tt_end.T, err.p, st);
   }
   void check_err() {
     uint32_t e = 0;
@@ -932,16 +1005,24 @@ struct VcfRun {
       if (!info_cols.empty()) {
         std::string blob;
         std::vector<uint32_t> koff{0};
-        for (auto& ic : info_cols) { blob += sch.info_fields[ic.second]; koff.push_back((uint32_t)blob.size()); }
+        std::vector<uint8_t> unsupported;   // Character keys: noodles hands a Value::Character, which has no builder (:632-636)
+        for (auto& ic : info_cols) {
+          const std::string& tag = sch.info_fields[ic.second];
+          blob += tag;
+          koff.push_back((uint32_t)blob.size());
+          const VcfFieldDefn* d = p.hdr.info(tag);
+          unsupported.push_back(d && d->type == "Character" ? 1 : 0);
+        }
         const int K = (int)info_cols.size();
-        DevBuf<uint8_t> d_keys(blob.size() + 1);
+        DevBuf<uint8_t> d_keys(blob.size() + 1), d_unsup(unsupported.size());
         DevBuf<uint32_t> d_koff(koff.size());
         HIP_CHECK(hipMemcpyAsync(d_keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(d_koff.p, koff.data(), koff.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(d_unsup.p, unsupported.data(), unsupported.size(), hipMemcpyHostToDevice, st));
         DevBuf<uint64_t> sp_off((uint64_t)K * n);
         DevBuf<uint32_t> sp_len((uint64_t)K * n);
         DevBuf<uint8_t> sp_state((uint64_t)K * n);
-        launch_vcf_info_locate(u, L, rows.p, n, d_keys.p, d_koff.p, K, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+        launch_vcf_info_locate(u, L, rows.p, n, d_keys.p, d_koff.p, d_unsup.p, K, tt_info.T, sp_off.p, sp_len.p, sp_state.p, err.p, st);
         for (int k = 0; k < K; k++) {
           VNode& nd = res->cols[info_cols[k].first];
           build_from_spans(cx, nd, sp_off.p + (uint64_t)k * n, sp_len.p + (uint64_t)k * n, sp_state.p + (uint64_t)k * n, n);
@@ -957,9 +1038,12 @@ struct VcfRun {
         std::string blob;
         std::vector<uint32_t> koff{0};
         int gt_field = -1;
+        uint32_t char_mask = 0;   // selected Character scalars: one character, or the record is an error
         for (int s = 0; s < S; s++) {
           const std::string& tag = sch.format_fields[sel[s]];
           if (tag == "GT") gt_field = s;
+          const VcfFieldDefn* d = p.hdr.format(tag);
+          if (s < 32 && tag != "GT" && d && d->type == "Character" && d->number == "1") char_mask |= 1u << s;
           blob += tag;
           koff.push_back((uint32_t)blob.size());
         }
@@ -973,7 +1057,8 @@ struct VcfRun {
         DevBuf<int32_t> d_scol(ns);
         HIP_CHECK(hipMemcpyAsync(d_scol.p, scol.data(), ns * 4, hipMemcpyHostToDevice, st));
         DevBuf<int16_t> fpos(n * (uint64_t)S);
-        launch_vcf_format_keys(u, L, rows.p, n, d_keys.p, d_koff.p, S, fpos.p, st);
+        DevBuf<uint64_t> cmap(std::max<uint64_t>(n, 1));
+        launch_vcf_format_keys(u, L, rows.p, n, d_keys.p, d_koff.p, S, tt_format.T, char_mask, fpos.p, cmap.p, err.p, st);
         const uint64_t N = n * ns;
         DevBuf<uint64_t> sp_off((uint64_t)S * N);
         DevBuf<uint32_t> sp_len((uint64_t)S * N);
@@ -1029,8 +1114,19 @@ struct VcfRun {
           cx.arrow_bytes += N * 4 + nwN * 8;
         }
         launch_vcf_format_cells(u, L, rows.p, n, d_scol.p, (int)ns, fpos.p, S, gt_field, D, sp_off.p, sp_len.p, sp_state.p, err.p, st);
+        // err[2]: GT cells with leading zeros in an allele (sized for the re-rendered genotype, written below); err[3]: values of
+        // keys without a column in this scan, typed by the header all the same
+        uint32_t after_cells[2] = {0, 0};
+        HIP_CHECK(hipMemcpyAsync(after_cells, err.p + 2, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (after_cells[0] || after_cells[1]) HIP_CHECK(hipMemsetAsync(err.p + 2, 0, 8, st));
+        if (after_cells[1]) launch_vcf_format_check(u, L, rows.p, n, d_scol.p, (int)ns, cmap.p, tt_format.T, err.p, st);
         for (int s = 0; s < S; s++) {
-          if (s < VCF_MAX_DIRECT && D.kind[s] == 3) { finish_utf8(cx, *leaf[s], gt_src.p, gt_len.p, N); continue; }
+          if (s < VCF_MAX_DIRECT && D.kind[s] == 3) {
+            finish_utf8(cx, *leaf[s], gt_src.p, gt_len.p, N);
+            if (after_cells[0]) launch_gt_render(u, gt_src.p, leaf[s]->d_off.p, leaf[s]->d_values.p, N, st);
+            continue;
+          }
           if (s < VCF_MAX_DIRECT && D.kind[s] != 0) continue;
           build_from_spans(cx, *leaf[s], sp_off.p + (uint64_t)s * N, sp_len.p + (uint64_t)s * N, sp_state.p + (uint64_t)s * N, N);
         }

@@ -10,8 +10,34 @@ namespace bioscan {
 enum VcfDevError : uint32_t {
   VERR_NONE = 0, VERR_BLANK_LINE = 1, VERR_SHORT_RECORD = 2, VERR_BAD_POS = 3, VERR_MISSING_START = 4, VERR_BAD_END = 5,
   VERR_BAD_QUAL = 6, VERR_FLOAT_PRECISION = 7, VERR_DUP_INFO_KEY = 8, VERR_BAD_INT = 9, VERR_BAD_FLOAT = 10,
-  VERR_INVALID_FLAG = 11, VERR_PERCENT = 12, VERR_BAD_GT = 13
+  VERR_INVALID_FLAG = 11, VERR_PERCENT = 12, VERR_BAD_GT = 13, VERR_BAD_CHAR = 14, VERR_UNSUPPORTED_INFO = 15
 };
+
+// ---- header types of INFO / FORMAT keys ------------------------------------------------------------------------
+// noodles types every entry of INFO (`info.iter(header)`, physical_exec.rs:561-571) and every value of a selected sample
+// (`sample.iter(header)`, :1661-1666) by the header as it walks them, whether or not the scan has a column for the key: a scalar
+// that does not parse is the record's error.  Lists and genotypes stay lazy and are only walked for keys the table has a builder
+// for (:572-611, :1668-1760).  The kernels therefore look every key they do NOT extract up in a table of the header's
+// declarations and check its value the same way.
+enum VcfCheckKind : uint32_t {
+  CK_NONE = 0,         // nothing to check (a lazy list / genotype of a key without a builder)
+  CK_INT = 1, CK_FLOAT = 2, CK_STR = 3, CK_FLAG = 4, CK_CHAR = 5,
+  CK_UNSUPPORTED = 6,  // INFO Character key with a builder: any value is "Unsupported INFO value type" (:632-636)
+  CK_GT = 7,           // genotype of a key with a builder
+  CK_LIST = 8          // bit: a list whose elements (of the scalar kind in the low bits) are walked
+};
+struct VcfTypeSlot { uint32_t off, len_kind; };  // key bytes at keys + off; len_kind = length | (kind + 1) << 24; 0 = empty slot
+struct VcfTypeTable {
+  const uint8_t* keys;
+  const VcfTypeSlot* slots;   // open addressing, linear probing, mask + 1 slots (a power of two, at most half full)
+  uint32_t mask;
+  uint32_t miss_kind;         // a key the header does not declare: String, Number=1 (noodles' default)
+};
+__host__ __device__ inline uint32_t vcf_key_hash(const uint8_t* k, uint32_t n) {   // FNV-1a
+  uint32_t h = 2166136261u;
+  for (uint32_t i = 0; i < n; i++) h = (h ^ k[i]) * 16777619u;
+  return h;
+}
 
 // delimiter index over u[lo, hi): positions of '\n' and '\t', and for each newline the number of tabs before it
 uint64_t vcf_delim_chunks(uint64_t lo, uint64_t hi);
@@ -27,8 +53,11 @@ struct VcfLines {
   uint64_t x0, hi;          // first line start, end of the decoded bytes
   uint64_t n_lines;         // n_nl (+1 for an unterminated last line at the end of the data)
 };
-void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, uint32_t* err,
-                     hipStream_t st);
+// need_end: 0 no END wanted; else 1 + the check kind of the key END (CK_INT: its value is the end; anything else: checked
+// like any other entry, the end stays POS + len(REF) - 1), | 0x100 when single-base substitutions are walked too (indexed
+// scans).  T: the INFO declarations as `Info::get` sees them -- no key has a builder -- (entries in front of END are typed).
+void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, VcfTypeTable T,
+                     uint32_t* err, hipStream_t st);
 
 struct VcfFilterTerm {
   int32_t field;     // 0 chrom, 1 start, 2 end, 3 id
@@ -71,8 +100,11 @@ void launch_vcf_core(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_
                      const uint8_t* flags, VcfCoreCols C, int zero_based, uint32_t* err, hipStream_t st);
 void launch_replace_byte(uint8_t* d, uint64_t n, uint8_t from, uint8_t to, hipStream_t st);
 
+// key_unsupported[k] != 0: selected key k is a Character key (a value is an error).  T: the INFO declarations, for every
+// entry whose key is not one of the K selected ones.
 void launch_vcf_info_locate(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
-                            int K, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state, uint32_t* err, hipStream_t st);
+                            const uint8_t* key_unsupported, int K, VcfTypeTable T, uint64_t* sp_off, uint32_t* sp_len,
+                            uint8_t* sp_state, uint32_t* err, hipStream_t st);
 
 // typed span kernels: span c = u[off[c], off[c]+len[c]) with state[c] (0 absent, 1 value, 2 bare key)
 void launch_span_num(const uint8_t* u, const uint64_t* off, const uint32_t* len, const uint8_t* state, uint64_t N, int kind,
@@ -91,8 +123,14 @@ void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_
 void launch_pack_bits(const uint8_t* bytes, uint64_t n, uint64_t* words, hipStream_t st);
 void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st);
 
+// cmap[r]: nibble j < 15 = check kind (low 3 bits; bit 3 = list) of the row's FORMAT key j when that key is NOT one of the S
+// selected ones (a selected key: CK_CHAR when char_mask has its bit -- a Character scalar, extracted as a string --, else 0);
+// nibble 15 != 0: the row has more keys than that.  err[3] is raised when some cmap of the chunk is not 0: only then
+// launch_vcf_format_check has anything to do.
 void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
-                            int S, int16_t* fpos, hipStream_t st);
+                            int S, VcfTypeTable T, uint32_t char_mask, int16_t* fpos, uint64_t* cmap, uint32_t* err, hipStream_t st);
+void launch_vcf_format_check(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
+                             const uint64_t* cmap, VcfTypeTable T, uint32_t* err, hipStream_t st);
 // FORMAT keys parsed inside the cell kernel: kind 1 Int32 / 2 Float32 -> values[s][c] + validity words valid[s];
 // kind 3 GT -> values[s][c] = rendered length, src[s][c] = its first byte (offset into u) + validity; kind 0 = emit
 // a span for the typed span kernels (other strings, lists).  Only the first VCF_MAX_DIRECT selected keys can be direct.
@@ -104,11 +142,13 @@ struct VcfCellDirect {
   uint64_t* src[VCF_MAX_DIRECT];
 };
 // The error word of a scan is followed by a queue of float cells whose rounding the parsing kernels could not prove:
-// err[0] error code, err[1] number of queued cells, entries from err + 4.  launch_f32_fix rewrites them exactly.
+// err[0] error code, err[1] number of queued cells, err[2] "a GT cell has to be rendered again" (launch_gt_render), err[3] "a FORMAT
+// value is checked without being extracted" (launch_vcf_format_check), entries from err + 4.  launch_f32_fix rewrites them exactly.
 struct F32Fix { const uint8_t* p; void* dst; uint32_t len, as_f64, approx, pad; };
 constexpr uint32_t F32_FIX_CAP = 65536;   // 2 MB of queue per scan; more such cells in one chunk are an error
 constexpr size_t VCF_ERR_DWORDS = 4 + F32_FIX_CAP * (sizeof(F32Fix) / 4);
 void launch_f32_fix(uint32_t* err, uint32_t n_queued, hipStream_t st);
+void launch_gt_render(const uint8_t* u, const uint64_t* src, const uint64_t* off, uint8_t* values, uint64_t N, hipStream_t st);
 void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
                              const int16_t* fpos, int S, int gt_field, VcfCellDirect D, uint64_t* sp_off, uint32_t* sp_len,
                              uint8_t* sp_state, uint32_t* err, hipStream_t st);

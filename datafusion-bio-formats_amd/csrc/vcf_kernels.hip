@@ -185,16 +185,21 @@ __device__ int parse_i32_text(const uint8_t* p, uint32_t len, int32_t* out) {
   *out = (int32_t)v;
   return 0;
 }
-__device__ int parse_u32_pos(const uint8_t* p, uint32_t len, uint32_t* out) {
-  if (len == 0) return 1;
+// POS: noodles parses a usize (an error beyond 2^64 - 1) and the reference casts it (`get() as u32`,
+// bio-format-vcf/src/physical_exec.rs:762, 2875): a position that does not fit wraps.  *wide: the value needed more than 32 bits.
+__device__ int parse_u32_pos(const uint8_t* p, uint32_t len, uint32_t* out, bool* wide, bool* zero) {
+  uint32_t i = (len && p[0] == '+') ? 1u : 0u;   // (usize::from_str takes a leading '+')
+  if (i >= len) return 1;
   uint64_t v = 0;
-  for (uint32_t i = 0; i < len; i++) {
+  for (; i < len; i++) {
     const uint32_t d = (uint32_t)p[i] - '0';
     if (d > 9) return 1;
+    if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10ull) return 1;
     v = v * 10 + d;
-    if (v > 0xFFFFFFFFull) return 1;
   }
   *out = (uint32_t)v;
+  *wide = v > 0xFFFFFFFFull;
+  *zero = v == 0;
   return 0;
 }
 
@@ -489,12 +494,95 @@ __device__ uint32_t pct_decoded_len(const uint8_t* p, uint32_t l, bool* pct, uin
   return out;
 }
 
+// ---- values of keys the scan has no column for ---------------------------------------------------------------------
+__device__ uint32_t type_lookup(const VcfTypeTable& T, const uint8_t* k, uint32_t kl) {
+  if (T.slots == nullptr) return T.miss_kind;
+  for (uint32_t h = vcf_key_hash(k, kl) & T.mask;; h = (h + 1) & T.mask) {
+    const VcfTypeSlot sl = T.slots[h];
+    if (sl.len_kind == 0) return T.miss_kind;
+    if ((sl.len_kind & 0xFFFFFFu) == kl) {
+      const uint8_t* q = T.keys + sl.off;
+      bool eq = true;
+      for (uint32_t i = 0; i < kl && eq; i++) eq = q[i] == k[i];
+      if (eq) return (sl.len_kind >> 24) - 1u;
+    }
+  }
+}
+// genotype text as noodles walks it: an optional leading phasing mark, then alleles ('.' or digits) joined by '/' or '|'
+__device__ bool gt_text_ok(const uint8_t* p, uint32_t l) {
+  uint32_t k = (l && (p[0] == '/' || p[0] == '|')) ? 1u : 0u;
+  if (k >= l) return false;
+  uint32_t tl = 0;
+  bool isdot = false;
+  for (; k < l; k++) {
+    const uint32_t ch = p[k];
+    if (ch == '/' || ch == '|') { if (tl == 0) return false; tl = 0; isdot = false; }
+    else if (ch == '.') { if (tl) return false; isdot = true; tl = 1; }
+    else if (ch - '0' <= 9u) { if (isdot) return false; tl++; }
+    else return false;
+  }
+  return tl != 0;
+}
+__device__ void check_scalar(uint32_t kind, const uint8_t* p, uint32_t l, uint32_t* err) {
+  switch (kind) {
+    case CK_INT: { int32_t v; if (parse_i32_text(p, l, &v)) set_err(err, VERR_BAD_INT); break; }
+    case CK_FLOAT: { float f; if (parse_f32_text(p, l, &f) == 1) set_err(err, VERR_BAD_FLOAT); break; }
+    case CK_STR: {
+      bool esc = false;
+      for (uint32_t k = 0; k < l; k++) esc |= p[k] == '%';
+      if (esc) pct_decoded_len(p, l, &esc, err);
+      break;
+    }
+    case CK_CHAR: {   // one character (the text is UTF-8: one byte that is not a continuation byte)
+      uint32_t nc = 0;
+      for (uint32_t k = 0; k < l; k++) nc += (p[k] & 0xC0u) != 0x80u;
+      if (nc != 1) set_err(err, VERR_BAD_CHAR);
+      break;
+    }
+    default: break;
+  }
+}
+// the value [p, p+l) of a key nothing is extracted for (not "." -- the caller has looked); kind from type_lookup
+__device__ __noinline__ void check_value(uint32_t kind, const uint8_t* p, uint32_t l, uint32_t* err) {
+  if (kind == CK_NONE) return;
+  if (kind == CK_FLAG) { set_err(err, VERR_INVALID_FLAG); return; }
+  if ((kind & 7u) == CK_UNSUPPORTED) { set_err(err, VERR_UNSUPPORTED_INFO); return; }
+  if (kind == CK_GT) { if (!gt_text_ok(p, l)) set_err(err, VERR_BAD_GT); return; }
+  if (!(kind & CK_LIST)) { check_scalar(kind, p, l, err); return; }
+  uint32_t a = 0;
+  for (uint32_t k = 0; k <= l; k++) {
+    if (k == l || p[k] == ',') {
+      if (!(k - a == 1 && p[a] == '.')) check_scalar(kind & 7u, p + a, k - a, err);
+      a = k + 1;
+    }
+  }
+}
+// The entries of an INFO field u[a, b) in file order: f(q, eq, e) for the entry [q, e) whose first '=' is at eq (~0 = a bare key);
+// f returns true to stop.  The delimiters are taken eight bytes at a time.
+template <typename F>
+__device__ __forceinline__ void info_entries(const uint8_t* __restrict__ u, uint64_t a, uint64_t b, F f) {
+  uint64_t q = a, eqp = ~0ull;
+  for (uint64_t w0 = a; w0 < b; w0 += 8) {
+    const uint64_t w = ((const dl_u64*)(u + w0))->v;  // reads past b stay inside the buffer slack
+    uint64_t m = eq_mask8(w, 0x3B3B3B3B3B3B3B3Bull) | eq_mask8(w, 0x3D3D3D3D3D3D3D3Dull);
+    while (m) {
+      const int bit = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint64_t pq = w0 + (uint64_t)(bit >> 3);
+      if (pq >= b) break;
+      if (((w >> (bit - 7)) & 0xFF) == ';') { if (f(q, eqp, pq)) return; q = pq + 1; eqp = ~0ull; }
+      else if (eqp == ~0ull) eqp = pq;
+    }
+  }
+  if (q < b) f(q, eqp, b);
+}
+
 // ---- line keys ----------------------------------------------------------------------------------------------
 // pos = POS; vend = noodles variant_end (INFO END, else POS + len(REF) - 1); flags bit0 = single-base ACGT SNV
-// (get_variant_end's fast path, physical_exec.rs:646-667), bit1 = blank line.
+// (get_variant_end's fast path, physical_exec.rs:646-667), bit1 = blank line, bit2 = POS needs more than 32 bits.
 __global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u, VcfLines L, uint32_t* __restrict__ pos,
                                                    uint32_t* __restrict__ vend, uint8_t* __restrict__ flags, int need_end,
-                                                   uint32_t* __restrict__ err) {
+                                                   VcfTypeTable T, uint32_t* __restrict__ err) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= L.n_lines) return;
   uint64_t a, b;
@@ -505,8 +593,9 @@ __global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u,
   if (line_te(L, i) - line_tb(L, i) < 7) { set_err(err, VERR_SHORT_RECORD); flags[i] = 2; return; }
   field_span(L, u, i, 1, &a, &b);
   uint32_t p = 0;
-  if (parse_u32_pos(u + a, (uint32_t)(b - a), &p)) { set_err(err, VERR_BAD_POS); p = 0; }
-  if (p == 0) set_err(err, VERR_MISSING_START);
+  bool wide = false, zero = false;
+  if (parse_u32_pos(u + a, (uint32_t)(b - a), &p, &wide, &zero)) { set_err(err, VERR_BAD_POS); p = 0; }
+  else if (zero) set_err(err, VERR_MISSING_START);
   pos[i] = p;
   uint64_t ra, rb, aa, ab;
   field_span(L, u, i, 3, &ra, &rb);
@@ -519,41 +608,40 @@ __global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u,
     const bool aok = al == 'A' || al == 'C' || al == 'G' || al == 'T';
     if (rok && aok) fl = 1;
   }
+  if (wide) fl |= 4;   // bit2: POS >= 2^32 (pos / vend hold the wrapped values the reference's columns show)
   flags[i] = fl;
   uint32_t ve = p + rl - 1;
-  if (need_end) {
+  // noodles' variant_end = `info.get(header, "END")`: the entries are walked and typed one after the other up to the first END;
+  // get_variant_end does not ask for it when the record is a single-base ACGT substitution (physical_exec.rs:646-667)
+  // (need_end bit 8: an indexed scan -- noodles' query asks every record for its variant_end to test the overlap)
+  if (need_end && (!(fl & 1) || (need_end & 0x100))) {
     uint64_t ia, ib;
     field_span(L, u, i, 7, &ia, &ib);
-    // entry starts = the field start and every byte after a ';': the ';' are found eight bytes at a time, only the
-    // four bytes at an entry start are compared with "END="
-    const uint32_t END_EQ = 0x3D444E45u;  // "END=" little endian
-    uint64_t hit = ~0ull;
-    if (ia + 4 <= ib && ((const dl_u32*)(u + ia))->v == END_EQ) hit = ia;
-    for (uint64_t q = ia; hit == ~0ull && q < ib; q += 8) {
-      uint64_t m = eq_mask8(((const dl_u64*)(u + q))->v, 0x3B3B3B3B3B3B3B3Bull);  // ';' (reads past ib stay inside the buffer slack)
-      while (m) {
-        const uint64_t pq = q + (uint64_t)(__builtin_ctzll(m) >> 3) + 1;
-        m &= m - 1;
-        if (pq + 4 <= ib && ((const dl_u32*)(u + pq))->v == END_EQ) { hit = pq; break; }
-      }
-    }
-    if (hit != ~0ull) {
-      const uint64_t v0 = hit + 4;
-      uint64_t v1 = v0;
-      while (v1 < ib && u[v1] != ';') v1++;
-      int32_t ev;
-      if (!(v1 - v0 == 1 && u[v0] == '.')) {
-        if (parse_i32_text(u + v0, (uint32_t)(v1 - v0), &ev) || ev <= 0) set_err(err, VERR_BAD_END);
-        else ve = (uint32_t)ev;
-      }
+    if (!(ib - ia == 1 && u[ia] == '.')) {
+      const uint32_t end_kind = ((uint32_t)need_end & 0xFFu) - 1u;
+      info_entries(u, ia, ib, [&](uint64_t q, uint64_t eqp, uint64_t e) -> bool {
+        if (e == q) return false;                       // empty entry (";;")
+        if (eqp == ~0ull) return e - q == 3 && u[q] == 'E' && u[q + 1] == 'N' && u[q + 2] == 'D';   // bare key: nothing to type
+        const uint32_t kl = (uint32_t)(eqp - q), vl = (uint32_t)(e - eqp - 1);
+        const uint8_t* v = u + eqp + 1;
+        const bool is_end = kl == 3 && u[q] == 'E' && u[q + 1] == 'N' && u[q + 2] == 'D';
+        if (!(vl == 1 && v[0] == '.')) {
+          if (is_end && end_kind == CK_INT) {
+            int32_t ev;
+            if (parse_i32_text(v, vl, &ev) || ev <= 0) set_err(err, VERR_BAD_END);
+            else ve = (uint32_t)ev;
+          } else check_value(is_end ? end_kind : type_lookup(T, u + q, kl), v, vl, err);
+        }
+        return is_end;
+      });
     }
   }
   vend[i] = ve;
 }
-void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, uint32_t* err,
-                     hipStream_t st) {
+void launch_vcf_keys(const uint8_t* u, VcfLines L, uint32_t* pos, uint32_t* vend, uint8_t* flags, int need_end, VcfTypeTable T,
+                     uint32_t* err, hipStream_t st) {
   if (!L.n_lines) return;
-  hipLaunchKernelGGL(k_vcf_keys, dim3((uint32_t)((L.n_lines + 255) / 256)), dim3(256), 0, st, u, L, pos, vend, flags, need_end, err);
+  hipLaunchKernelGGL(k_vcf_keys, dim3((uint32_t)((L.n_lines + 255) / 256)), dim3(256), 0, st, u, L, pos, vend, flags, need_end, T, err);
 }
 
 // ---- row selection ------------------------------------------------------------------------------------------
@@ -630,7 +718,9 @@ __global__ __launch_bounds__(256) void k_vcf_row_flags(const uint8_t* __restrict
     const uint32_t p = pos[i];
     if (S.mode == 1) {
       if (!bytes_eq(u + ca, (uint32_t)(cb - ca), strs + S.chrom_off, S.chrom_len)) break;
-      if (!((int64_t)p <= S.q_end1 && (int64_t)vend[i] >= S.q_start1)) break;   // noodles intersects()
+      // noodles intersects() on the positions as parsed: a POS beyond 2^32 lies behind every bounded interval
+      if (flags[i] & 4) { if (S.end1 > 0) break; }
+      else if (!((int64_t)p <= S.q_end1 && (int64_t)vend[i] >= S.q_start1)) break;
       if (S.start1 > 0 && (int64_t)p < S.start1) break;                           // physical_exec.rs:2886-2895
       if (S.end1 > 0 && (int64_t)p > S.end1) break;
     }
@@ -759,7 +849,8 @@ void launch_replace_byte(uint8_t* d, uint64_t n, uint8_t from, uint8_t to, hipSt
 // would append twice and misalign the column).
 __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
                                                           uint64_t n, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
-                                                          int K, uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
+                                                          const uint8_t* __restrict__ key_unsupported, int K, VcfTypeTable T,
+                                                          uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
                                                           uint8_t* __restrict__ sp_state, uint32_t* __restrict__ err) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
@@ -768,47 +859,36 @@ __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restri
   uint64_t a, b;
   field_span(L, u, i, 7, &a, &b);
   if (b - a == 1 && u[a] == '.') return;
-  // delimiter events (';' and '=') are taken eight bytes at a time; an entry is [q, next ';'), its key ends at the
-  // first '=' inside it
-  uint64_t q = a;        // current entry start
-  uint64_t eqp = ~0ull;  // first '=' of the current entry
-  auto finish = [&](uint64_t ve) {
+  info_entries(u, a, b, [&](uint64_t q, uint64_t eqp, uint64_t ve) -> bool {
+    if (ve == q) return false;   // empty entry
     const bool has_val = eqp != ~0ull;
     const uint64_t ke = has_val ? eqp : ve;
     const uint32_t kl = (uint32_t)(ke - q);
-    if (kl) {
-      for (int k = 0; k < K; k++) {
-        const uint32_t ko = key_off[k], kn = key_off[k + 1] - ko;
-        if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) {
-          const uint64_t o = (uint64_t)k * n + r;
-          if (sp_state[o]) set_err(err, VERR_DUP_INFO_KEY);
-          sp_state[o] = has_val ? 1 : 2;
-          sp_off[o] = has_val ? ke + 1 : ke;
-          sp_len[o] = has_val ? (uint32_t)(ve - ke - 1) : 0;
-          break;
-        }
+    const uint32_t vl = has_val ? (uint32_t)(ve - ke - 1) : 0u;
+    const bool value = has_val && !(vl == 1 && u[ke + 1] == '.');
+    for (int k = 0; kl && k < K; k++) {
+      const uint32_t ko = key_off[k], kn = key_off[k + 1] - ko;
+      if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) {
+        const uint64_t o = (uint64_t)k * n + r;
+        if (sp_state[o]) set_err(err, VERR_DUP_INFO_KEY);
+        if (value && key_unsupported[k]) set_err(err, VERR_UNSUPPORTED_INFO);
+        sp_state[o] = has_val ? 1 : 2;
+        sp_off[o] = has_val ? ke + 1 : ke;
+        sp_len[o] = vl;
+        return false;
       }
     }
-  };
-  for (uint64_t w0 = a; w0 < b; w0 += 8) {
-    const uint64_t w = ((const dl_u64*)(u + w0))->v;  // reads past b stay inside the buffer slack
-    uint64_t m = eq_mask8(w, 0x3B3B3B3B3B3B3B3Bull) | eq_mask8(w, 0x3D3D3D3D3D3D3D3Dull);
-    while (m) {
-      const int bit = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint64_t pq = w0 + (uint64_t)(bit >> 3);
-      if (pq >= b) break;
-      if (((w >> (bit - 7)) & 0xFF) == ';') { finish(pq); q = pq + 1; eqp = ~0ull; }
-      else if (eqp == ~0ull) eqp = pq;
-    }
-  }
-  if (q < b) finish(b);
+    // no column for this key: typed by the header all the same (see VcfCheckKind)
+    if (value) check_value(type_lookup(T, u + q, kl), u + ke + 1, vl, err);
+    return false;
+  });
 }
 void launch_vcf_info_locate(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
-                            int K, uint64_t* sp_off, uint32_t* sp_len, uint8_t* sp_state, uint32_t* err, hipStream_t st) {
+                            const uint8_t* key_unsupported, int K, VcfTypeTable T, uint64_t* sp_off, uint32_t* sp_len,
+                            uint8_t* sp_state, uint32_t* err, hipStream_t st) {
   if (!n || !K) return;
-  hipLaunchKernelGGL(k_vcf_info_locate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off, K, sp_off,
-                     sp_len, sp_state, err);
+  hipLaunchKernelGGL(k_vcf_info_locate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off,
+                     key_unsupported, K, T, sp_off, sp_len, sp_state, err);
 }
 
 // ---- typed span kernels (shared by INFO and FORMAT cells) -----------------------------------------------------
@@ -1021,31 +1101,93 @@ void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream
 // fpos[r*S + s] = index of selected FORMAT key s among the ':'-separated keys of row r's FORMAT column (-1 absent)
 __global__ __launch_bounds__(256) void k_vcf_format_keys(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
                                                           uint64_t n, const uint8_t* __restrict__ keys, const uint32_t* __restrict__ key_off,
-                                                          int S, int16_t* __restrict__ fpos) {
+                                                          int S, VcfTypeTable T, uint32_t char_mask, int16_t* __restrict__ fpos,
+                                                          uint64_t* __restrict__ cmap, uint32_t* __restrict__ err) {
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   for (int s = 0; s < S; s++) fpos[r * S + s] = -1;
+  cmap[r] = 0;
   uint64_t a, b;
   if (!field_span(L, u, rows[r], 8, &a, &b)) return;
   if (b == a || (b - a == 1 && u[a] == '.')) return;
   int j = 0;
-  uint64_t q = a;
+  uint64_t q = a, cm = 0;
   while (q <= b) {
     uint64_t e = q;
     while (e < b && u[e] != ':') e++;
     const uint32_t kl = (uint32_t)(e - q);
+    uint32_t ck = ~0u;
     for (int s = 0; s < S; s++) {
       const uint32_t ko = key_off[s], kn = key_off[s + 1] - ko;
-      if (kn == kl && fpos[r * S + s] < 0 && bytes_eq(u + q, kl, keys + ko, kn)) fpos[r * S + s] = (int16_t)j;
+      if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) {
+        // extracted (and typed) by the cell kernel; a selected Character scalar is a string there and still has to be one character
+        ck = (s < 32 && ((char_mask >> s) & 1u)) ? (uint32_t)CK_CHAR : (uint32_t)CK_NONE;
+        if (fpos[r * S + s] < 0) fpos[r * S + s] = (int16_t)j;
+      }
     }
+    if (j < 15) {
+      if (ck == ~0u) ck = type_lookup(T, u + q, kl) & 15u;
+      cm |= (uint64_t)ck << (4 * j);
+    } else cm |= 15ull << 60;   // more keys than the map holds: k_vcf_format_check looks those up itself
     j++;
     q = e + 1;
   }
+  cmap[r] = cm;
+  if (cm) err[3] = 1u;   // some value of this chunk is checked without being extracted: k_vcf_format_check has to run
+}
+// check kind of the row's FORMAT key j (for the rows with more keys than a cmap holds; a selected key is then checked a
+// second time, with the same outcome as its extraction)
+__device__ __noinline__ uint32_t format_key_kind(const uint8_t* __restrict__ u, const VcfLines& L, uint64_t line, int j, const VcfTypeTable& T) {
+  uint64_t a, b;
+  if (!field_span(L, u, line, 8, &a, &b)) return CK_NONE;
+  uint64_t q = a;
+  for (int k = 0; q <= b; k++) {
+    uint64_t e = q;
+    while (e < b && u[e] != ':') e++;
+    if (k == j) return type_lookup(T, u + q, (uint32_t)(e - q)) & 15u;
+    q = e + 1;
+  }
+  return CK_NONE;
 }
 void launch_vcf_format_keys(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const uint8_t* keys, const uint32_t* key_off,
-                            int S, int16_t* fpos, hipStream_t st) {
+                            int S, VcfTypeTable T, uint32_t char_mask, int16_t* fpos, uint64_t* cmap, uint32_t* err, hipStream_t st) {
   if (!n || !S) return;
-  hipLaunchKernelGGL(k_vcf_format_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off, S, fpos);
+  hipLaunchKernelGGL(k_vcf_format_keys, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, u, L, rows, n, keys, key_off, S, T,
+                     char_mask, fpos, cmap, err);
+}
+// The values of FORMAT keys the cell kernel does not extract, typed by the header as `sample.iter(header)` does for every value
+// of a selected sample (see VcfCheckKind).  One thread per (row, selected sample); run only when k_vcf_format_keys has found
+// such a key in the chunk (err[3]) -- a scan of all the table's FORMAT fields over a file that declares its keys never does.
+__global__ __launch_bounds__(256) void k_vcf_format_check(const uint8_t* __restrict__ u, VcfLines L, const uint64_t* __restrict__ rows,
+                                                           uint64_t n, const int32_t* __restrict__ sample_col, int NS,
+                                                           const uint64_t* __restrict__ cmap, VcfTypeTable T, uint32_t* __restrict__ err) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n * (uint64_t)NS) return;
+  const uint64_t r = c / (uint64_t)NS;
+  const uint64_t cm = cmap[r];
+  if (cm == 0) return;
+  uint64_t a, b;
+  if (!field_span(L, u, rows[r], 9 + (uint32_t)sample_col[c - r * NS], &a, &b)) return;
+  if (b == a || (b - a == 1 && u[a] == '.')) return;
+  int j = 0;
+  for (uint64_t q = a; q <= b; j++) {
+    uint64_t e = q;
+    while (e < b && u[e] != ':') e++;
+    const uint32_t ck = j < 15 ? (uint32_t)((cm >> (4 * j)) & 15ull) : format_key_kind(u, L, rows[r], j, T);
+    if (ck != CK_NONE && !(e - q == 1 && u[q] == '.')) check_value(ck, u + q, (uint32_t)(e - q), err);
+    q = e + 1;
+  }
+}
+void launch_vcf_format_check(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
+                             const uint64_t* cmap, VcfTypeTable T, uint32_t* err, hipStream_t st) {
+  const uint64_t N = n * (uint64_t)NS;
+  if (!N) return;
+  hipLaunchKernelGGL(k_vcf_format_check, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, L, rows, n, sample_col, NS, cmap, T, err);
+}
+// zeros a finished GT allele token loses when it is rendered again as an integer: all its leading zeros, but one digit stays
+__device__ __forceinline__ uint32_t gt_strip_add(bool isdot, bool still_leading, uint32_t nz, uint32_t tl) {
+  if (isdot || tl == 0) return 0u;
+  return still_leading ? tl - 1u : nz;
 }
 // One thread per (row, selected sample) cell c = r*NS + os: the ':'-separated value of each selected FORMAT
 // key -> sp_*[s*N + c] (N = n*NS).  gt_field = index of GT among the selected keys (-1 none): its span drops
@@ -1154,22 +1296,29 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
               }
             }
           } else if (ckind == 3) {    // GT as a direct string: validated, leading phasing mark dropped
-            uint32_t tl = 0;
+            // (noodles parses an allele as an integer and the reference renders it again: "01/1" comes out as "1/1" --
+            // `strip` counts the leading zeros that go; k_gt_render writes such a cell, see gt_strip_add)
+            uint32_t tl = 0, nz = 0, strip = 0;
             bool isdot = false, lead0 = false, gt_ok = true;
             for (uint32_t k = start; k < e; k++) {
               const uint32_t ch = byte_at(k);
               if (ch == '/' || ch == '|') {
-                if (k != start) { if (tl == 0 || (!isdot && lead0 && tl > 1)) gt_ok = false; tl = 0; isdot = false; lead0 = false; }
+                if (k != start) { if (tl == 0) gt_ok = false; strip += gt_strip_add(isdot, lead0, nz, tl); tl = 0; isdot = false; lead0 = false; nz = 0; }
               } else if (ch == '.') { if (tl) gt_ok = false; isdot = true; tl = 1; }
-              else if (ch >= '0' && ch <= '9') { if (isdot) gt_ok = false; if (tl == 0) lead0 = ch == '0'; tl++; }
-              else gt_ok = false;
+              else if (ch >= '0' && ch <= '9') {
+                if (isdot) gt_ok = false;
+                if (tl == 0) { lead0 = ch == '0'; nz = lead0 ? 1u : 0u; } else if (lead0) { if (ch == '0') nz++; else lead0 = false; }
+                tl++;
+              } else gt_ok = false;
             }
+            strip += gt_strip_add(isdot, lead0, nz, tl);
             uint32_t x = start;
             const uint32_t c0 = byte_at(start);
             if (c0 == '/' || c0 == '|') x++;
-            if (!gt_ok || tl == 0 || (!isdot && lead0 && tl > 1) || x >= e) set_err(err, VERR_BAD_GT);
+            if (!gt_ok || tl == 0 || x >= e) set_err(err, VERR_BAD_GT);
+            if (strip) err[2] = 1u;
 #pragma unroll
-            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = e - x; dsrc[s] = x; dok |= 1u << s; }
+            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = e - x - strip; dsrc[s] = x; dok |= 1u << s; }
           } else {                    // span for the typed span kernels (strings, lists)
             const uint64_t o = (uint64_t)cur * N + c;
             sp_state[o] = 1;
@@ -1183,7 +1332,7 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
       }
     }
     if (have && len && !fast) select();
-    uint32_t start = 0, ndig = 0, tl = 0;
+    uint32_t start = 0, ndig = 0, tl = 0, nz = 0, strip = 0;
     int64_t acc = 0;
     bool neg = false, bad = false, isdot = false, lead0 = false, gt_ok = true;
     for (uint32_t k = 0; have && !fast && k <= len; k++) {
@@ -1218,9 +1367,11 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
             uint32_t x = start;
             const uint32_t c0 = byte_at(start);
             if (c0 == '/' || c0 == '|') x++;
-            if (!gt_ok || tl == 0 || (!isdot && lead0 && tl > 1) || x >= k) set_err(err, VERR_BAD_GT);
+            strip += gt_strip_add(isdot, lead0, nz, tl);
+            if (!gt_ok || tl == 0 || x >= k) set_err(err, VERR_BAD_GT);
+            if (strip) err[2] = 1u;
 #pragma unroll
-            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = k - x; dsrc[s] = x; dok |= 1u << s; }
+            for (int s = 0; s < VCF_MAX_DIRECT; s++) if (s == cur) { dval[s] = k - x - strip; dsrc[s] = x; dok |= 1u << s; }
           } else {                    // span for the typed span kernels (strings, lists)
             const uint64_t o = (uint64_t)cur * N + c;
             sp_state[o] = 1;
@@ -1231,7 +1382,7 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
         j++;
         start = k + 1;
         if (k < len) select();
-        acc = 0; ndig = 0; neg = false; bad = false; tl = 0; isdot = false; lead0 = false; gt_ok = true;
+        acc = 0; ndig = 0; neg = false; bad = false; tl = 0; isdot = false; lead0 = false; gt_ok = true; nz = 0; strip = 0;
       } else if (cur >= 0) {
         if (ckind == 1) {
           const uint32_t dgt = ch - '0';
@@ -1240,9 +1391,13 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
           else bad = true;
         } else if (ckind == 3) {
           if (ch == '/' || ch == '|') {
-            if (k != start) { if (tl == 0 || (!isdot && lead0 && tl > 1)) gt_ok = false; tl = 0; isdot = false; lead0 = false; }
+            if (k != start) { if (tl == 0) gt_ok = false; strip += gt_strip_add(isdot, lead0, nz, tl); tl = 0; isdot = false; lead0 = false; nz = 0; }
           } else if (ch == '.') { if (tl) gt_ok = false; isdot = true; tl = 1; }
-          else if (ch >= '0' && ch <= '9') { if (isdot) gt_ok = false; if (tl == 0) lead0 = ch == '0'; tl++; }
+          else if (ch >= '0' && ch <= '9') {
+            if (isdot) gt_ok = false;
+            if (tl == 0) { lead0 = ch == '0'; nz = lead0 ? 1u : 0u; } else if (lead0) { if (ch == '0') nz++; else lead0 = false; }
+            tl++;
+          }
           else gt_ok = false;
         }
       }
@@ -1261,6 +1416,39 @@ __global__ __launch_bounds__(256, 6) void k_vcf_format_cells(const uint8_t* __re
     }
   }
 }
+// GT cells whose alleles carry leading zeros: the value of the column is the re-rendered genotype (alleles as the integers
+// noodles parsed, physical_exec.rs:1675-1694), which is not a substring of the text.  The cell kernel has sized the cell for
+// the rendered form (and raised err[2]); this kernel, run only then, writes those cells.
+__global__ __launch_bounds__(256) void k_gt_render(const uint8_t* __restrict__ u, const uint64_t* __restrict__ src, const uint64_t* __restrict__ off,
+                                                    uint8_t* __restrict__ values, uint64_t N) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const uint64_t o0 = off[i], o1 = off[i + 1];
+  if (o1 == o0) return;
+  const uint8_t* p = u + src[i];
+  // raw length of the genotype: up to the next ':' / tab / end of line
+  uint32_t raw = 0;
+  while (true) { const uint8_t c = p[raw]; if (c == ':' || c == '\t' || c == '\n' || c == '\r' || c == 0) break; raw++; }
+  if ((uint64_t)raw == o1 - o0) return;   // nothing was stripped: the scatter copied the cell
+  uint8_t* q = values + o0;
+  uint32_t k = 0;
+  while (k < raw && q < values + o1) {
+    const uint8_t c = p[k];
+    if (c >= '0' && c <= '9') {
+      uint32_t e = k;
+      while (e < raw && p[e] >= '0' && p[e] <= '9') e++;
+      uint32_t b = k;
+      while (b + 1 < e && p[b] == '0') b++;   // leading zeros go, one digit stays
+      for (; b < e && q < values + o1; b++) *q++ = p[b];
+      k = e;
+    } else { *q++ = c; k++; }
+  }
+}
+void launch_gt_render(const uint8_t* u, const uint64_t* src, const uint64_t* off, uint8_t* values, uint64_t N, hipStream_t st) {
+  if (!N) return;
+  hipLaunchKernelGGL(k_gt_render, dim3((uint32_t)((N + 255) / 256)), dim3(256), 0, st, u, src, off, values, N);
+}
+
 void launch_vcf_format_cells(const uint8_t* u, VcfLines L, const uint64_t* rows, uint64_t n, const int32_t* sample_col, int NS,
                              const int16_t* fpos, int S, int gt_field, VcfCellDirect D, uint64_t* sp_off, uint32_t* sp_len,
                              uint8_t* sp_state, uint32_t* err, hipStream_t st) {

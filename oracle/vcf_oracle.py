@@ -402,11 +402,39 @@ _MISSING = object()   # bare non-flag key ("missing value" error that the refere
 FLAG = object()
 
 
-def parse_info_fields(info: str, infos: dict, selected=None, strict: bool = True, stop_at=None):
-    """-> [(key, value)] in file order; value is FLAG, None ('.'), a scalar, a list, or _MISSING.
+class LazyList:
+    """A list value noodles has typed but not walked: `Value::Array(..)` holds the text, and its elements are parsed only when the
+    caller iterates them -- load_infos_single_pass does that for the keys it has a builder for (`values.iter().collect::<io::Result<_>>()`,
+    physical_exec.rs:580-611), the FORMAT builder likewise (:1703-1760).  An element that does not parse is then the record's error;
+    under a key without a builder nobody ever looks."""
+    __slots__ = ("raw", "ty")
+
+    def __init__(self, raw: str, ty: str):
+        self.raw, self.ty = raw, ty
+
+    def collect(self):
+        parts = self.raw.split(",")
+        if self.ty == "Integer":
+            return [None if p == "." else parse_i32(p) for p in parts]
+        if self.ty == "Float":
+            return [None if p == "." else parse_f32(p) for p in parts]
+        return [None if p == "." else _percent_decode(p) for p in parts]
+
+
+class CharValue:
+    """`Value::Character`: typed by noodles (exactly one character), but a value the reference has no builder arm for."""
+    __slots__ = ("c",)
+
+    def __init__(self, raw: str):
+        if len(raw) != 1:
+            raise VcfError(f"invalid character: {raw!r}")
+        self.c = raw
+
+
+def parse_info_fields(info: str, infos: dict, stop_at=None):
+    """-> [(key, value)] in file order; value is FLAG, None ('.'), a scalar, a CharValue, a LazyList, or _MISSING.
     noodles' `info.iter(header)` types EVERY entry by the header as it goes (physical_exec.rs:561-571: an error in any entry
-    is the record's error), whether or not the caller wants that key.  strict=False restates the product's documented
-    deviation instead: an entry whose key is not in `selected` is skipped unparsed.
+    is the record's error), whether or not the caller wants that key; a key the header does not declare is a String, Number=1.
     stop_at: stop behind the first entry with this key (`Info::get`, used for END)."""
     if info == "." or info == "":
         return []
@@ -415,47 +443,34 @@ def parse_info_fields(info: str, infos: dict, selected=None, strict: bool = True
         if ent == "":
             continue
         key, sep, raw = ent.partition("=")
-        if not strict and selected is not None and key not in selected:
-            continue
         d = infos.get(key)
         number, ty = (d.number, d.type) if d is not None else ("1", "String")
         if not sep:
             out.append((key, FLAG if ty == "Flag" else _MISSING))
-            continue
-        if raw == ".":
+        elif raw == ".":
             out.append((key, None))
-            continue
-        if ty == "Flag":
+        elif ty == "Flag":
             raise VcfError(f"Error reading INFO field: invalid flag ({key})")
-        if number == "1":
+        elif number == "1":
             if ty == "Integer":
                 out.append((key, parse_i32(raw)))
             elif ty == "Float":
                 out.append((key, parse_f32(raw)))
             elif ty == "Character":
-                raise VcfError(f"Unsupported INFO value type for field '{key}'")
+                out.append((key, CharValue(raw)))
             else:
                 out.append((key, _percent_decode(raw)))
         else:
-            parts = raw.split(",")
-            if ty == "Integer":
-                out.append((key, [None if p == "." else parse_i32(p) for p in parts]))
-            elif ty == "Float":
-                out.append((key, [None if p == "." else parse_f32(p) for p in parts]))
-            elif ty == "Character":
-                raise VcfError(f"Unsupported INFO value type for field '{key}'")
-            else:
-                out.append((key, [None if p == "." else _percent_decode(p) for p in parts]))
+            out.append((key, LazyList(raw, ty)))
         if stop_at is not None and key == stop_at:
             break
     return out
 
 
 class Rec:
-    __slots__ = ("f", "chrom", "pos", "_info", "sel", "strict")
+    __slots__ = ("f", "chrom", "pos", "_info")
 
-    def __init__(self, line: str, selected_info=None, strict: bool = True):
-        self.sel, self.strict = selected_info, strict
+    def __init__(self, line: str):
         f = line.split("\t")
         if len(f) < 8:
             raise VcfError("VCF read error: invalid record")
@@ -468,23 +483,20 @@ class Rec:
         if not digits or not digits.isascii() or not digits.isdigit():
             raise VcfError(f"VCF read error: invalid position {f[1]!r}")
         self.pos = int(digits)
-        if self.pos > 0xFFFFFFFF:
-            # the reference casts the usize to u32 (`get() as u32`, physical_exec.rs:762): a position that does not fit
-            # would silently wrap; both the product and this restatement refuse it
-            raise VcfError(f"VCF read error: invalid position {f[1]!r}")
+        if self.pos > 0xFFFFFFFFFFFFFFFF:
+            raise VcfError(f"VCF read error: invalid position {f[1]!r}")   # usize::from_str: number too large
+        # (the reference casts the usize to u32 wherever a column or a filter takes it -- `get() as u32`,
+        # physical_exec.rs:762, 663-665, 2875: a position that does not fit WRAPS; see `u32` below)
         self._info = None
 
     def info(self, infos):
         if self._info is None:
-            self._info = parse_info_fields(self.f[7], infos, self.sel, self.strict)
+            self._info = parse_info_fields(self.f[7], infos)
         return self._info
 
     def variant_end(self, infos) -> int:
         # noodles `variant_end`: `info.get(header, "END")` walks the entries, typing each, up to the first END
-        if self.strict:
-            ents = self._info if self._info is not None else parse_info_fields(self.f[7], infos, stop_at="END")
-        else:
-            ents = parse_info_fields(self.f[7], infos, {"END"}, False, stop_at="END")
+        ents = self._info if self._info is not None else parse_info_fields(self.f[7], infos, stop_at="END")
         for k, v in ents:
             if k == "END":
                 if isinstance(v, int):
@@ -493,12 +505,17 @@ class Rec:
         return self.pos + len(self.f[3]) - 1
 
 
-def get_variant_end(rec: Rec, infos) -> int:  # physical_exec.rs:646-667
+def u32(v: int) -> int:
+    """`as u32` of a position (usize): values beyond 2^32 - 1 wrap."""
+    return v & 0xFFFFFFFF
+
+
+def get_variant_end(rec: Rec, infos) -> int:  # physical_exec.rs:646-667 (`... .get() as u32`)
     ref, alt = rec.f[3], rec.f[4]
     alts = [] if alt == "." else alt.split(",")
     if len(ref) == 1 and len(alts) == 1 and ref in "ACGT" and alts[0] in ("A", "C", "G", "T"):
-        return rec.pos
-    return rec.variant_end(infos)
+        return u32(rec.pos)
+    return u32(rec.variant_end(infos))
 
 
 def render_gt(raw: str) -> str:
@@ -527,11 +544,11 @@ def render_gt(raw: str) -> str:
     return "".join(out)
 
 
-def parse_sample_values(fmt_keys, sample: str, formats: dict, selected=None, strict: bool = True):
+def parse_sample_values(fmt_keys, sample: str, formats: dict, built=None):
     """-> [(key, value)]; value None for '.', python scalar / list otherwise; GT -> rendered string tagged.
-    `sample.iter(header)` types every value of the sample (physical_exec.rs:1661-1666); a genotype stays lazy and is only
-    walked when GT is one of the selected fields (:1668-1676).  strict=False: values of unselected keys are not looked at
-    (the product's documented deviation)."""
+    `sample.iter(header)` types every value of the sample (physical_exec.rs:1661-1666); a genotype and a list stay lazy and
+    are only walked for the keys the FORMAT builder holds (`built`, None = all; :1664-1760) -- under another key they come
+    back as None here, unlooked at."""
     if sample == "." or sample == "":
         vals = []
     else:
@@ -541,12 +558,9 @@ def parse_sample_values(fmt_keys, sample: str, formats: dict, selected=None, str
         if raw == ".":
             out.append((key, None))
             continue
-        unselected = selected is not None and key not in selected
+        walked = built is None or key in built
         if key == "GT":
-            out.append((key, None) if unselected else (key, ("GT", render_gt(raw))))
-            continue
-        if unselected and not strict:
-            out.append((key, None))
+            out.append((key, ("GT", render_gt(raw))) if walked else (key, None))
             continue
         d = formats.get(key)
         number, ty = (d.number, d.type) if d is not None else ("1", "String")
@@ -555,16 +569,12 @@ def parse_sample_values(fmt_keys, sample: str, formats: dict, selected=None, str
                 out.append((key, parse_i32(raw)))
             elif ty == "Float":
                 out.append((key, parse_f32(raw)))
+            elif ty == "Character":
+                out.append((key, CharValue(raw).c))   # (`SV::Character(c)` -> c.to_string(), :1699)
             else:
                 out.append((key, _percent_decode(raw)))
         else:
-            parts = raw.split(",")
-            if ty == "Integer":
-                out.append((key, [None if p == "." else parse_i32(p) for p in parts]))
-            elif ty == "Float":
-                out.append((key, [None if p == "." else parse_f32(p) for p in parts]))
-            else:
-                out.append((key, [None if p == "." else _percent_decode(p) for p in parts]))
+            out.append((key, LazyList(raw, ty).collect() if walked else None))
     return out
 
 
@@ -617,11 +627,7 @@ class VcfOracle:
     """Mirror of VcfTableProvider::new_with_samples + scan + VcfExec::execute on the CPU."""
 
     def __init__(self, path: str, info_fields=None, format_fields=None, samples=None, zero_based: bool = True,
-                 index_path: Optional[str] = "auto", strict_unselected: bool = True):
-        # strict_unselected=False: INFO entries / FORMAT values whose key is not selected are not validated (what the HIP
-        # path does; the reference's noodles iterators type every entry they pass)
-        self.strict_unselected = strict_unselected
-        self._lax_info, self._lax_fmt = set(), set()
+                 index_path: Optional[str] = "auto"):
         self.path = path
         self.zero_based = zero_based
         self.compression, self.u, self.blocks = _read_text_source(path)
@@ -848,14 +854,14 @@ class VcfOracle:
         return fl
 
     def _rec(self, line: str) -> Rec:
-        return Rec(line, set(self.info_fields) if self.strict_unselected else self._lax_info, self.strict_unselected)
+        return Rec(line)
 
     def _core_row(self, rec: Rec, fl=None):
         """The eight core columns, each only when the projection holds it (physical_exec.rs:800-822: noodles' record is lazy,
         so a QUAL that does not parse, or an INFO entry in front of END, is an error only for a scan that asks for it)."""
         f = rec.f
         need = (lambda k: True) if fl is None else (lambda k: fl[k])
-        row = {"chrom": rec.chrom, "start": rec.pos - 1 if self.zero_based else rec.pos,
+        row = {"chrom": rec.chrom, "start": u32(u32(rec.pos) - 1) if self.zero_based else u32(rec.pos),   # (`start_pos_1based - 1` on a u32)
                "id": "" if f[2] == "." else f[2], "ref": f[3], "alt": "" if f[4] == "." else f[4].replace(",", "|"),
                "filter": "" if f[6] == "." else f[6]}
         row["end"] = get_variant_end(rec, self.header.infos) if need("end") else None
@@ -877,7 +883,11 @@ class VcfOracle:
                 continue
             i = idx_of.get(key)
             if i is None:
-                continue
+                continue       # no builder: a list under this key is never walked
+            if isinstance(v, CharValue) or (isinstance(v, LazyList) and v.ty == "Character"):
+                raise VcfError(f"Unsupported INFO value type for field '{key}'")   # (:632-636)
+            if isinstance(v, LazyList):
+                v = v.collect()
             if populated[i]:
                 if projected is None or i in projected:
                     raise VcfError(f"duplicate INFO key {key} (the reference appends twice and misaligns rows)")
@@ -926,7 +936,7 @@ class VcfOracle:
             oi = out_of_header.get(hi)
             if oi is None:
                 continue
-            for key, v in parse_sample_values(keys, s, h.formats, set(self.format_fields) if self.strict_unselected else self._lax_fmt, self.strict_unselected):
+            for key, v in parse_sample_values(keys, s, h.formats, set(self.format_fields)):
                 i = field_idx.get(key)
                 if i is None:
                     continue
@@ -1006,7 +1016,7 @@ class VcfOracle:
         if not samples:
             return None  # no sample iterated: nothing appended (would misalign rows in the reference)
         field_idx = {t: i for i, t in enumerate(self.format_fields)}
-        for key, v in parse_sample_values(keys, samples[0], h.formats, set(self.format_fields) if self.strict_unselected else self._lax_fmt, self.strict_unselected):
+        for key, v in parse_sample_values(keys, samples[0], h.formats, set(self.format_fields)):
             i = field_idx.get(key)
             if i is None:
                 continue
@@ -1077,24 +1087,13 @@ class VcfOracle:
         return schema, batches
 
     def _filter_fields(self, rec: Rec):
-        start = rec.pos - 1 if self.zero_based else rec.pos
+        start = u32(u32(rec.pos) - 1) if self.zero_based else u32(rec.pos)
         f = rec.f
         return {"chrom": rec.chrom, "start": start, "end": get_variant_end(rec, self.header.infos),
                 "id": "" if f[2] == "." else f[2]}
 
     def execute(self, plan, partition: int = 0, batch_size: int = 8192):
         projection, limit = plan["projection"], plan["limit"]
-        # strict_unselected=False looks only at the keys of PROJECTED columns (a multi-sample `genotypes` column holds every
-        # selected FORMAT field)
-        self._lax_info = set(self.info_fields if projection is None else
-                             [self.info_fields[i - 8] for i in projection if 8 <= i < 8 + self.n_info])
-        if len(self.source_samples) > 1:
-            any_fmt = projection is None or any(i >= 8 + self.n_info for i in projection)
-            self._lax_fmt = set(self.format_fields) if any_fmt else set()
-        else:
-            self._lax_fmt = set(self.format_fields if projection is None else
-                                [self.format_fields[i - 8 - self.n_info] for i in projection
-                                 if 8 + self.n_info <= i < 8 + self.n_info + len(self.format_fields)])
         if plan["kind"] == "empty":
             return self.projected_schema(projection), []
         if plan["kind"] == "sequential":
@@ -1111,9 +1110,9 @@ class VcfOracle:
                 if region.start is not None and region.end is not None and region.end < region.start:
                     raise VcfError(f"Invalid region '{region.chrom}': end ({region.end}) is less than start ({region.start})")
                 for rec in self._query(region):
-                    if region.start is not None and rec.pos < region.start:
+                    if region.start is not None and u32(rec.pos) < region.start:   # physical_exec.rs:2875-2895: on the u32
                         continue
-                    if region.end is not None and rec.pos > region.end:
+                    if region.end is not None and u32(rec.pos) > region.end:
                         continue
                     if residual and not evaluate_record_filters(self._filter_fields(rec), residual,
                                                                 string_fields=("chrom", "id"), num_fields=("start", "end")):

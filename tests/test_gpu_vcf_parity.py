@@ -609,14 +609,89 @@ def test_format_cell_errors_are_loud_on_both_sides(pkg, vo, tmp_path, cell, fmt)
         list(g.scan().execute(0, 8192))
 
 
-def test_gt_with_leading_zero_allele_is_refused(pkg, tmp_path):
-    """noodles parses allele indices as integers and the reference re-renders them ("01/1" -> "1/1"); the device path
-    copies the GT text, so an allele it could not reproduce byte for byte is refused loudly instead of being passed on."""
+def test_gt_with_leading_zero_alleles_is_rendered_again(pkg, vo, tmp_path):
+    """noodles parses allele indices as integers and the reference renders them again (physical_exec.rs:1675-1694): "01/1"
+    comes out as "1/1", "00|007" as "0|7" -- on the device the cell is sized for the rendered form and written by
+    k_gt_render (r03 refused such a file)."""
     p = tmp_path / "lz.vcf"
-    p.write_text(_ms_vcf([["0/1:1:1", "01/1:5:5"]]))
-    g = pkg.VcfTableProvider(str(p), None, ["GT", "GQ", "DP"])
-    with pytest.raises(pkg.BioscanError):
-        list(g.scan().execute(0, 8192))
+    p.write_text(_ms_vcf([["0/1:1:1", "01/1:5:5", "00|007:1:2"], ["./000:3:3", "|010/0:4:4", "10/020/3:5:6"]]))
+    for kw in ({"format_fields": ["GT", "GQ", "DP"]}, {"format_fields": ["GT"], "samples": ["S2", "S1"]}):
+        assert _parity(pkg, vo, str(p), kw, exact_batches=False) == 2
+    g = pkg.VcfTableProvider(str(p), None, ["GT"])
+    t = pa.Table.from_batches(list(g.scan().execute(0, 8192)))
+    assert t.column("genotypes").to_pylist()[0]["GT"] == ["0/1", "1/1", "0|7"]
+    assert t.column("genotypes").to_pylist()[1]["GT"] == ["./0", "10/0", "10/20/3"]
+    # single-sample source: the GT column of the one sample
+    q = tmp_path / "lz1.vcf"
+    q.write_text(_ms_vcf([["007/01:1:1"], ["1|02:2:2"]]))
+    assert _parity(pkg, vo, str(q), {"format_fields": ["GT", "DP"]}) == 2
+
+
+def test_values_without_a_column_are_typed_all_the_same(pkg, vo, tmp_path):
+    """noodles types every INFO entry (`info.iter(header)`, physical_exec.rs:561-571) and every value of a selected sample
+    (`sample.iter(header)`, :1661-1666) as it walks them: a scalar that does not parse under a key the scan has NO column for is
+    the record's error all the same -- once some INFO / FORMAT column is asked for.  A list or a genotype stays unwalked unless
+    the table has a builder for its key (:580-611, :1668-1760); `end` walks INFO up to END only, and not at all for a
+    single-base substitution (:646-667).  Each case: both sides refuse, or both read the same rows."""
+    hdr = ("##fileformat=VCFv4.3\n##contig=<ID=c,length=100000>\n"
+           '##INFO=<ID=DP,Number=1,Type=Integer,Description="d">\n##INFO=<ID=MQ,Number=1,Type=Float,Description="m">\n'
+           '##INFO=<ID=LST,Number=.,Type=Integer,Description="l">\n##INFO=<ID=DB,Number=0,Type=Flag,Description="f">\n'
+           '##INFO=<ID=CH,Number=1,Type=Character,Description="c">\n##INFO=<ID=NOTE,Number=1,Type=String,Description="n">\n'
+           '##INFO=<ID=END,Number=1,Type=Integer,Description="e">\n'
+           '##FORMAT=<ID=GT,Number=1,Type=String,Description="g">\n##FORMAT=<ID=GQ,Number=1,Type=Integer,Description="q">\n'
+           '##FORMAT=<ID=XF,Number=1,Type=Float,Description="x">\n##FORMAT=<ID=PL,Number=G,Type=Integer,Description="p">\n'
+           '##FORMAT=<ID=FC,Number=1,Type=Character,Description="c">\n##FORMAT=<ID=FT,Number=1,Type=String,Description="t">\n'
+           "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS0\tS1\n")
+    good = "c\t5\t.\tA\tT\t1\t.\tDP=1;MQ=2.5\tGT:GQ\t0/1:5\t1/1:6\n"
+
+    def both(body, kw, names, expect):
+        p = tmp_path / "t.vcf"
+        p.write_text(hdr + good + body)
+        if expect == "read":
+            assert _parity(pkg, vo, str(p), kw, names=names, exact_batches=False) == 2, (body, kw, names)
+            return
+        o = vo.VcfOracle(str(p), **kw)
+        proj = None if names is None else [o.schema.get_field_index(n) for n in names]
+        with pytest.raises((vo.VcfError, ValueError)):
+            o.execute(o.scan(projection=proj, filters=[], limit=None, target_partitions=1), 0, 100)
+        g = pkg.VcfTableProvider(str(p), kw.get("info_fields"), kw.get("format_fields"), None, True, kw.get("samples"))
+        with pytest.raises(pkg.BioscanError):
+            list(g.scan(projection=proj, filters=[], limit=None, target_partitions=1).execute(0, 100))
+
+    rec = lambda info, fmt="GT:GQ", s0="0/1:5", s1="1/1:6", ref="A": f"c\t9\t.\t{ref}\tT\t1\t.\t{info}\t{fmt}\t{s0}\t{s1}\n"
+    # ---- INFO: a scalar of a key without a column
+    for info in ("DP=1;MQ=--", "MQ=--;DP=1", "DP=1x", "DB=1", "DP=1;CH=xy", "NOTE=%FF;DP=1", "UNDECLARED=%FF", "DP=1;;MQ=1e"):
+        both(rec(info), {"info_fields": ["DP"]}, ["chrom", "DP"], "refuse")          # MQ / DB / CH / NOTE are not table fields
+        both(rec(info), {}, ["chrom", "LST"], "refuse")                               # ... or are, but not projected
+        both(rec(info), {}, ["chrom", "start", "genotypes"], "read")                  # no INFO column: INFO is never walked
+    both(rec("DP=1;CH=x;UNDECLARED=a%2Cb;MQ=."), {"info_fields": ["DP"]}, ["DP"], "read")   # one character; '.'; a good escape
+    both(rec("DP=1;CH=x"), {}, ["DP"], "refuse")                                      # Character with a builder: unsupported value type
+    # ---- INFO: lists are walked only under a key with a builder
+    both(rec("DP=1;LST=1,x,3"), {"info_fields": ["DP"]}, ["DP"], "read")
+    both(rec("DP=1;LST=1,x,3"), {}, ["DP"], "refuse")
+    both(rec("DP=1;LST=1,.,3"), {}, ["DP"], "read")
+    # ---- `end`: entries in front of END are typed, those behind it are not; a single-base substitution asks nothing
+    both(rec("MQ=--;END=20", ref="AC"), {}, ["chrom", "end"], "refuse")
+    both(rec("END=20;MQ=--", ref="AC"), {}, ["chrom", "end"], "read")
+    both(rec("MQ=--;END=20", ref="A"), {}, ["chrom", "end"], "read")
+    both(rec("LST=1,x;END=20", ref="AC"), {}, ["chrom", "end"], "read")
+    # ---- FORMAT: every value of a selected sample
+    for s1 in ("1/1:6x", "1/1:6:--", "1/1:6:1.5:0,1,2:xy", "1/1:6:1.5:0,1,2:x:%FF"):
+        fmt = "GT:GQ:XF:PL:FC:FT"
+        s0 = "0/1:5:1.5:0,1,2:x:ok"
+        both(rec("DP=1", fmt, s0, s1), {"format_fields": ["GT"]}, None, "refuse")
+        both(rec("DP=1", fmt, s0, s1), {"format_fields": ["GT"]}, ["chrom", "DP"], "read")         # no FORMAT column
+        both(rec("DP=1", fmt, s0, s1), {"format_fields": ["GT"], "samples": ["S0"]}, None, "read")  # the other sample
+    both(rec("DP=1", "GT:GQ:XF:PL:FC:FT", "0/1:5:1.5:0,1,2:x:ok", "1/1:6:2:0,x,2:y:a%2Cb"), {"format_fields": ["GT", "FC"]}, None, "read")
+    both(rec("DP=1", "GT:GQ:XF:PL:FC:FT", "0/1:5:1.5:0,1,2:x:ok", "1/1:6:2:0,x,2:y:ok"), {"format_fields": ["GT", "PL"]}, None, "refuse")
+    both(rec("DP=1", "GT:GQ", "0/1:5", "1/x:6"), {"format_fields": ["GQ"]}, None, "read")           # a genotype nobody walks
+    both(rec("DP=1", "GT:GQ", "0/1:5", "1/x:6"), {"format_fields": ["GT"]}, None, "refuse")
+    both(rec("DP=1", "GT:GQ:FC", "0/1:5:x", "1/1:6:xy"), {"format_fields": ["GT", "FC"]}, None, "refuse")   # a selected Character
+    # more FORMAT keys than the kernels' per-row map holds: the 17th value is typed too
+    many = ":".join(["GT"] + [f"K{i}" for i in range(15)] + ["GQ"])
+    vals = ":".join(["0/1"] + ["v"] * 15)
+    both(rec("DP=1", many, vals + ":5", vals + ":6x"), {"format_fields": ["GT"]}, None, "refuse")
+    both(rec("DP=1", many, vals + ":5", vals + ":6"), {"format_fields": ["GT"]}, None, "read")
 
 
 def test_large_file_properties(pkg, tmp_path):
@@ -682,11 +757,11 @@ def test_differential_fuzz_of_whole_files(pkg, vo):
     """tools/fuzz_vcf_parity.py, a fixed number of files of two seeds: random headers (every Number / Type), 0..5 samples,
     missing values wherever the grammar allows them, escapes, lines spanning 150-byte BGZF members, one file in five with a
     malformed record -- schema, plan and rows against the oracle under random selections, projections and batch sizes; a file
-    one side refuses the other refuses too (the one documented exception is counted: a malformed value under a key whose
-    column is not projected, which the reference's iterators would still type)."""
+    one side refuses the other refuses too -- including a value that does not type under a key the scan has no column for
+    (noodles types every INFO entry and every value of a selected sample as it passes them)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_vcf_parity as F
-    tot = dict(files=0, scans=0, indexed_scans=0, rows=0, refused_by_both=0, read_under_product_rule=0)
+    tot = dict(files=0, scans=0, indexed_scans=0, rows=0, refused_by_both=0)
     for seed in (5, 6):
         t, failures = F.run(pkg, seed=seed, max_files=60, verbose=False)
         assert not failures, failures[:3]
