@@ -54,6 +54,12 @@ constexpr int V4_WIN = V4_WIN_BYTES;                    // LDS output window of 
 // The compressed bits of a round live in LDS while it is decoded (three passes over them): 64 sub-streams plus the dwords a
 // lane may look at behind the last sub-stream's end (a symbol that begins before the limit, the two prefetched dwords).
 constexpr uint32_t V4_LCAP = 256;                      // matches of a mini-round (together with the window size: what a mini-round takes)
+#ifndef V4_PIPE_CK
+#define V4_PIPE_CK 0    // 1: a mini-round's checkpoint rows are asked for one mini-round ahead (measured: no gain -- see below)
+#endif
+#ifndef V4_PREFETCH
+#define V4_PREFETCH 1   // 0: every round waits for its own staging loads (A/B switch)
+#endif
 constexpr uint32_t V4_STAGE_SLACK = 16, V4_STAGE_DW = 64u * V4_SUB_DW + V4_STAGE_SLACK;
 // One table of 1076 32-bit entries, addressed in entry units (all table starts are even):
 //   [0, 64)             distance root
@@ -1334,30 +1340,18 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
         }
       }
       TOCK(5);
-      {
-        // literal/length sub-tables from the pool's high end, distance sub-tables from its low end; codes that need more
-        // than the pool holds go to the wide-table kernel
-        uint32_t lit_tot, dist_tot;
-        int rc = v4_build(L, L.b.lens, 288, V4_LIT_ROOT, V4_LIT_BITS, V4_POOL_LO, V4_LIT_ROOT, L.b.lit_sorted, false, lane, lit_tot);
-        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (3u << 8); break; }
-        rc = v4_build(L, L.b.lens + 288, 32, V4_DIST_ROOT, V4_DIST_BITS, V4_POOL_LO, V4_LIT_ROOT - lit_tot, L.b.dist_sorted, true, lane, dist_tot);
-        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (4u << 8); break; }
-        if (lane == 0) L.lit_lo = V4_LIT_ROOT - lit_tot;
-        V4_SYNC();
-      }
-      P = ub_bitpos(in);
-      TOCK(0);
+      P = ub_bitpos(in);   // the block's body starts here (the table builds below read the code lengths from LDS only)
 
-      // ---- rounds over the block body ----
       bool block_done = false;
       uint32_t force_dw = 0;  // != 0: the round is being re-run with short sub-streams (a pass ran out of checkpoint rows)
       const uint64_t block_P0 = P;
-      while (!block_done) {
+      // dwords per sub-stream of the round that starts at bit Pq of this block
+      auto round_sub_dw = [&](uint64_t Pq) -> uint32_t {
         // A round should end with its block: it covers what is left of the predicted block length (the previous block's
         // length -- zlib and libdeflate cut blocks of similar size), with a little slack because an underestimate costs a
         // whole extra round and an overestimate only idle lanes behind the END-OF-BLOCK.
-        const uint64_t rem_bits = end_bits > P ? end_bits - P : 0;
-        const uint64_t used = P - block_P0;
+        const uint64_t rem_bits = end_bits > Pq ? end_bits - Pq : 0;
+        const uint64_t used = Pq - block_P0;
         uint64_t want = pred_bits > used + pred_bits / 8 ? pred_bits - used : pred_bits / 8;
         want += want / 16 + 64;
         if (want > rem_bits) want = rem_bits;
@@ -1372,9 +1366,45 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           want = rounds_left > 1u ? (rb + rounds_left - 1u) / rounds_left : rb;
         }
 #endif
-        uint32_t sub_dw = (uint32_t)((want + 64ull * 32 - 1) / (64ull * 32));
-        if (sub_dw > (uint32_t)V4_MAX_SUB_DW) sub_dw = V4_MAX_SUB_DW;
-        if (sub_dw < 5) sub_dw = 5;
+        uint32_t sdw = (uint32_t)((want + 64ull * 32 - 1) / (64ull * 32));
+        if (sdw > (uint32_t)V4_MAX_SUB_DW) sdw = V4_MAX_SUB_DW;
+        if (sdw < 5) sdw = 5;
+        return sdw;
+      };
+      // the NEXT round's dwords, asked for as soon as this round's decode passes have fixed where it ends and held in registers
+      // while the round writes and resolves: staging them then costs three LDS stores instead of an HBM round trip (the stage
+      // phase goes from 3.1 % to 1.4 % of the wave cycles; the launch gains 0.6 % -- other waves were hiding most of that wait)
+      constexpr bool PF_ON = WPW == 1 && V4_PREFETCH != 0;   // (the shared-table shape of long members has no registers to spare)
+      constexpr int V4_PF = (V4_STAGE_DW / 4 + WAVE - 1) / WAVE;
+      u32x4 pf[V4_PF];
+      uint64_t pf_wb = ~0ull;   // dword index the registers were loaded from (~0: nothing held)
+      if constexpr (PF_ON) {
+        // the first round's dwords travel while the tables are built
+        const uint32_t n16n = (round_sub_dw(P) * 64u + V4_STAGE_SLACK) / 4u;
+        const uint64_t wbn = P >> 5;
+#pragma unroll
+        for (int q = 0; q < V4_PF; q++) {
+          const uint32_t i = (uint32_t)lane + (uint32_t)q * WAVE;
+          if (i < n16n) pf[q] = ld16((const uint8_t*)(base32 + wbn) + 16u * i);
+        }
+        pf_wb = wbn;
+      }
+      {
+        // literal/length sub-tables from the pool's high end, distance sub-tables from its low end; codes that need more
+        // than the pool holds go to the wide-table kernel
+        uint32_t lit_tot, dist_tot;
+        int rc = v4_build(L, L.b.lens, 288, V4_LIT_ROOT, V4_LIT_BITS, V4_POOL_LO, V4_LIT_ROOT, L.b.lit_sorted, false, lane, lit_tot);
+        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (3u << 8); break; }
+        rc = v4_build(L, L.b.lens + 288, 32, V4_DIST_ROOT, V4_DIST_BITS, V4_POOL_LO, V4_LIT_ROOT - lit_tot, L.b.dist_sorted, true, lane, dist_tot);
+        if (rc) { st = rc == 2 ? (uint32_t)INF_RETRY : INF_BAD_CODE | (4u << 8); break; }
+        if (lane == 0) L.lit_lo = V4_LIT_ROOT - lit_tot;
+        V4_SYNC();
+      }
+      TOCK(0);
+
+      // ---- rounds over the block body ----
+      while (!block_done) {
+        uint32_t sub_dw = round_sub_dw(P);
         if (force_dw) sub_dw = force_dw;
         const uint32_t subb = sub_dw * 32;
         uint32_t ovb = (subb * (uint32_t)V4_OV_QUARTERS) >> 2;   // pre-roll of the speculative lanes
@@ -1386,11 +1416,19 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
         // loads), the one HBM round trip of the round -- the decode loops below never touch global memory
         {
           const uint32_t n16 = (sub_dw * 64u + V4_STAGE_SLACK) / 4u;
+          if (PF_ON && pf_wb == wb && !force_dw) {
+#pragma unroll
+            for (int q = 0; q < V4_PF; q++) {
+              const uint32_t i = (uint32_t)lane + (uint32_t)q * WAVE;
+              if (i < n16) { u32x4_raw r; r.x = pf[q].x; r.y = pf[q].y; r.z = pf[q].z; r.w = pf[q].w; *(u32x4_raw*)(L.stage + 4u * i) = r; }
+            }
+          } else
           for (uint32_t i = (uint32_t)lane; i < n16; i += WAVE) {
             const u32x4 v = ld16((const uint8_t*)(base32 + wb) + 16u * i);
             u32x4_raw r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
             *(u32x4_raw*)(L.stage + 4u * i) = r;
           }
+          pf_wb = ~0ull;
           V4_SYNC();
         }
         TOCK(1);
@@ -1448,15 +1486,37 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
         const uint32_t mbase = wave_excl_scan_u32(valid ? (acc >> 20) : 0u, lane, &tot_m);
         if (opos + tot_out > isize) { st = INF_OVERRUN; break; }
         if (dbg) dbg_idle += 63u - (uint32_t)last;
+        if (PF_ON && !stopm) {
+          // the block goes on: its next round starts at the end of the last lane's last symbol -- the same loads, with the same
+          // bounds, that the staging above would issue then
+          const uint64_t Pn = (wb << 5) + __builtin_amdgcn_readlane(end, last);
+          if (Pn < end_bits + 64) {
+            const uint32_t n16n = (round_sub_dw(Pn) * 64u + V4_STAGE_SLACK) / 4u;
+            const uint64_t wbn = Pn >> 5;
+#pragma unroll
+            for (int q = 0; q < V4_PF; q++) {
+              const uint32_t i = (uint32_t)lane + (uint32_t)q * WAVE;
+              if (i < n16n) pf[q] = ld16((const uint8_t*)(base32 + wbn) + 16u * i);
+            }
+            pf_wb = wbn;
+          }
+        }
         // ---- write phase: the round's segments, in output order, 64 per mini-round ----
         const uint32_t nseg = (valid && start < limit) ? 1u + cn : 0u;
         uint32_t n_seg_tot;
         const uint32_t segbase = wave_excl_scan_u32(nseg, lane, &n_seg_tot);
         const uint32_t segend = segbase + nseg;
         uint32_t n_take = 0;  // segments of the current mini-round: 64, or as many as fit in the LDS window
-        for (uint32_t s0 = 0; s0 < n_seg_tot; s0 += n_take) {
+        // A mini-round's lanes read their segment's checkpoint rows from the wave's scratch: one L2 round trip.  V4_PIPE_CK=1 asks
+        // for the rows as soon as the PREVIOUS mini-round knows how many segments it takes, so that its write and resolve phases
+        // hide the trip.  Measured (262144 members, same box): 45.28 ms against 45.14 ms without -- the kernel is VALU-bound at
+        // four waves per SIMD and another wave already runs while this one waits; the seven registers the rows in flight take
+        // spill two.  Kept as a switch, off.
+        uint32_t seg_n = 0;   // the segment the rows in flight belong to: owner lane | row k << 6 | "there is one" << 31
+        uint32_t l_p0 = 0, l_a0 = 0, l_st0 = 0, l_p1 = 0, l_a1 = 0;
+        auto seg_issue = [&](uint32_t s0) {
           const uint32_t g = s0 + (uint32_t)lane;
-          bool has = g < n_seg_tot;
+          const bool has_n = g < n_seg_tot;
           // owner of segment g: the first lane whose segments end after g (segend is non-decreasing)
           int lo = 0, hi = WAVE;
 #pragma unroll
@@ -1465,8 +1525,26 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
             const uint32_t v = (uint32_t)__shfl((int)segend, mid & 63, WAVE);
             if (lo < hi) { if (v <= g) lo = mid + 1; else hi = mid; }
           }
-          const int own = lo < WAVE ? lo : WAVE - 1;
-          const uint32_t k = g - (uint32_t)__shfl((int)segbase, own, WAVE);
+          const int own_n = lo < WAVE ? lo : WAVE - 1;
+          const uint32_t own_base = (uint32_t)__shfl((int)segbase, own_n, WAVE);   // (every lane takes part: a lane may own segments of a mini-round it has none in)
+          const uint32_t k_n = has_n ? g - own_base : 0u;
+          seg_n = (uint32_t)own_n | (k_n << 6) | (has_n ? 0x80000000u : 0u);
+          const uint32_t o_cn = (uint32_t)__shfl((int)cn, own_n, WAVE);
+          if (has_n && k_n > 0) {
+            const uint32_t* q = ck + k_n * V4_CK_ROW + (uint32_t)own_n;        // row k = state after k * V4_CK_STEPS steps
+            l_p0 = q[0]; l_a0 = q[64]; l_st0 = q[128];
+          }
+          if (has_n && k_n < o_cn) {
+            const uint32_t* q = ck + (k_n + 1u) * V4_CK_ROW + (uint32_t)own_n;
+            l_p1 = q[0]; l_a1 = q[64];
+          }
+        };
+        if (V4_PIPE_CK && n_seg_tot) seg_issue(0);
+        for (uint32_t s0 = 0; s0 < n_seg_tot; s0 += n_take) {
+          if (!V4_PIPE_CK) seg_issue(s0);
+          bool has = (seg_n >> 31) != 0u;
+          const int own = (int)(seg_n & 63u);
+          const uint32_t k = (seg_n >> 6) & 0x1FFFFFFu;
           const uint32_t o_start = (uint32_t)__shfl((int)start, own, WAVE);
           const uint32_t o_obase = (uint32_t)__shfl((int)obase, own, WAVE);
           const uint32_t o_mbase = (uint32_t)__shfl((int)mbase, own, WAVE);
@@ -1474,14 +1552,8 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           const uint32_t o_acc = (uint32_t)__shfl((int)acc, own, WAVE);
           const uint32_t o_limit = rel0 + (uint32_t)(own + 1) * subb;
           uint32_t p0 = o_start, a0 = 0, st0 = V4_LIT_ROOT | ((uint32_t)V4_LIT_BITS << 12), p1 = 0xFFFFFFFFu, a1 = o_acc;
-          if (has && k > 0) {
-            const uint32_t* q = ck + k * V4_CK_ROW + (uint32_t)own;        // row k = state after k * V4_CK_STEPS steps
-            p0 = q[0]; a0 = q[64]; st0 = q[128];
-          }
-          if (has && k < o_cn) {
-            const uint32_t* q = ck + (k + 1u) * V4_CK_ROW + (uint32_t)own;
-            p1 = q[0]; a1 = q[64];
-          }
+          if (has && k > 0) { p0 = l_p0; a0 = l_a0; st0 = l_st0; }
+          if (has && k < o_cn) { p1 = l_p1; a1 = l_a1; }
           const uint32_t seg_out = has ? (a1 & 0xFFFFFu) - (a0 & 0xFFFFFu) : 0u;
           const uint32_t seg_m = has ? (a1 >> 20) - (a0 >> 20) : 0u;
           const uint32_t my_opos = o_obase + (a0 & 0xFFFFFu);
@@ -1500,6 +1572,7 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
           const uint32_t m_s = __builtin_amdgcn_readlane(my_mabs + seg_m, nl) - M0;
           if (!use_win && m_s > (uint32_t)V4_ML_ENTRIES) { st = INF_OVERRUN | (1u << 8); break; }
           if (dbg && !use_win) dbg_hbm++;
+          if (V4_PIPE_CK && s0 + n_take < n_seg_tot) seg_issue(s0 + n_take);
           {
             uint32_t f2 = 0;
             const uint32_t tb0 = st0 & 0xFFFu, mb0 = (st0 >> 12) & 15u, ml0 = st0 >> 16;
