@@ -53,7 +53,10 @@ constexpr int V4_MAX_SUB_DW = V4_SUB_DW;
 constexpr int V4_WIN = V4_WIN_BYTES;                    // LDS output window of one round (multiple of 16)
 // The compressed bits of a round live in LDS while it is decoded (three passes over them): 64 sub-streams plus the dwords a
 // lane may look at behind the last sub-stream's end (a symbol that begins before the limit, the two prefetched dwords).
-constexpr uint32_t V4_LCAP = 256;                      // matches of a mini-round (together with the window size: what a mini-round takes)
+#ifndef V4_LCAP_N
+#define V4_LCAP_N 256
+#endif
+constexpr uint32_t V4_LCAP = V4_LCAP_N;                      // matches of a mini-round (together with the window size: what a mini-round takes)
 #ifndef V4_PIPE_CK
 #define V4_PIPE_CK 0    // 1: a mini-round's checkpoint rows are asked for one mini-round ahead (measured: no gain -- see below)
 #endif
@@ -1589,9 +1592,9 @@ __global__ __launch_bounds__(WAVE * WPW, V4_WAVES_PER_EU) void k_bgzf_inflate_v4
 #else
             else f2 = v4_write<1>(L, has, p0, tb0, mb0, ml0, o_limit, p1, out, my_opos, mlist, my_mabs - M0, R, gsrc);
 #endif
-#endif
             PRIO_WRITE(0);
             if (dbg) tcx[1] += clock64() - tw0;
+#endif
             dbg_minis++;
             if (__ballot(f2 & F_BAD) != 0ull) { st = INF_BAD_DIST; break; }
           }
