@@ -584,15 +584,17 @@ struct DevTypeTable {
     if (ents.empty()) return;
     uint32_t cap = 8;
     while (cap < 2 * ents.size()) cap *= 2;
-    std::vector<VcfTypeSlot> h(cap, VcfTypeSlot{0, 0});
+    std::vector<VcfTypeSlot> h(cap, VcfTypeSlot{0, 0, 0});
     std::string blob;
     for (auto& e : ents) {
-      uint32_t i = vcf_key_hash((const uint8_t*)e.first.data(), (uint32_t)e.first.size()) & (cap - 1);
+      uint64_t k8 = 0;
+      for (size_t i = 0; i < e.first.size() && i < 8; i++) k8 |= (uint64_t)(uint8_t)e.first[i] << (8 * i);
+      uint32_t i = vcf_key_hash(k8, (uint32_t)e.first.size()) & (cap - 1);
       bool dup = false;
       for (; h[i].len_kind; i = (i + 1) & (cap - 1))
         if ((h[i].len_kind & 0xFFFFFFu) == e.first.size() && blob.compare(h[i].off, e.first.size(), e.first) == 0) { dup = true; break; }
       if (dup) continue;   // (the first declaration of an id counts)
-      h[i] = VcfTypeSlot{(uint32_t)blob.size(), (uint32_t)e.first.size() | ((e.second + 1u) << 24)};
+      h[i] = VcfTypeSlot{k8, (uint32_t)blob.size(), (uint32_t)e.first.size() | ((e.second + 1u) << 24)};
       blob += e.first;
     }
     keys.alloc(blob.size() + 1);

@@ -26,17 +26,17 @@ enum VcfCheckKind : uint32_t {
   CK_GT = 7,           // genotype of a key with a builder
   CK_LIST = 8          // bit: a list whose elements (of the scalar kind in the low bits) are walked
 };
-struct VcfTypeSlot { uint32_t off, len_kind; };  // key bytes at keys + off; len_kind = length | (kind + 1) << 24; 0 = empty slot
+// key8 = the key's first (up to) eight bytes, little endian, zero padded: most keys are compared and hashed as one 64-bit word;
+// the bytes of a longer key are at keys + off.  len_kind = length | (kind + 1) << 24; 0 = empty slot.
+struct VcfTypeSlot { uint64_t key8; uint32_t off, len_kind; };
 struct VcfTypeTable {
   const uint8_t* keys;
   const VcfTypeSlot* slots;   // open addressing, linear probing, mask + 1 slots (a power of two, at most half full)
   uint32_t mask;
   uint32_t miss_kind;         // a key the header does not declare: String, Number=1 (noodles' default)
 };
-__host__ __device__ inline uint32_t vcf_key_hash(const uint8_t* k, uint32_t n) {   // FNV-1a
-  uint32_t h = 2166136261u;
-  for (uint32_t i = 0; i < n; i++) h = (h ^ k[i]) * 16777619u;
-  return h;
+__host__ __device__ inline uint32_t vcf_key_hash(uint64_t key8, uint32_t n) {
+  return (uint32_t)(((key8 ^ n) * 0x9E3779B97F4A7C15ull) >> 40);
 }
 
 // delimiter index over u[lo, hi): positions of '\n' and '\t', and for each newline the number of tabs before it

@@ -495,18 +495,50 @@ __device__ uint32_t pct_decoded_len(const uint8_t* p, uint32_t l, bool* pct, uin
 }
 
 // ---- values of keys the scan has no column for ---------------------------------------------------------------------
+// A kernel that looks many keys up copies the table to LDS first (a header declares a few dozen keys: <= 128 slots of 16 bytes);
+// every lookup is then an LDS read instead of a dependent L2 round trip per INFO entry.  Called by all threads of the block.
+constexpr uint32_t VCF_TT_LDS_SLOTS = 128;
+__device__ __forceinline__ VcfTypeTable stage_type_table(VcfTypeTable T, VcfTypeSlot* s_slots) {
+  if (T.slots != nullptr && T.mask < VCF_TT_LDS_SLOTS) {
+    for (uint32_t i = threadIdx.x; i <= T.mask; i += blockDim.x) s_slots[i] = T.slots[i];
+    __syncthreads();
+    T.slots = s_slots;
+  }
+  return T;
+}
 __device__ uint32_t type_lookup(const VcfTypeTable& T, const uint8_t* k, uint32_t kl) {
   if (T.slots == nullptr) return T.miss_kind;
-  for (uint32_t h = vcf_key_hash(k, kl) & T.mask;; h = (h + 1) & T.mask) {
+  uint64_t k8 = ((const dl_u64*)k)->v;   // (reads past the key stay inside the text buffer's slack)
+  if (kl < 8) k8 &= (1ull << (8 * kl)) - 1ull;
+  for (uint32_t h = vcf_key_hash(k8, kl) & T.mask;; h = (h + 1) & T.mask) {
     const VcfTypeSlot sl = T.slots[h];
     if (sl.len_kind == 0) return T.miss_kind;
-    if ((sl.len_kind & 0xFFFFFFu) == kl) {
-      const uint8_t* q = T.keys + sl.off;
+    if (sl.key8 == k8 && (sl.len_kind & 0xFFFFFFu) == kl) {
       bool eq = true;
-      for (uint32_t i = 0; i < kl && eq; i++) eq = q[i] == k[i];
+      for (uint32_t i = 8; i < kl && eq; i++) eq = T.keys[sl.off + i] == k[i];
       if (eq) return (sl.len_kind >> 24) - 1u;
     }
   }
+}
+// a float literal Rust's `str::parse::<f32>` takes (the grammar of parse_f32_text, without the value)
+__device__ bool f32_text_ok(const uint8_t* p, uint32_t len) {
+  uint32_t i = (len && (p[0] == '+' || p[0] == '-')) ? 1u : 0u;
+  if (ci_eq(p + i, len - i, "inf") || ci_eq(p + i, len - i, "infinity") || ci_eq(p + i, len - i, "nan")) return true;
+  bool any = false, dot = false;
+  for (; i < len; i++) {
+    const uint32_t c = p[i];
+    if (c - '0' <= 9u) any = true;
+    else if (c == '.') { if (dot) return false; dot = true; }
+    else break;
+  }
+  if (!any) return false;
+  if (i < len && (p[i] == 'e' || p[i] == 'E')) {
+    i++;
+    if (i < len && (p[i] == '+' || p[i] == '-')) i++;
+    if (i >= len) return false;
+    for (; i < len; i++) if ((uint32_t)p[i] - '0' > 9u) return false;
+  }
+  return i == len;
 }
 // genotype text as noodles walks it: an optional leading phasing mark, then alleles ('.' or digits) joined by '/' or '|'
 __device__ bool gt_text_ok(const uint8_t* p, uint32_t l) {
@@ -523,13 +555,31 @@ __device__ bool gt_text_ok(const uint8_t* p, uint32_t l) {
   }
   return tl != 0;
 }
+// The common well-formed values in one 8-byte word: 1 .. 8 decimal digits (always an i32), or 1 .. 8 characters of digits with at
+// most one '.' and at least one digit (a float literal without sign and exponent).  Anything else takes the parsers' road.
+__device__ __forceinline__ bool swar_plain_number(const uint8_t* p, uint32_t l, bool allow_dot) {
+  if (l == 0 || l > 8) return false;
+  uint64_t w = ((const dl_u64*)p)->v;   // (reads past the value stay inside the text buffer's slack)
+  if (l < 8) { const uint64_t keep = (1ull << (8 * l)) - 1ull; w = (w & keep) | (0x3030303030303030ull & ~keep); }
+  uint32_t ndot = 0;
+  if (allow_dot) {
+    const uint64_t dm = eq_mask8(w, 0x2E2E2E2E2E2E2E2Eull);
+    ndot = (uint32_t)__popcll(dm);
+    w ^= (dm >> 7) * 0x1Eull;           // '.' -> '0'
+  }
+  const uint64_t x = w ^ 0x3030303030303030ull;   // a digit is 0 .. 9 now
+  const bool digits = ((((x & 0x7F7F7F7F7F7F7F7Full) + 0x7676767676767676ull) | x) & 0x8080808080808080ull) == 0;
+  return digits && ndot <= 1 && l > ndot;
+}
 __device__ void check_scalar(uint32_t kind, const uint8_t* p, uint32_t l, uint32_t* err) {
   switch (kind) {
-    case CK_INT: { int32_t v; if (parse_i32_text(p, l, &v)) set_err(err, VERR_BAD_INT); break; }
-    case CK_FLOAT: { float f; if (parse_f32_text(p, l, &f) == 1) set_err(err, VERR_BAD_FLOAT); break; }
-    case CK_STR: {
+    case CK_INT: { int32_t v; if (!swar_plain_number(p, l, false) && parse_i32_text(p, l, &v)) set_err(err, VERR_BAD_INT); break; }
+    case CK_FLOAT: if (!swar_plain_number(p, l, true) && !f32_text_ok(p, l)) set_err(err, VERR_BAD_FLOAT); break;
+    case CK_STR: {   // only an escape can make a string value an error
       bool esc = false;
-      for (uint32_t k = 0; k < l; k++) esc |= p[k] == '%';
+      uint32_t k = 0;
+      for (; k + 8 <= l && !esc; k += 8) esc = eq_mask8(((const dl_u64*)(p + k))->v, 0x2525252525252525ull) != 0;
+      for (; k < l; k++) esc |= p[k] == '%';
       if (esc) pct_decoded_len(p, l, &esc, err);
       break;
     }
@@ -583,6 +633,8 @@ __device__ __forceinline__ void info_entries(const uint8_t* __restrict__ u, uint
 __global__ __launch_bounds__(256) void k_vcf_keys(const uint8_t* __restrict__ u, VcfLines L, uint32_t* __restrict__ pos,
                                                    uint32_t* __restrict__ vend, uint8_t* __restrict__ flags, int need_end,
                                                    VcfTypeTable T, uint32_t* __restrict__ err) {
+  __shared__ VcfTypeSlot s_slots[VCF_TT_LDS_SLOTS];
+  if (need_end) T = stage_type_table(T, s_slots);
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= L.n_lines) return;
   uint64_t a, b;
@@ -852,6 +904,8 @@ __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restri
                                                           const uint8_t* __restrict__ key_unsupported, int K, VcfTypeTable T,
                                                           uint64_t* __restrict__ sp_off, uint32_t* __restrict__ sp_len,
                                                           uint8_t* __restrict__ sp_state, uint32_t* __restrict__ err) {
+  __shared__ VcfTypeSlot s_slots[VCF_TT_LDS_SLOTS];
+  T = stage_type_table(T, s_slots);
   const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= n) return;
   const uint64_t i = rows[r];
