@@ -76,6 +76,14 @@ struct VNode {
   DevBuf<uint64_t> d_off;      // utf8 / list: n + 1
   DevBuf<uint64_t> d_valid;
   HostBuf h_values, h_off, h_valid;
+  // utf8 / list nodes whose offsets fit 32 bits (every chunk of a stream; a whole partition mostly): the offsets cross the link as
+  // int32 and a batch is exported as an Arrow SLICE of the chunk's arrays (ArrowArray::offset) -- no per-batch rebasing, no
+  // repacking of validity bits on the host (export_node)
+  DevBuf<int32_t> d_off32;
+  HostBuf h_off32;
+  bool off32 = false;
+  mutable int64_t nulls_all = -1;   // NULLs of elements [0, nulls_hi), counted on first use (a list's child is exported whole)
+  mutable uint64_t nulls_hi = 0;
   std::vector<VNode> kids;
   VNode() = default;
   VNode(VNode&&) = default;
@@ -394,10 +402,14 @@ static void copy_node_to_host(VNode& nd, hipStream_t st) {
       break;
     case VK_UTF8:
       if (nd.d_values.p) d2h(nd.h_values, nd.d_values.p, nd.total);
-      if (nd.d_off.p) d2h(nd.h_off, nd.d_off.p, (nd.n + 1) * 8);
-      break;
+      [[fallthrough]];
     case VK_LIST:
-      if (nd.d_off.p) d2h(nd.h_off, nd.d_off.p, (nd.n + 1) * 8);
+      if (nd.d_off.p && nd.total < 0x7FFFFFFFull) {
+        nd.d_off32.alloc(nd.n + 1);
+        launch_off64_to_32(nd.d_off.p, nd.n + 1, nd.d_off32.p, st);
+        d2h(nd.h_off32, nd.d_off32.p, (nd.n + 1) * 4);
+        nd.off32 = true;
+      } else if (nd.d_off.p) d2h(nd.h_off, nd.d_off.p, (nd.n + 1) * 8);
       break;
     default: break;
   }
@@ -405,7 +417,7 @@ static void copy_node_to_host(VNode& nd, hipStream_t st) {
   for (auto& k : nd.kids) copy_node_to_host(k, st);
 }
 static void free_node_device(VNode& nd) {
-  nd.d_values.reset(); nd.d_off.reset(); nd.d_valid.reset();
+  nd.d_values.reset(); nd.d_off.reset(); nd.d_valid.reset(); nd.d_off32.reset();
   for (auto& k : nd.kids) free_node_device(k);
 }
 
@@ -462,7 +474,74 @@ static uint64_t copy_bits(const uint8_t* src, uint64_t bit0, uint64_t n, std::ve
   return set;
 }
 
+static uint64_t node_off(const VNode& nd, uint64_t i) {
+  return nd.off32 ? (uint64_t)((const int32_t*)nd.h_off32.p)[i] : ((const uint64_t*)nd.h_off.p)[i];
+}
+// every utf8 / list node of the subtree has its offsets as int32: rows [lo, hi) are a slice of the node's own buffers
+static bool sliceable(const VNode& nd) {
+  if ((nd.fd.kind == VK_UTF8 || nd.fd.kind == VK_LIST) && !nd.off32) return false;
+  for (auto& k : nd.kids) if (!sliceable(k)) return false;
+  return true;
+}
+static int64_t count_nulls(const VNode& nd, uint64_t lo, uint64_t hi) {
+  if (nd.all_valid || !nd.h_valid.p || hi <= lo) return 0;
+  auto range = [&](uint64_t a, uint64_t b) {   // set bits in [a, b)
+    const uint64_t* w = (const uint64_t*)nd.h_valid.p;
+    uint64_t set = 0;
+    for (uint64_t i = a >> 6; i <= (b - 1) >> 6; i++) {
+      uint64_t v = w[i];
+      if (i == a >> 6) v &= ~0ull << (a & 63);
+      if (i == (b - 1) >> 6 && (b & 63)) v &= (1ull << (b & 63)) - 1ull;
+      set += (uint64_t)__builtin_popcountll(v);
+    }
+    return set;
+  };
+  if (lo == 0 && hi > 8192) {   // a whole child array, asked for again by every batch of the chunk
+    if (nd.nulls_all < 0 || nd.nulls_hi != hi) { nd.nulls_all = (int64_t)(hi - range(0, hi)); nd.nulls_hi = hi; }
+    return nd.nulls_all;
+  }
+  return (int64_t)((hi - lo) - range(lo, hi));
+}
+// Rows [lo, hi) of a sliceable node as an Arrow slice: offset = lo over the node's own host buffers; a list's child is the
+// whole child array (the list's int32 offsets index it as they are).  O(nodes) per batch, whatever the batch holds.
+static void export_slice(const std::shared_ptr<VResult>& res, const VNode& nd, uint64_t lo, uint64_t hi, ArrowArray* out) {
+  ArrayPriv* pr = init_array(out, res, (int64_t)(hi - lo));
+  out->offset = (int64_t)lo;
+  out->null_count = count_nulls(nd, lo, hi);
+  pr->buffers.push_back(out->null_count ? (const void*)nd.h_valid.p : nullptr);
+  static const uint64_t zero = 0;
+  switch (nd.fd.kind) {
+    case VK_INT32: case VK_UINT32: case VK_FLOAT32: case VK_FLOAT64: case VK_BOOL:
+      pr->buffers.push_back(nd.h_values.p ? (const void*)nd.h_values.p : (const void*)&zero);
+      break;
+    case VK_UTF8:
+      pr->buffers.push_back(nd.h_off32.p);
+      pr->buffers.push_back(nd.h_values.p ? (const void*)nd.h_values.p : (const void*)"");
+      break;
+    case VK_LIST: {
+      pr->buffers.push_back(nd.h_off32.p);
+      std::unique_ptr<ArrowArray> item(new ArrowArray);
+      const VNode& ch = nd.kids.at(0);
+      export_slice(res, ch, 0, node_off(nd, nd.n), item.get());   // (the elements the node's offsets address)
+      pr->children.push_back(item.get());
+      pr->owned.push_back(std::move(item));
+      break;
+    }
+    case VK_STRUCT:
+      // (a struct's offset applies to its children on top of their own: they are exported whole)
+      for (auto& k : nd.kids) {
+        std::unique_ptr<ArrowArray> ca(new ArrowArray);
+        export_slice(res, k, 0, k.n, ca.get());
+        pr->children.push_back(ca.get());
+        pr->owned.push_back(std::move(ca));
+      }
+      break;
+  }
+  finish_array(out);
+}
+
 static void export_node(const std::shared_ptr<VResult>& res, const VNode& nd, uint64_t lo, uint64_t hi, ArrowArray* out) {
+  if (sliceable(nd) && hi > lo) { export_slice(res, nd, lo, hi, out); return; }
   const uint64_t len = hi - lo;
   ArrayPriv* pr = init_array(out, res, (int64_t)len);
   // validity
@@ -485,19 +564,17 @@ static void export_node(const std::shared_ptr<VResult>& res, const VNode& nd, ui
       pr->buffers.push_back(pr->local_bits2.data());
       break;
     case VK_UTF8: {
-      const uint64_t* o = (const uint64_t*)nd.h_off.p;
       pr->local_off.resize(len + 1);
-      const uint64_t b0 = len ? o[lo] : 0;
-      for (uint64_t k = 0; k <= len; k++) pr->local_off[k] = len ? (int32_t)(o[lo + k] - b0) : 0;
+      const uint64_t b0 = len ? node_off(nd, lo) : 0;
+      for (uint64_t k = 0; k <= len; k++) pr->local_off[k] = len ? (int32_t)(node_off(nd, lo + k) - b0) : 0;
       pr->buffers.push_back(pr->local_off.data());
       pr->buffers.push_back(nd.h_values.p ? nd.h_values.p + b0 : (const uint8_t*)"");
       break;
     }
     case VK_LIST: {
-      const uint64_t* o = (const uint64_t*)nd.h_off.p;
       pr->local_off.resize(len + 1);
-      const uint64_t b0 = len ? o[lo] : 0, b1 = len ? o[hi] : 0;
-      for (uint64_t k = 0; k <= len; k++) pr->local_off[k] = len ? (int32_t)(o[lo + k] - b0) : 0;
+      const uint64_t b0 = len ? node_off(nd, lo) : 0, b1 = len ? node_off(nd, hi) : 0;
+      for (uint64_t k = 0; k <= len; k++) pr->local_off[k] = len ? (int32_t)(node_off(nd, lo + k) - b0) : 0;
       pr->buffers.push_back(pr->local_off.data());
       std::unique_ptr<ArrowArray> item(new ArrowArray);
       export_node(res, nd.kids.at(0), b0, b1, item.get());
@@ -1484,7 +1561,7 @@ static void concat_nodes(VNode& dst, const std::vector<NodePiece>& ps) {
     }
     case VK_UTF8: {
       uint64_t bytes = 0;
-      for (auto& q : ps) if (q.hi > q.lo) { const uint64_t* o = (const uint64_t*)q.nd->h_off.p; bytes += o[q.hi] - o[q.lo]; }
+      for (auto& q : ps) if (q.hi > q.lo) bytes += node_off(*q.nd, q.hi) - node_off(*q.nd, q.lo);
       dst.total = bytes;
       dst.h_off.alloc((n + 1) * 8 + 16);
       dst.h_values.alloc(bytes + 16);
@@ -1493,11 +1570,10 @@ static void concat_nodes(VNode& dst, const std::vector<NodePiece>& ps) {
       d[0] = 0;
       for (auto& q : ps) {
         if (q.hi <= q.lo) continue;
-        const uint64_t* o = (const uint64_t*)q.nd->h_off.p;
-        const uint64_t b0 = o[q.lo];
-        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (o[k + 1] - b0);
-        if (o[q.hi] > b0) memcpy(dst.h_values.p + b, q.nd->h_values.p + b0, o[q.hi] - b0);
-        b += o[q.hi] - b0;
+        const uint64_t b0 = node_off(*q.nd, q.lo), b1 = node_off(*q.nd, q.hi);
+        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (node_off(*q.nd, k + 1) - b0);
+        if (b1 > b0) memcpy(dst.h_values.p + b, q.nd->h_values.p + b0, b1 - b0);
+        b += b1 - b0;
       }
       break;
     }
@@ -1509,11 +1585,10 @@ static void concat_nodes(VNode& dst, const std::vector<NodePiece>& ps) {
       std::vector<NodePiece> kid;
       for (auto& q : ps) {
         if (q.hi <= q.lo) continue;
-        const uint64_t* o = (const uint64_t*)q.nd->h_off.p;
-        const uint64_t b0 = o[q.lo];
-        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (o[k + 1] - b0);
-        b += o[q.hi] - b0;
-        kid.push_back(NodePiece{&q.nd->kids.at(0), b0, o[q.hi]});
+        const uint64_t b0 = node_off(*q.nd, q.lo), b1 = node_off(*q.nd, q.hi);
+        for (uint64_t k = q.lo; k < q.hi; k++) d[++pos] = b + (node_off(*q.nd, k + 1) - b0);
+        b += b1 - b0;
+        kid.push_back(NodePiece{&q.nd->kids.at(0), b0, b1});
       }
       dst.total = b;
       dst.kids.resize(1);

@@ -122,6 +122,7 @@ void launch_span_list_elems(const uint8_t* u, const uint64_t* off, const uint32_
                             uint32_t* pct_flag, uint32_t* err, hipStream_t st);
 void launch_pack_bits(const uint8_t* bytes, uint64_t n, uint64_t* words, hipStream_t st);
 void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st);
+void launch_off64_to_32(const uint64_t* off, uint64_t n, int32_t* out, hipStream_t st);   // (values below 2^31)
 
 // cmap[r]: nibble j < 15 = check kind (low 3 bits; bit 3 = list) of the row's FORMAT key j when that key is NOT one of the S
 // selected ones (a selected key: CK_CHAR when char_mask has its bit -- a Character scalar, extracted as a string --, else 0);

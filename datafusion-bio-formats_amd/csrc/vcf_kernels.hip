@@ -1147,6 +1147,13 @@ __global__ __launch_bounds__(256) void k_stride_offsets(uint64_t* off, uint64_t 
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k <= n) off[k] = k * stride;
 }
+__global__ __launch_bounds__(256) void k_off64_to_32(const uint64_t* __restrict__ off, uint64_t n, int32_t* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int32_t)off[i];
+}
+void launch_off64_to_32(const uint64_t* off, uint64_t n, int32_t* out, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_off64_to_32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, off, n, out);
+}
 void launch_stride_offsets(uint64_t* off, uint64_t n, uint64_t stride, hipStream_t st) {
   hipLaunchKernelGGL(k_stride_offsets, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, st, off, n, stride);
 }

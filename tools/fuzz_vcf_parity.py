@@ -394,6 +394,9 @@ def run(pkg, seconds=60.0, seed=1, max_files=None, verbose=True):
                     except AssertionError as e:
                         diverged("rows differ", ctx, names, str(e), path)
                         continue
+                    except Exception as e:   # (an exported batch pyarrow cannot read, ...)
+                        diverged("scan raised " + type(e).__name__, ctx, names, repr(e), path)
+                        continue
                 # the oracle refused: so must the GPU
                 try:
                     g = pkg.VcfTableProvider(path, kw.get("info_fields"), kw.get("format_fields"), None, kw.get("zero_based", True), kw.get("samples"))
