@@ -23,6 +23,7 @@ const char* inflate_status_str(uint32_t s) {
     case INF_SIZE_MISMATCH: return "ISIZE mismatch";
     case INF_BAD_STORED: return "invalid stored block";
     case INF_CRC_MISMATCH: return "CRC32 mismatch";
+    case 0xFF: return "no wave took the member (a bounded inflate launch ran out of scratch strides)";
     default: return "unknown";
   }
 }

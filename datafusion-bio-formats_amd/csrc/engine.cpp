@@ -769,6 +769,12 @@ struct BamExecState : ChunkProducer {
   uint64_t data_off[2] = {0, 0};  // where the inflated chunk starts inside ubuf[k]
   std::vector<WorkItem> items;
   size_t item = 0;
+  // the region predicates and the BAI chunk table of a region item on the device: constant for the item, uploaded when its
+  // first chunk asks for them (r03 re-uploaded both from pageable memory for every chunk)
+  DevBuf<RowSelect> d_sels;
+  DevBuf<uint64_t> d_chunks;
+  size_t sels_item = (size_t)-1;
+  int n_sels = 0;
   // position inside the current item
   bool item_open = false;
   uint32_t next_member = 0;
@@ -1010,25 +1016,30 @@ struct BamExecState : ChunkProducer {
     bool stop_item = last;
     if ((w.sel.mode == 1 || w.sel.mode == 3) && n_rec) {
       // region / no-coor items: one pass over the records decides every region of the decode (no key table)
-      std::vector<RowSelect> sels;
-      sels.push_back(w.sel);
-      for (auto& extra : w.more) sels.push_back(extra);
-      DevBuf<RowSelect> d_sels(sels.size());
-      HIP_CHECK(hipMemcpyAsync(d_sels.p, sels.data(), sels.size() * sizeof(RowSelect), hipMemcpyHostToDevice, st));
-      DevBuf<uint64_t> d_chunks(std::max<size_t>(w.chunk_tab.size(), 1));
-      if (!w.chunk_tab.empty()) HIP_CHECK(hipMemcpyAsync(d_chunks.p, w.chunk_tab.data(), w.chunk_tab.size() * 8, hipMemcpyHostToDevice, st));
+      if (sels_item != item) {
+        std::vector<RowSelect> sels;
+        sels.push_back(w.sel);
+        for (auto& extra : w.more) sels.push_back(extra);
+        n_sels = (int)sels.size();
+        d_sels.alloc(sels.size());
+        d_chunks.alloc(std::max<size_t>(w.chunk_tab.size(), 1));
+        HIP_CHECK(hipMemcpyAsync(d_sels.p, sels.data(), sels.size() * sizeof(RowSelect), hipMemcpyHostToDevice, st));
+        if (!w.chunk_tab.empty()) HIP_CHECK(hipMemcpyAsync(d_chunks.p, w.chunk_tab.data(), w.chunk_tab.size() * 8, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));   // (the staging vector goes out of scope)
+        sels_item = item;
+      }
       DevBuf<uint32_t> kerr(1), keep(n_rec);
       DevBuf<uint64_t> kscan(n_rec + 1), tmp(scan_tmp_elems(n_rec));
       HIP_CHECK(hipMemsetAsync(kerr.p, 0, 4, st));
       // u[0] is the first carried byte: the bytes of member m0 start carry_len further on
-      launch_row_flags_rec(u, rec_off.p, n_rec, d_sels.p, (int)sels.size(), d_terms.p, keep.p, kerr.p, st,
+      launch_row_flags_rec(u, rec_off.p, n_rec, d_sels.p, n_sels, d_terms.p, keep.p, kerr.p, st,
                            w.chunk_tab.empty() ? nullptr : d_chunks.p, p.blk_uoff[m0] - carry_len);
       launch_exclusive_scan_u32_to_u64(keep.p, kscan.p, n_rec, tmp.p, st);
       uint64_t tsel = 0;
       uint32_t e8 = 0;
       HIP_CHECK(hipMemcpyAsync(&tsel, kscan.p + n_rec, 8, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(&e8, kerr.p, 4, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));   // (the staging vector `sels` is done with as well)
+      HIP_CHECK(hipStreamSynchronize(st));
       throw_extract_err(e8);
       n_rows = tsel;
       rows_owned.alloc(std::max<uint64_t>(n_rows, 1));

@@ -891,9 +891,11 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
     uint32_t h = 0;
     if (lane == 0) {
       h = (slot * 0x9E3779B1u) % n_slots;
-      // every resident wave holds at most one stride and there are more strides than resident waves, so a free one turns
-      // up within a few probes; the probe count is bounded anyway: a wave that finds none takes no member and retires (the
-      // members it would have taken are decoded by the waves that follow)
+      // every resident wave holds at most one stride and there are more strides than resident waves (n_slots >= 1.05 x what the
+      // device holds), so a free one turns up within a few probes; the probe count is bounded anyway.  A wave that finds none
+      // takes no member and retires: the grid is exactly ceil(members / (waves x per_wave)), so ITS members stay undecoded --
+      // their status keeps the 0xFFFFFFFF the host wrote before the launch and the launch is reported as failed ("no wave took
+      // the member", bgzf_source.cpp).  Safe, never seen with the slot count above, and only reachable in the opt-in look-ahead.
       uint32_t tries = 0;
       while (atomicCAS(&slots[h], 0u, 1u) != 0u) {
         h = h + 1u == n_slots ? 0u : h + 1u;

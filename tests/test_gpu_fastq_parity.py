@@ -301,3 +301,17 @@ def test_chunked_stream_any_chunk_size(pkg, fo, tmp_path, chunk):
         else:
             assert sum(b.num_rows for b in got) == 100
             assert pa.Table.from_batches(got).equals(pa.Table.from_batches(want).slice(0, 100))
+
+
+def test_differential_fuzz_of_whole_files(pkg):
+    """tools/fuzz_fastq_parity.py, a fixed number of files: random record shapes, line ends and descriptions, plain / BGZF with GZI
+    / BGZF without, members of 60 .. 65 280 bytes, one file in eight with a broken record -- partition plans and every batch against
+    the oracle under random target_partitions, pipeline chunk sizes (down to one member), batch sizes, projections and limits; a
+    file one side refuses the other refuses too."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_fastq_parity as F
+    t, failures = F.run(pkg, seed=11, max_files=80, verbose=False)
+    assert not failures, failures[:3]
+    assert t["rows"] > 20000 and t["scans"] > 80, t
+    from conftest import report_size
+    report_size("test_differential_fuzz_of_whole_files[fastq]", **t)
