@@ -1110,9 +1110,14 @@ struct VcfRun {
       }
       // FORMAT
       if (sch.has_format && (geno_col >= 0 || !fmt_cols.empty())) {
-        std::vector<int> sel;  // FORMAT field indices to extract
-        if (geno_col >= 0) for (size_t k = 0; k < sch.format_fields.size(); k++) sel.push_back((int)k);
-        else for (auto& fc : fmt_cols) sel.push_back(fc.second);
+        std::vector<int> sel;   // FORMAT field indices to extract, in the order the kernels number them
+        std::vector<int> dst;   // where key s goes: child of `genotypes` (multi-sample) / entry of fmt_cols (single-sample)
+        if (geno_col >= 0) for (size_t k = 0; k < sch.format_fields.size(); k++) { sel.push_back((int)k); dst.push_back((int)k); }
+        else for (size_t k = 0; k < fmt_cols.size(); k++) { sel.push_back(fmt_cols[k].second); dst.push_back((int)k); }
+        // GT first: only the first VCF_MAX_DIRECT keys are parsed inside the cell kernel, and a genotype has to be (it is validated
+        // and sized there, and rendered again when an allele has leading zeros -- as the ninth key it would come out as written)
+        for (size_t k = 1; k < sel.size(); k++)
+          if (sch.format_fields[sel[k]] == "GT") { std::rotate(sel.begin(), sel.begin() + k, sel.begin() + k + 1); std::rotate(dst.begin(), dst.begin() + k, dst.begin() + k + 1); break; }
         const int S = (int)sel.size();
         std::string blob;
         std::vector<uint32_t> koff{0};
@@ -1149,8 +1154,8 @@ struct VcfRun {
           VNode& g = res->cols[geno_col];
           g.kids.resize((size_t)S);
           for (int s = 0; s < S; s++) {
-            VNode& lst = g.kids[s];
-            lst.fd = g.fd.children.at((size_t)s);
+            VNode& lst = g.kids[(size_t)dst[s]];
+            lst.fd = g.fd.children.at((size_t)dst[s]);
             lst.n = n;
             lst.total = N;
             lst.d_off.alloc(n + 1);
@@ -1161,7 +1166,7 @@ struct VcfRun {
             cx.arrow_bytes += (n + 1) * 4;
           }
         } else {
-          for (int s = 0; s < S; s++) leaf[s] = &res->cols[fmt_cols[s].first];
+          for (int s = 0; s < S; s++) leaf[s] = &res->cols[fmt_cols[(size_t)dst[s]].first];
         }
         VcfCellDirect D{};
         const uint64_t nwN = (N + 63) / 64;

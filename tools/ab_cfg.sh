@@ -4,6 +4,8 @@
 make -C tools >/dev/null 2>&1
 tools/_build/synth_bam /tmp/ab.bam 16384 42 >/dev/null 2>&1
 C=datafusion-bio-formats_amd/csrc
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/inflate_v3.hip; make -C $C >/dev/null 2>&1' EXIT
 IFS=';' read -ra CFGS <<< "${CFGS_STR:-}"
 [ ${#CFGS[@]} -eq 0 ] && CFGS=("")
 for cfg in "${CFGS[@]}"; do

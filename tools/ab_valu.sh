@@ -5,6 +5,8 @@ R=$GRAFT_REPO_ROOT
 make -C $R/tools >/dev/null 2>&1
 $R/tools/_build/synth_bam /tmp/ab.bam 16384 42 >/dev/null 2>&1
 C=$R/datafusion-bio-formats_amd/csrc
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/inflate_v3.hip; make -C $C >/dev/null 2>&1' EXIT
 cat > /tmp/ab_run.py <<PY
 import sys
 sys.path.insert(0, '$R/tests')

@@ -1,6 +1,8 @@
 #!/bin/bash
 # dev tool: per-kernel times of the extract at 65536 members (rocprofv3 --kernel-trace --stats) for the flags in $CFGS_STR
 C=datafusion-bio-formats_amd/csrc
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/bam_rows.hip; make -C $C >/dev/null 2>&1' EXIT
 O=$PWD/gpurun_out/extract_prof.txt
 mkdir -p gpurun_out; : > $O
 export TMPDIR=/tmp

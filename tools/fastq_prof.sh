@@ -1,6 +1,8 @@
 #!/bin/bash
 # dev tool: per-kernel times of the FASTQ bench (rocprofv3 --kernel-trace --stats) for the ';'-separated build flags in $CFGS_STR
 C=$GRAFT_REPO_ROOT/datafusion-bio-formats_amd/csrc
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/fastq_kernels.hip; make -C $C >/dev/null 2>&1' EXIT
 O=$GRAFT_REPO_ROOT/gpurun_out/fastq_prof.txt
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out; : > $O
 cd /tmp && export TMPDIR=/tmp

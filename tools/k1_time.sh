@@ -1,6 +1,8 @@
 #!/bin/bash
 # dev tool: K1 timing at 65536 members with the debug anatomy, for the build flags in $EXTRA (rebuilds, then restores)
 C=datafusion-bio-formats_amd/csrc
+# the product library is rebuilt in place per configuration: whatever ends this script, the default build comes back
+trap 'touch $C/inflate_v3.hip $C/bgzf_source.cpp; make -C $C >/dev/null 2>&1' EXIT
 O=gpurun_out/k1_time.txt
 mkdir -p gpurun_out; : > $O
 IFS=';' read -ra CFGS <<< "${CFGS_STR:-}"

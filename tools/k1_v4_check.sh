@@ -3,7 +3,8 @@
 # QUICK=1: inflate fuzz test only, no fuzz campaign; VERS="4": time only these versions; EXTRA=...: rebuild with flags first
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-.}
-if [ -n "$EXTRA" ]; then touch $R/datafusion-bio-formats_amd/csrc/inflate_v4.hip; fi
+# a build with EXTRA flags replaces the product library in place: whatever ends this script, the default build comes back
+if [ -n "$EXTRA" ]; then touch $R/datafusion-bio-formats_amd/csrc/inflate_v4.hip; trap 'touch $R/datafusion-bio-formats_amd/csrc/inflate_v4.hip; make -C $R/datafusion-bio-formats_amd/csrc >/dev/null 2>&1' EXIT; fi
 make -C $R/datafusion-bio-formats_amd/csrc EXTRA="$EXTRA" >/dev/null 2>&1 || { echo BUILD FAILED; exit 1; }
 O=$R/gpurun_out/k1_v4_check.txt
 mkdir -p $R/gpurun_out; : > $O
