@@ -1442,8 +1442,10 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
       n_rows = r;
-      // the last owned record must be complete: 4 newline-terminated lines, or the data really ends
-      if (n_rows * 4 > n_nl + (at_eof ? 1 : 0)) {
+      // the last record that is READ must be complete: 4 newline-terminated lines, or the data really ends (the reference
+      // stops reading at `limit` rows: a record cut short behind that is never looked at)
+      const uint64_t n_read = plan.limit >= 0 ? std::min<uint64_t>(n_rows, (uint64_t)plan.limit) : n_rows;
+      if (n_read * 4 > n_nl + (at_eof ? 1 : 0)) {
         if (!at_eof) { extra *= 4; continue; }
         throw Error("FASTQ read error: unexpected end of file inside a record");
       }
@@ -1685,9 +1687,11 @@ struct FastqExecState : ChunkProducer {
         cs = (v & ((1ull << 48) - 1)) + 1;   // (fastq_kernels.hip NL_POS: the low 48 bits are the position)
       } else if (complete) cs = L;           // (the file's last record, without its final newline)
       // the partition is over when a record that starts at or behind the threshold has been seen, or the data has
-      if (owned > complete && at_eof) throw Error("FASTQ read error: unexpected end of file inside a record");
       bool finished = none || owned < complete || origin + cs >= T || (at_eof && cs >= L);
-      if (plan.limit >= 0 && rows_emitted + n >= (uint64_t)plan.limit) { n = (uint64_t)plan.limit - rows_emitted; finished = true; }
+      const bool limit_ends_it = plan.limit >= 0 && rows_emitted + n >= (uint64_t)plan.limit;
+      if (limit_ends_it) { n = (uint64_t)plan.limit - rows_emitted; finished = true; }
+      // (a record cut short by the end of the file is an error only when the reference would read it: not behind `limit` rows)
+      else if (owned > complete && at_eof) throw Error("FASTQ read error: unexpected end of file inside a record");
       s.ms_chain += t.stop();
       s.n_records = n;
       s.n_rows = n;

@@ -170,6 +170,33 @@ def test_edge_cases(pkg, fo, tmp_path):
                 assert n == 400, (p_, target, n)
 
 
+@pytest.mark.parametrize("tail", ["@r9 d\nACGT", "@r9 d\nACGT\n", "@r9 d\r\nACGT\r\n", "@r9\n"])
+def test_record_cut_short_at_the_end_is_refused_by_both(pkg, fo, tmp_path, tail):
+    """A file that ends inside a record, before its '+' line: noodles reads the '+' with read_exact (UnexpectedEof), so the
+    reference's stream ends with an error -- on both sides here, plain and BGZF (tools/fuzz_fastq_parity.py seed 73 found the
+    oracle accepting such a record with an empty quality line).  A record whose quality line is merely missing its newline, or is
+    absent after a complete '+' line, is read."""
+    good = "".join(f"@r{i} x\nACGTACGT\n+\nIIIIIIII\n" for i in range(5))
+    for mode in ("plain", "bgzf"):
+        text = (good + tail).encode()
+        path = str(tmp_path / ("t.fastq" if mode == "plain" else "t.fastq.bgz"))
+        open(path, "wb").write(text if mode == "plain" else _bgzf([text[:70], text[70:]]))
+        orc = fo.FastqOracle(path)
+        strat, parts = orc.scan(1)
+        with pytest.raises(ValueError):
+            orc.execute(strat, parts[0])
+        with pytest.raises(pkg.BioscanError):
+            _run_gpu(pkg, path, 1)
+        ok = (good + "@r9 d\nACGT\n+\nIII").encode()          # the last line without its newline
+        open(path, "wb").write(ok if mode == "plain" else _bgzf([ok[:70], ok[70:]]))
+        orc = fo.FastqOracle(path)
+        strat, parts = orc.scan(1)
+        _, want = orc.execute(strat, parts[0])
+        _, _, got = _run_gpu(pkg, path, 1)
+        _cmp(got[0], want, (mode, "unterminated last line"))
+        assert sum(b.num_rows for b in got[0]) == 6
+
+
 def test_synthetic_fastq_partitions(pkg, fo, tmp_path):
     """medium scale: tools/synth_fastq (records straddle members), GPU == oracle per partition."""
     import json
