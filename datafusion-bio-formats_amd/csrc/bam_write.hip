@@ -333,7 +333,25 @@ void launch_ser_write(SerCols c, SerTags t, uint64_t n, const uint64_t* rec_off,
 // =================================================================================================================
 // BGZF deflate: one member per wavefront
 // =================================================================================================================
-constexpr int DF_HASH_BITS = 12;
+#ifndef DF_HASH_BITS_N
+#define DF_HASH_BITS_N 11
+#endif
+constexpr int DF_HASH_BITS = DF_HASH_BITS_N;
+#ifndef DF_WAYS
+#define DF_WAYS 6            // candidates per hash (the most recent positions): 6 x 2048 entries = 24 KB of LDS
+#endif
+// A short match far away costs more bits than the literals it replaces (zlib's TOO_FAR): length 3 only within DF_FAR3 bytes,
+// length 4 within DF_FAR4.  On config-2 payload (CPU model of this parse, tools/experiments/w2_parse_model.py): 2 ways 0.451 ->
+// 0.436 with the two rules alone, 4 ways 0.430, 8 ways 0.427; 64 ways WITHOUT them 0.437 -- the rules are worth more than
+// any number of candidates.  Measured on the GPU (tools/w2_variants.sh; 266 MB of config-2 payload; r03: 2 ways x 4096 without the
+// rules 0.4440 at 16.4 GB/s): 2 ways 0.4278 / 15.1 GB/s, 3 ways 0.4242 / 13.7, 4 x 2048 0.4239 / 12.0, 4 x 4096 0.4222 / 8.9 (LDS:
+// one wave per SIMD), **6 x 2048 0.4212 / 10.1 (the default)**, 8 x 2048 0.4199 / 6.2; zlib -6: 0.3949.
+#ifndef DF_FAR3
+#define DF_FAR3 128u
+#endif
+#ifndef DF_FAR4
+#define DF_FAR4 4096u
+#endif
 constexpr uint32_t DF_NONE = 0xFFFFu;
 constexpr int DF_WORDS = 160;  // staging window: a carried partial dword + 64 tokens of <= 48 bits (97 dwords); the block header (<= 75 dwords)
 constexpr int DF_NLIT = 286, DF_NDIST = 30, DF_NPRE = 19;
@@ -380,7 +398,7 @@ __device__ __forceinline__ void df_dist_sym(uint32_t dist, uint32_t* sym, uint32
 }
 
 struct DfLds {
-  uint16_t table[2][1 << DF_HASH_BITS];   // two ways: the two most recent positions of every hash
+  uint16_t table[DF_WAYS][1 << DF_HASH_BITS];   // the DF_WAYS most recent positions of every hash
   uint32_t W[DF_WORDS];
   uint32_t hl[DF_NLIT + 2], hd[DF_NDIST + 2], hp[DF_NPRE + 1];  // symbol counts
   uint32_t cl[DF_NLIT + 2], cd[DF_NDIST + 2], cp[DF_NPRE + 1];  // bit-reversed code << 8 | length
@@ -499,9 +517,9 @@ __device__ __forceinline__ void df_put(uint32_t* W, uint32_t* bitpos, uint32_t v
   *bitpos += nb;
 }
 
-// One BGZF member per wavefront.  Pass 1 parses (64 positions per step; a two-way 4096-entry hash table of 3-byte prefixes
-// proposes two candidates per lane, + the distance-1 candidate for runs; lazy evaluation; a scalar walk over the lanes' token
-// lengths picks the parse), stores the tokens and counts the symbols.  Then the block's own Huffman codes are built (df_build_code), the cost
+// One BGZF member per wavefront.  Pass 1 parses (64 positions per step; a DF_WAYS-way 4096-entry hash table of 3-byte prefixes
+// proposes its most recent candidates per lane, + the distance-1 candidate for runs; short matches far away are left to the
+// literals (DF_FAR3 / DF_FAR4); lazy evaluation; a scalar walk over the lanes' token lengths picks the parse), stores the tokens and counts the symbols.  Then the block's own Huffman codes are built (df_build_code), the cost
 // of the dynamic block (header included) is compared with the fixed code's, and pass 2 codes the tokens: bit offsets by a
 // wave prefix sum, bits OR-ed into an LDS window that is flushed as whole dwords.  A member whose coded form would be
 // larger than its payload is written as a stored block, so no member exceeds 64 KiB.
@@ -517,7 +535,10 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
   uint8_t* slot = slots + (uint64_t)m * slot_stride;
   uint8_t* data = slot + 18;  // DEFLATE stream (dwords are stored unaligned: gfx950 global stores need no alignment)
   uint32_t* tokens = tokens_all + (uint64_t)m * 65536u;
-  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) { L.table[0][k] = (uint16_t)DF_NONE; L.table[1][k] = (uint16_t)DF_NONE; }
+  for (int k = lane; k < (1 << DF_HASH_BITS); k += WAVE) {
+#pragma unroll
+    for (int w = 0; w < DF_WAYS; w++) L.table[w][k] = (uint16_t)DF_NONE;
+  }
   for (int k = lane; k < DF_NLIT + 2; k += WAVE) L.hl[k] = 0;
   if (lane < DF_NDIST + 2) L.hd[lane] = 0;
   if (lane < DF_NPRE + 1) L.hp[lane] = 0;
@@ -532,22 +553,30 @@ __global__ __launch_bounds__(WAVE) void k_bgzf_deflate(const uint8_t* __restrict
     uint32_t v = 0;
     if (inb) v = ((const bw_u32*)(in + p))->v;  // (the payload buffer is padded)
     const uint32_t h = ((v & 0xFFFFFFu) * 0x9E3779B1u) >> (32 - DF_HASH_BITS);
-    const uint32_t cand = can ? (uint32_t)L.table[0][h] : DF_NONE;
-    const uint32_t cand2 = can ? (uint32_t)L.table[1][h] : DF_NONE;
+    uint32_t cand[DF_WAYS];
+#pragma unroll
+    for (int w = 0; w < DF_WAYS; w++) cand[w] = can ? (uint32_t)L.table[w][h] : DF_NONE;
     df_sync();
-    // the newest position moves in, the previous newest moves to the second way (lanes with equal hashes: any of them is a
-    // valid candidate for later positions)
-    if (can) { L.table[1][h] = (uint16_t)cand; L.table[0][h] = (uint16_t)p; }
+    // the newest position moves in, the others move one way down (lanes with equal hashes: any of them is a valid candidate
+    // for later positions)
+    if (can) {
+#pragma unroll
+      for (int w = DF_WAYS - 1; w > 0; w--) L.table[w][h] = (uint16_t)cand[w - 1];
+      L.table[0][h] = (uint16_t)p;
+    }
     uint32_t best_len = 0, best_dist = 0;
     if (can) {
       const uint32_t cap = n - p < 258u ? n - p : 258u;
-      if (cand != DF_NONE && cand < p && p - cand <= 32768u) {
-        const uint32_t l = df_match_len(in + cand, in + p, cap);
-        if (l >= 3) { best_len = l; best_dist = p - cand; }
-      }
-      if (cand2 != DF_NONE && cand2 < p && p - cand2 <= 32768u && best_len < cap) {
-        const uint32_t l = df_match_len(in + cand2, in + p, cap);
-        if (l >= 3 && l > best_len) { best_len = l; best_dist = p - cand2; }
+#pragma unroll
+      for (int w = 0; w < DF_WAYS; w++) {
+        const uint32_t c = cand[w];
+        if (c != DF_NONE && c < p && p - c <= 32768u && best_len < cap) {
+          // (zlib's shortcut -- skip a candidate that does not continue where the best match so far ends -- was measured and is
+          // slower here, 10.1 -> 9.1 GB/s: the lanes run in lock step, so a wave pays for the full compare whenever one lane needs it)
+          const uint32_t l = df_match_len(in + c, in + p, cap);
+          const uint32_t d = p - c;
+          if (l >= 3 && l > best_len && !(l == 3 && d > DF_FAR3) && !(l == 4 && d > DF_FAR4)) { best_len = l; best_dist = d; }
+        }
       }
       if (p >= 1) {  // runs: the previous byte (positions of this very step are not in the table yet)
         const uint32_t l = df_match_len(in + p - 1, in + p, cap);
