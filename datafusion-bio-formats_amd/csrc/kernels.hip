@@ -493,19 +493,27 @@ __global__ void k_row_flags_rec(const uint8_t* __restrict__ u, const uint64_t* _
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t* r = u + rec_off[i];
-  const uint32_t bs = ld_u32(r), lrn = r[12], ncig = ld_u16(r + 16);
-  const int32_t lseq = ld_i32(r + 20);
+  // the 36-byte header as two 16-byte loads (the eight fields read one by one were eight dependent-free but separate requests
+  // to lines 300 bytes apart)
+  struct __attribute__((packed, aligned(1))) hdr16 { uint32_t x, y, z, w; };
+  const hdr16 h0 = *(const hdr16*)r, h1 = *(const hdr16*)(r + 16);
+  const uint32_t bs = h0.x, lrn = h0.w & 0xFFu, ncig = h1.x & 0xFFFFu;
+  const int32_t lseq = (int32_t)h1.y;
   if (lrn == 0 || lseq < 0 || 32ull + lrn + 4ull * ncig + (((uint64_t)(uint32_t)lseq + 1) >> 1) + (uint64_t)(uint32_t)lseq > (uint64_t)bs) {
     atomicExch(err, 8u);
     keep[i] = 0u;
     return;
   }
-  const int32_t refid = ld_i32(r + 4), pos = ld_i32(r + 8);
-  const uint32_t fm = ld_u16(r + 18) | ((uint32_t)r[13] << 16);
-  // the end needs the CIGAR: only records on a reference some region asks for pay for it
+  const int32_t refid = (int32_t)h0.y, pos = (int32_t)h0.z;
+  const uint32_t fm = (h1.x >> 16) | (((h0.w >> 8) & 0xFFu) << 16);
+  // The end needs the CIGAR (a dependent load on another line).  A region's overlap test asks `q_start1 <= end`: a record that
+  // starts behind the query's start passes it whatever its CIGAR says (end >= start - 1 >= q_start1), so only a record that starts
+  // at or before some region's query start on that region's reference pays for the CIGAR -- or one whose residual terms look at
+  // `end`.  (In a coordinate-sorted file those are the few records in front of each region.)
   bool want_end = false;
-  for (int k = 0; k < n_sel; k++) want_end = want_end || (sels[k].mode == 1 && sels[k].ref == refid);
-  const uint32_t end1 = want_end ? rec_end1(r) : 0u;
+  for (int k = 0; k < n_sel; k++)
+    want_end = want_end || (sels[k].mode == 1 && sels[k].ref == refid && (sels[k].n_terms != 0 || (int64_t)pos + 1 <= sels[k].q_start1));
+  const uint32_t end1 = want_end ? rec_end1(r) : (pos >= 0 ? (uint32_t)pos + 1u : 0u);
   bool kp = false;
   const uint64_t apos = buf_base_abs + rec_off[i];
   for (int k = 0; k < n_sel && !kp; k++) kp = row_verdict(sels[k], i, refid, pos, end1, fm, terms, chunk_tab, apos);
