@@ -655,30 +655,35 @@ struct LineIndex {
 struct DevTypeTable {
   DevBuf<uint8_t> keys;
   DevBuf<VcfTypeSlot> slots;
-  VcfTypeTable T{nullptr, nullptr, 0, CK_STR};
-  void build(const std::vector<std::pair<std::string, uint32_t>>& ents) {
-    T = VcfTypeTable{nullptr, nullptr, 0, CK_STR};
+  VcfTypeTable T{nullptr, nullptr, 0, CK_STR, 0};
+  // sel (optional): for every entry 1 + its index among the keys the scan extracts, 0 = none
+  void build(const std::vector<std::pair<std::string, uint32_t>>& ents, const std::vector<uint32_t>* sel = nullptr) {
+    T = VcfTypeTable{nullptr, nullptr, 0, CK_STR, 0};
     if (ents.empty()) return;
     uint32_t cap = 8;
     while (cap < 2 * ents.size()) cap *= 2;
     std::vector<VcfTypeSlot> h(cap, VcfTypeSlot{0, 0, 0});
     std::string blob;
-    for (auto& e : ents) {
+    bool sel_ok = sel != nullptr;
+    for (size_t ei = 0; ei < ents.size(); ei++) {
+      auto& e = ents[ei];
       uint64_t k8 = 0;
       for (size_t i = 0; i < e.first.size() && i < 8; i++) k8 |= (uint64_t)(uint8_t)e.first[i] << (8 * i);
       uint32_t i = vcf_key_hash(k8, (uint32_t)e.first.size()) & (cap - 1);
       bool dup = false;
       for (; h[i].len_kind; i = (i + 1) & (cap - 1))
-        if ((h[i].len_kind & 0xFFFFFFu) == e.first.size() && blob.compare(h[i].off, e.first.size(), e.first) == 0) { dup = true; break; }
+        if ((h[i].len_kind & 0xFFFFFFu) == e.first.size() && blob.compare(h[i].off & 0xFFFFu, e.first.size(), e.first) == 0) { dup = true; break; }
       if (dup) continue;   // (the first declaration of an id counts)
-      h[i] = VcfTypeSlot{k8, (uint32_t)blob.size(), (uint32_t)e.first.size() | ((e.second + 1u) << 24)};
+      if (blob.size() + e.first.size() > 0xFFFFu || (sel && (*sel)[ei] > 0xFFFFu)) sel_ok = false;
+      h[i] = VcfTypeSlot{k8, (uint32_t)blob.size() | (sel ? (*sel)[ei] << 16 : 0u), (uint32_t)e.first.size() | ((e.second + 1u) << 24)};
       blob += e.first;
     }
+    if (!sel_ok) for (auto& sl : h) sl.off &= 0xFFFFu;
     keys.alloc(blob.size() + 1);
     slots.alloc(cap);
     HIP_CHECK(hipMemcpy(keys.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(slots.p, h.data(), cap * sizeof(VcfTypeSlot), hipMemcpyHostToDevice));
-    T = VcfTypeTable{keys.p, slots.p, cap - 1, CK_STR};
+    T = VcfTypeTable{keys.p, slots.p, cap - 1, CK_STR, sel_ok ? 1u : 0u};
   }
 };
 static uint32_t scalar_check_kind(const std::string& type) {
@@ -904,11 +909,17 @@ struct VcfRun {
   void build_type_tables() {
     auto in = [](const std::vector<std::string>& v, const std::string& k) { return std::find(v.begin(), v.end(), k) != v.end(); };
     std::vector<std::pair<std::string, uint32_t>> e_end, e_info, e_fmt;
+    std::vector<uint32_t> info_sel;   // 1 + the index build_columns gives a projected INFO column (output order), 0 = not projected
+    std::vector<std::string> projected;
+    for (size_t c = 0; c < col_src.size(); c++)
+      if (col_src[c] >= 8 && col_src[c] < 8 + n_info) projected.push_back(sch.info_fields[(size_t)col_src[c] - 8]);
     uint32_t end_kind = CK_STR;
     bool seen_end = false;
     for (auto& d : p.hdr.infos) {
       e_end.emplace_back(d.id, info_check_kind(d, false));
       e_info.emplace_back(d.id, info_check_kind(d, in(sch.info_fields, d.id)));
+      const auto it = std::find(projected.begin(), projected.end(), d.id);
+      info_sel.push_back(it == projected.end() ? 0u : (uint32_t)(it - projected.begin()) + 1u);
       if (d.id == "END" && !seen_end) { seen_end = true; end_kind = info_check_kind(d, false); }
     }
     bool seen_gt = false;
@@ -920,7 +931,7 @@ struct VcfRun {
       VcfFieldDefn gt; gt.id = "GT"; gt.number = "1"; gt.type = "String";
       e_fmt.emplace_back(gt.id, format_check_kind(gt, sch.has_format && in(sch.format_fields, gt.id)));
     }
-    tt_end.build(e_end); tt_info.build(e_info); tt_format.build(e_fmt);
+    tt_end.build(e_end); tt_info.build(e_info, &info_sel); tt_format.build(e_fmt);
     need_end = want_end ? (int)(1u + end_kind) | (plan.indexed ? 0x100 : 0) : 0;
   }
   void line_keys(const TextSpan& t, LineIndex& li) {

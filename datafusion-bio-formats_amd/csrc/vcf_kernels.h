@@ -27,13 +27,16 @@ enum VcfCheckKind : uint32_t {
   CK_LIST = 8          // bit: a list whose elements (of the scalar kind in the low bits) are walked
 };
 // key8 = the key's first (up to) eight bytes, little endian, zero padded: most keys are compared and hashed as one 64-bit word;
-// the bytes of a longer key are at keys + off.  len_kind = length | (kind + 1) << 24; 0 = empty slot.
+// the bytes of a longer key are at keys + (off & 0xFFFF).  len_kind = length | (kind + 1) << 24; 0 = empty slot.  off >> 16 = 1 + the
+// index of the key among the keys the scan extracts (0: not one of them) -- k_vcf_info_locate finds a selected key with the same
+// lookup that types an unselected one (has_sel; r04: comparing every entry with each of the K selected keys was a third of the kernel).
 struct VcfTypeSlot { uint64_t key8; uint32_t off, len_kind; };
 struct VcfTypeTable {
   const uint8_t* keys;
   const VcfTypeSlot* slots;   // open addressing, linear probing, mask + 1 slots (a power of two, at most half full)
   uint32_t mask;
   uint32_t miss_kind;         // a key the header does not declare: String, Number=1 (noodles' default)
+  uint32_t has_sel;           // the slots carry selected-key indices
 };
 __host__ __device__ inline uint32_t vcf_key_hash(uint64_t key8, uint32_t n) {
   return (uint32_t)(((key8 ^ n) * 0x9E3779B97F4A7C15ull) >> 40);

@@ -506,7 +506,8 @@ __device__ __forceinline__ VcfTypeTable stage_type_table(VcfTypeTable T, VcfType
   }
   return T;
 }
-__device__ uint32_t type_lookup(const VcfTypeTable& T, const uint8_t* k, uint32_t kl) {
+__device__ uint32_t type_lookup(const VcfTypeTable& T, const uint8_t* k, uint32_t kl, uint32_t* sel = nullptr) {
+  if (sel) *sel = 0;
   if (T.slots == nullptr) return T.miss_kind;
   uint64_t k8 = ((const dl_u64*)k)->v;   // (reads past the key stay inside the text buffer's slack)
   if (kl < 8) k8 &= (1ull << (8 * kl)) - 1ull;
@@ -515,8 +516,8 @@ __device__ uint32_t type_lookup(const VcfTypeTable& T, const uint8_t* k, uint32_
     if (sl.len_kind == 0) return T.miss_kind;
     if (sl.key8 == k8 && (sl.len_kind & 0xFFFFFFu) == kl) {
       bool eq = true;
-      for (uint32_t i = 8; i < kl && eq; i++) eq = T.keys[sl.off + i] == k[i];
-      if (eq) return (sl.len_kind >> 24) - 1u;
+      for (uint32_t i = 8; i < kl && eq; i++) eq = T.keys[(sl.off & 0xFFFFu) + i] == k[i];
+      if (eq) { if (sel) *sel = sl.off >> 16; return (sl.len_kind >> 24) - 1u; }
     }
   }
 }
@@ -920,20 +921,28 @@ __global__ __launch_bounds__(256) void k_vcf_info_locate(const uint8_t* __restri
     const uint32_t kl = (uint32_t)(ke - q);
     const uint32_t vl = has_val ? (uint32_t)(ve - ke - 1) : 0u;
     const bool value = has_val && !(vl == 1 && u[ke + 1] == '.');
-    for (int k = 0; kl && k < K; k++) {
-      const uint32_t ko = key_off[k], kn = key_off[k + 1] - ko;
-      if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) {
-        const uint64_t o = (uint64_t)k * n + r;
-        if (sp_state[o]) set_err(err, VERR_DUP_INFO_KEY);
-        if (value && key_unsupported[k]) set_err(err, VERR_UNSUPPORTED_INFO);
-        sp_state[o] = has_val ? 1 : 2;
-        sp_off[o] = has_val ? ke + 1 : ke;
-        sp_len[o] = vl;
-        return false;
+    auto take = [&](int k) {
+      const uint64_t o = (uint64_t)k * n + r;
+      if (sp_state[o]) set_err(err, VERR_DUP_INFO_KEY);
+      if (value && key_unsupported[k]) set_err(err, VERR_UNSUPPORTED_INFO);
+      sp_state[o] = has_val ? 1 : 2;
+      sp_off[o] = has_val ? ke + 1 : ke;
+      sp_len[o] = vl;
+    };
+    uint32_t kind = 0, sel = 0;
+    if (T.has_sel) {
+      // one lookup says both: which selected key this is, or how the header types a key nothing is extracted for
+      kind = type_lookup(T, u + q, kl, &sel);
+      if (sel) { take((int)sel - 1); return false; }
+    } else {
+      for (int k = 0; kl && k < K; k++) {
+        const uint32_t ko = key_off[k], kn = key_off[k + 1] - ko;
+        if (kn == kl && bytes_eq(u + q, kl, keys + ko, kn)) { take(k); return false; }
       }
+      kind = type_lookup(T, u + q, kl);
     }
     // no column for this key: typed by the header all the same (see VcfCheckKind)
-    if (value) check_value(type_lookup(T, u + q, kl), u + ke + 1, vl, err);
+    if (value) check_value(kind, u + ke + 1, vl, err);
     return false;
   });
 }
