@@ -132,6 +132,10 @@ static uint32_t k1_retry_count(const uint32_t* ctr_dev, hipStream_t st) {
   return n;
 }
 
+// waves of the retry launch: a handful of members (config 2: a few per 65 536) do not need the whole device -- and dispatching
+// its 5 120 one-wave workgroups costs 0.7 ms; enough waves that finding the members in the status array stays a few loads each
+static uint32_t k1_retry_grid(uint32_t full, uint32_t n_retry) { return std::min<uint32_t>(full, std::max<uint32_t>(256u, 8u * n_retry)); }
+
 void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
   uint8_t* base = dst - blk_uoff[b0];
   HIP_CHECK(hipMemsetAsync(d_k1_ctr.p, 0, 256, stream));
@@ -141,9 +145,9 @@ void BgzfSource::launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0) {
     // members whose Huffman codes do not fit v4's table pool (it counts them in ctr[1]): the wide-table kernel, same stream --
     // launched only when there is one (an empty persistent grid still costs 0.7 ms of dispatch; the host waits for K1 here
     // instead, which it does a stage later anyway to look at the members' status)
-    if (k1_retry_count(d_k1_ctr.p, stream))
-      launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
-                             nullptr, stream, nullptr, 0, 0, 0, nullptr, true);
+    if (const uint32_t nr = k1_retry_count(d_k1_ctr.p, stream))
+      launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p,
+                             k1_retry_grid(k1_grid, nr), nullptr, stream, nullptr, 0, 0, 0, nullptr, true);
   } else {
     launch_bgzf_inflate_v3(d_comp.p, d_coff.p + b0, d_uoff.p + b0, base, nb, d_status.p + b0, d_k1_ctr.p, d_k1_scratch.p, k1_grid,
                            env_knobs().debug ? d_k1_ctr.p + 2 : nullptr, stream, nullptr, 0, 0, 0, nullptr);
@@ -240,9 +244,9 @@ void BgzfSource::launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* ds
   if (env_knobs().k1_version == 4 && !c.n_slots) {
     launch_bgzf_inflate_v4(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
                            env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, nullptr, 0, 0, 0, k0 ? c.pre.p : nullptr);
-    if (k1_retry_count(c.ctr.p, c.stream))
-      launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
-                             nullptr, c.stream, nullptr, 0, 0, 0, nullptr, true);
+    if (const uint32_t nr = k1_retry_count(c.ctr.p, c.stream))
+      launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p,
+                             k1_retry_grid(c.grid, nr), nullptr, c.stream, nullptr, 0, 0, 0, nullptr, true);
   } else {
     launch_bgzf_inflate_v3(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, base, nb, status, c.ctr.p, c.scratch.p, c.grid,
                            env_knobs().debug ? c.ctr.p + 2 : nullptr, c.stream, c.n_slots ? c.slots.p : nullptr, c.n_slots,

@@ -110,6 +110,7 @@ struct __attribute__((aligned(16))) V3Lds {
   uint16_t null_slot[7];  // must follow be_lut: self-pointing entries a stopped lane idles on (see v3_pass)
   uint16_t eob_fix;       // bits a lane over-consumed when it followed the end-of-block pointer (see E_EOB)
   uint32_t bnd_slot, bnd_budget;  // bounded launches: the scratch stride this wave borrowed, members it may still take
+  uint32_t rt_lo, rt_hi, rt_base; // retry launches: members of the current group of 64 still to be decoded (a bit each), the group's first member
   uint32_t pre_lo, pre_hi;        // K0's records (address, or 0), parked here for the same reason as blk_final
   uint32_t blk_final;             // BFINAL of the block being decoded (kept here, not in a register: the kernel is at its SGPR limit)
 #ifdef V3_PAD_LDS
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
   const int lane = threadIdx.x & 63;
   if constexpr (RETRY) {
     if (uni2(counter[1]) == 0u) return;
-    if (lane == 0) L.bnd_budget = blockIdx.x;
+    if (lane == 0) { L.bnd_budget = blockIdx.x * 64u; L.rt_lo = 0u; L.rt_hi = 0u; L.rt_base = 0u; }
   }
   // Two launch shapes.  PERSISTENT (slots == nullptr): the grid is what the device holds at once, every wave owns scratch
   // stride blockIdx and pulls members from the atomic counter until none is left.  BOUNDED (slots != nullptr): workgroups
@@ -961,14 +962,24 @@ __global__ __launch_bounds__(WAVE * WPW, V3_WAVES_PER_EU) void k_bgzf_inflate_v3
     }
     uint32_t b = 0;
     if constexpr (RETRY) {
-      // (no shared counter: 65 536 atomic pulls to find 80 members took a quarter as long as the launch they repair; every
-      // wave looks at its own stride of the status array)
-      b = uni2(L.bnd_budget);  // the wave's next member, parked in LDS like the bounded shape's loop state
+      // (no shared counter: 65 536 atomic pulls to find 80 members took a quarter as long as the launch they repair.)  A wave
+      // looks at the status array 64 members at a time -- one coalesced load, one ballot -- in its own stride of such groups, so a
+      // small grid finds a handful of members in a few loads per wave; the loop state is parked in LDS like the bounded shape's
       V3_SYNC();
-      if (lane == 0) L.bnd_budget = b + gridDim.x;
+      unsigned long long pend = (unsigned long long)uni2(L.rt_lo) | (unsigned long long)uni2(L.rt_hi) << 32;
+      uint32_t gbase = uni2(L.rt_base), nxt = uni2(L.bnd_budget);
+      while (pend == 0ull && nxt < n_blocks) {
+        gbase = nxt;
+        nxt += 64u * gridDim.x;
+        const uint32_t bi = gbase + (uint32_t)lane;
+        pend = __ballot(bi < n_blocks && status[bi] == (uint32_t)INF_RETRY);
+      }
+      if (pend == 0ull) break;
+      b = gbase + (uint32_t)__builtin_ctzll(pend);
+      pend &= pend - 1ull;
       V3_SYNC();
-      if (b >= n_blocks) break;
-      if (uni2(status[b]) != (uint32_t)INF_RETRY) continue;
+      if (lane == 0) { L.rt_lo = (uint32_t)pend; L.rt_hi = (uint32_t)(pend >> 32); L.rt_base = gbase; L.bnd_budget = nxt; }
+      V3_SYNC();
     } else {
       if (lane == 0) b = atomicAdd(counter, 1u);
       b = uni2(b);
