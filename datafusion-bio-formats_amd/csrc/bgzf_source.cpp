@@ -257,11 +257,13 @@ void BgzfSource::launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, 
   launch_inflate_to(c, img, dst, nb, b0, c.status.p);
 }
 
-void BgzfSource::launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st) {
-  launch_bgzf_crc32(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, dst - blk_uoff[b0], nb, status, st);
+void BgzfSource::launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st,
+                               uint32_t* nl_cnt, uint64_t nl_head) {
+  if (nl_cnt && (((uintptr_t)dst - nl_head) & 15)) throw Error("internal: text buffer not 16-byte aligned");
+  launch_bgzf_crc32(img.comp_base, img.d_coff.p + b0, img.d_uoff.p + b0, dst - blk_uoff[b0], nb, status, st, nl_cnt, nl_head - blk_uoff[b0]);
 }
-void BgzfSource::launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0) {
-  launch_crc_on(img, dst, nb, b0, c.status.p, c.stream);
+void BgzfSource::launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* nl_cnt, uint64_t nl_head) {
+  launch_crc_on(img, dst, nb, b0, c.status.p, c.stream, nl_cnt, nl_head);
 }
 
 void BgzfSource::check_inflate_status_on(uint32_t* status, hipStream_t st, uint32_t b0, uint32_t nb) {
@@ -280,8 +282,9 @@ void BgzfSource::check_inflate_status_on(uint32_t* status, hipStream_t st, uint3
 }
 void BgzfSource::check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb) { check_inflate_status_on(c.status.p, c.stream, b0, nb); }
 
-void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0) {
-  launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream);
+void BgzfSource::launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* nl_cnt, uint64_t nl_head) {
+  if (nl_cnt && (((uintptr_t)dst - nl_head) & 15)) throw Error("internal: text buffer not 16-byte aligned");
+  launch_bgzf_crc32(d_comp.p, d_coff.p + b0, d_uoff.p + b0, dst - blk_uoff[b0], nb, d_status.p + b0, stream, nl_cnt, nl_head - blk_uoff[b0]);
 }
 
 void BgzfSource::report_k1_debug(uint32_t nb) { report_k1_debug(d_k1_ctr.p, nb); }

@@ -82,7 +82,8 @@ struct BgzfSource {
   void make_resident();
   // Inflate members [b0, b0+nb) so that member b0's payload lands at dst[0].
   void launch_inflate(uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
-  void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0);
+  // nl_cnt / nl_head (FASTQ): per-tile newline counts of the text buffer in which `dst` lies nl_head bytes behind the start
+  void launch_crc(const uint8_t* dst, uint32_t nb, uint32_t b0 = 0, uint32_t* nl_cnt = nullptr, uint64_t nl_head = 0);
   void report_k1_debug(uint32_t nb);
   void report_k1_debug(const uint32_t* ctr_dev, uint32_t nb);  // BIOSCAN_DEBUG=1: pass / phase counters of the last K1 launch
   void check_inflate_status(uint32_t b0, uint32_t nb);
@@ -95,12 +96,13 @@ struct BgzfSource {
   std::shared_ptr<DeviceImage> build_image(int dev, uint32_t m_lo, uint32_t m_hi);
   void init_ctx(K1Ctx& c, const DeviceImage& img, uint32_t max_members, bool oneshot = false);
   void launch_inflate(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0);
-  void launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0);
+  void launch_crc(K1Ctx& c, const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* nl_cnt = nullptr, uint64_t nl_head = 0);
   void check_inflate_status(K1Ctx& c, uint32_t b0, uint32_t nb);
   // the same three steps with the status slots and the stream named by the caller (look-ahead inflate: K1 of the next
   // chunk runs on the context's stream while CRC and the status check of this chunk run on the execute's own stream)
   void launch_inflate_to(K1Ctx& c, const DeviceImage& img, uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status);
-  void launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st);
+  void launch_crc_on(const DeviceImage& img, const uint8_t* dst, uint32_t nb, uint32_t b0, uint32_t* status, hipStream_t st,
+                     uint32_t* nl_cnt = nullptr, uint64_t nl_head = 0);
   void check_inflate_status_on(uint32_t* status, hipStream_t st, uint32_t b0, uint32_t nb);
   // Inflate blocks [0, b1) into a temporary device buffer and copy to the host (header / sampling).
   std::vector<uint8_t> inflate_prefix_to_host(uint32_t b1);

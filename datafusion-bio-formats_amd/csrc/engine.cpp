@@ -1354,6 +1354,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
   DevBuf<uint64_t> nl, nl_base, tmp;
   DevBuf<uint32_t> nl_cnt;
   uint64_t n_nl = 0, x0 = 0, n_rows = 0, base = 0, hi = 0;
+  const uint64_t* nlp = nullptr;   // the index entries from x0 on
   const uint8_t* u = nullptr;
   uint32_t extra = 2;
   for (;;) {
@@ -1368,8 +1369,12 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       t.start();
       p.launch_inflate(p.d_u.p, b_hi - b_start, b_start);
       res->stats.ms_inflate += t.stop();
+      // K2 counts the newlines of every 16 KiB tile of the text while it reads it for the CRC (crc32.hip): the count pass of
+      // the newline index -- one more sweep over the text, 8 of the 18 ms of the index on the bench's file -- is not run
+      nl_cnt.alloc(nl_chunks(0, bytes) + 1);
+      HIP_CHECK(hipMemsetAsync(nl_cnt.p, 0, (nl_chunks(0, bytes) + 1) * 4, p.stream));
       t.start();
-      p.launch_crc(p.d_u.p, b_hi - b_start, b_start);
+      p.launch_crc(p.d_u.p, b_hi - b_start, b_start, nl_cnt.p, 0);
       res->stats.ms_crc += t.stop();
       p.check_inflate_status(b_start, b_hi - b_start);
       u = p.d_u.p;
@@ -1423,21 +1428,44 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
     }
     n_rows = 0;
     n_nl = 0;
+    nlp = nullptr;
     if (!none && x0 < hi - base) {
-      // ---- newline index of [x0, hi) ----
-      const uint64_t nch = nl_chunks(x0, hi - base);
-      nl_cnt.alloc(nch + 1);
-      nl_base.alloc(nch + 2);
-      tmp.alloc(scan_tmp_elems(nch));
-      launch_nl_count(u, x0, hi - base, nl_cnt.p, st);
-      launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
-      HIP_CHECK(hipMemcpyAsync(&n_nl, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      nl.alloc(n_nl + 1);
-      launch_nl_write(u, x0, hi - base, nl_base.p, nl.p, st);
+      if (bgzf) {
+        // ---- newline index of the whole buffer from K2's tile counts; the entries in front of x0 are skipped ----
+        const uint64_t nch = nl_chunks(0, hi - base);
+        nl_base.alloc(nch + 2);
+        tmp.alloc(scan_tmp_elems(nch));
+        launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
+        uint64_t n_all = 0;
+        HIP_CHECK(hipMemcpyAsync(&n_all, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        nl.alloc(n_all + 1);
+        launch_nl_write(u, 0, hi - base, nl_base.p, nl.p, st);
+        unsigned long long skip = 0;
+        if (x0) {
+          launch_nl_lower_bound(nl.p, n_all, x0, d_res.p, st);
+          HIP_CHECK(hipMemcpyAsync(&skip, d_res.p, 8, hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+        }
+        nlp = nl.p + skip;
+        n_nl = n_all - skip;
+      } else {
+        // ---- newline index of [x0, hi) ----
+        const uint64_t nch = nl_chunks(x0, hi - base);
+        nl_cnt.alloc(nch + 1);
+        nl_base.alloc(nch + 2);
+        tmp.alloc(scan_tmp_elems(nch));
+        launch_nl_count(u, x0, hi - base, nl_cnt.p, st);
+        launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
+        HIP_CHECK(hipMemcpyAsync(&n_nl, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        nl.alloc(n_nl + 1);
+        launch_nl_write(u, x0, hi - base, nl_base.p, nl.p, st);
+        nlp = nl.p;
+      }
       // ---- how many records start before T ----
       const uint64_t T_rel = T > base ? T - base : 0;
-      launch_fastq_count_owned(nl.p, n_nl, x0, hi - base, T_rel, d_res.p, st);
+      launch_fastq_count_owned(nlp, n_nl, x0, hi - base, T_rel, d_res.p, st);
       unsigned long long r = 0;
       HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -1478,7 +1506,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
     }
     const uint64_t n_tiles = (n + ROWS_TILE - 1) / ROWS_TILE;
     DevBuf<uint64_t> tile_sums(bam_rows_scratch_elems(n));
-    launch_fastq_pass1(u, x0, hi - base, nl.p, n_nl, n, fc, tile_sums.p, err.p, st);
+    launch_fastq_pass1(u, x0, hi - base, nlp, n_nl, n, fc, tile_sums.p, err.p, st);
     uint64_t totals[4] = {0, 0, 0, 0};
     for (int k = 0; k < 4; k++)
       if ((fc.want >> k) & 1u) HIP_CHECK(hipMemcpyAsync(&totals[k], tile_sums.p + (uint64_t)k * (n_tiles + 1) + n_tiles, 8, hipMemcpyDeviceToHost, st));
@@ -1495,7 +1523,7 @@ static std::shared_ptr<Result> run_partition_fastq(const Plan& plan, int partiti
       fc.val[k] = col.d_values.p; fc.off32[k] = col.d_off32.p; fc.base[k] = col.d_base.p;
       arrow_bytes += totals[k] + nb * ((uint64_t)batch_size + 1) * 4;
     }
-    launch_fastq_pass2(u, x0, hi - base, nl.p, n_nl, n, fc, batch_size, 0, tile_sums.p, st);
+    launch_fastq_pass2(u, x0, hi - base, nlp, n_nl, n, fc, batch_size, 0, tile_sums.p, st);
     HIP_CHECK(hipStreamSynchronize(st));
   }
   res->stats.ms_extract = t.stop();
@@ -1611,13 +1639,19 @@ struct FastqExecState : ChunkProducer {
       }
       uint8_t* u = ubuf[cur].p;
       const bool at_eof = m1 == p.n_blocks();
+      DevBuf<uint32_t> nl_cnt;   // newlines per 16 KiB tile of u[0, L)
       if (m1 > m0) {
         if (k1.status.n < m1 - m0) p.init_ctx(k1, *img, m1 - m0, false);
         t.start();
         p.launch_inflate(k1, *img, u + carry_len, m1 - m0, m0);
         s.ms_inflate += t.stop();
+        // K2 counts the newlines per 16 KiB tile of the buffer while it reads the members for their CRC; the carried bytes in
+        // front of them are counted into the same tiles here (fastq_kernels.hip: k_nl_count, add mode)
+        nl_cnt.alloc(nl_chunks(0, L) + 1);
+        HIP_CHECK(hipMemsetAsync(nl_cnt.p, 0, (nl_chunks(0, L) + 1) * 4, st));
+        if (carry_len) launch_nl_count(u, 0, carry_len, nl_cnt.p, st, true);
         t.start();
-        p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0);
+        p.launch_crc(k1, *img, u + carry_len, m1 - m0, m0, nl_cnt.p, carry_len);
         s.ms_crc += t.stop();
         p.check_inflate_status(k1, m0, m1 - m0);
       }
@@ -1656,20 +1690,31 @@ struct FastqExecState : ChunkProducer {
       }
       uint64_t n_nl = 0, owned = 0;
       DevBuf<uint64_t> nl, nl_base, tmp;
-      DevBuf<uint32_t> nl_cnt;
+      const uint64_t* nlp = nullptr;   // the index entries from x0 on
       if (!none && x0 < L) {
-        const uint64_t nch = nl_chunks(x0, L);
-        nl_cnt.alloc(nch + 1);
+        const uint64_t nch = nl_chunks(0, L);
         nl_base.alloc(nch + 2);
         tmp.alloc(scan_tmp_elems(nch));
-        launch_nl_count(u, x0, L, nl_cnt.p, st);
+        if (m1 == m0) {   // (no member in this chunk: nothing has been counted)
+          nl_cnt.alloc(nch + 1);
+          launch_nl_count(u, 0, L, nl_cnt.p, st);
+        }
         launch_exclusive_scan_u32_to_u64(nl_cnt.p, nl_base.p, nch, tmp.p, st);
-        HIP_CHECK(hipMemcpyAsync(&n_nl, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
+        uint64_t n_all = 0;
+        HIP_CHECK(hipMemcpyAsync(&n_all, nl_base.p + nch, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        nl.alloc(n_nl + 1);
-        launch_nl_write(u, x0, L, nl_base.p, nl.p, st);
+        nl.alloc(n_all + 1);
+        launch_nl_write(u, 0, L, nl_base.p, nl.p, st);
+        unsigned long long skip = 0;
+        if (x0) {
+          launch_nl_lower_bound(nl.p, n_all, x0, d_res.p, st);
+          HIP_CHECK(hipMemcpyAsync(&skip, d_res.p, 8, hipMemcpyDeviceToHost, st));
+          HIP_CHECK(hipStreamSynchronize(st));
+        }
+        nlp = nl.p + skip;
+        n_nl = n_all - skip;
         const uint64_t T_rel = T > origin ? T - origin : 0;
-        launch_fastq_count_owned(nl.p, n_nl, x0, L, T_rel, d_res.p, st);
+        launch_fastq_count_owned(nlp, n_nl, x0, L, T_rel, d_res.p, st);
         unsigned long long r = 0;
         HIP_CHECK(hipMemcpyAsync(&r, d_res.p, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1682,7 +1727,7 @@ struct FastqExecState : ChunkProducer {
       uint64_t cs = none ? L : x0;
       if (complete && 4 * complete - 1 < n_nl) {
         uint64_t v = 0;
-        HIP_CHECK(hipMemcpyAsync(&v, nl.p + 4 * complete - 1, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&v, nlp + 4 * complete - 1, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         cs = (v & ((1ull << 48) - 1)) + 1;   // (fastq_kernels.hip NL_POS: the low 48 bits are the position)
       } else if (complete) cs = L;           // (the file's last record, without its final newline)
@@ -1698,7 +1743,7 @@ struct FastqExecState : ChunkProducer {
       // ---- the chunk's rows ----
       std::shared_ptr<Result> res;
       t.start();
-      if (n) res = extract(u, x0, L, nl.p, n_nl, n, &s);
+      if (n) res = extract(u, x0, L, nlp, n_nl, n, &s);
       s.ms_extract = t.stop();
       s.ms_total_gpu = s.ms_inflate + s.ms_crc + s.ms_chain + s.ms_extract;
       accumulate(s);

@@ -114,7 +114,9 @@ __device__ __forceinline__ uint32_t nl_thread_masks(const uint8_t* __restrict__ 
   }
   return n;
 }
-__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi, uint32_t* __restrict__ cnt) {
+// add: the counts are added to cnt (tiles K2 has counted the member bytes of -- crc32.hip -- get the bytes in front of the first
+// member, the record carried from the previous chunk, this way)
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi, uint32_t* __restrict__ cnt, int add) {
   __shared__ uint32_t s_w[4];
   const uint64_t a = lo + (uint64_t)blockIdx.x * NL_CHUNK + (uint64_t)threadIdx.x * NL_PER_THREAD;
   uint64_t m[8];
@@ -123,7 +125,22 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t* __restrict__ u,
   for (int d = 32; d >= 1; d >>= 1) n += __shfl_down(n, d, 64);
   if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = n;
   __syncthreads();
-  if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (add) { if (t) atomicAdd(&cnt[blockIdx.x], t); } else cnt[blockIdx.x] = t;
+  }
+}
+// number of entries of the newline index whose position is below x (entries are in position order)
+__global__ void k_nl_lower_bound(const uint64_t* __restrict__ nl, uint64_t n, uint64_t x, unsigned long long* out) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if ((nl[mid] & NL_POS) < x) lo = mid + 1; else hi = mid;
+  }
+  *out = lo;
+}
+void launch_nl_lower_bound(const uint64_t* nl, uint64_t n, uint64_t x, unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_nl_lower_bound, dim3(1), dim3(1), 0, st, nl, n, x, out);
 }
 __global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ u, uint64_t lo, uint64_t hi,
                                                    const uint64_t* __restrict__ base, uint64_t* __restrict__ nl) {
@@ -168,10 +185,10 @@ __global__ __launch_bounds__(256) void k_nl_write(const uint8_t* __restrict__ u,
   }
 }
 uint64_t nl_chunks(uint64_t lo, uint64_t hi) { return hi > lo ? (hi - lo + NL_CHUNK - 1) / NL_CHUNK : 0; }
-void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st) {
+void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st, bool add) {
   const uint64_t n = nl_chunks(lo, hi);
   if (!n) return;
-  hipLaunchKernelGGL(k_nl_count, dim3((uint32_t)n), dim3(256), 0, st, u, lo, hi, cnt);
+  hipLaunchKernelGGL(k_nl_count, dim3((uint32_t)n), dim3(256), 0, st, u, lo, hi, cnt, add ? 1 : 0);
 }
 void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base, uint64_t* nl, hipStream_t st) {
   const uint64_t n = nl_chunks(lo, hi);

@@ -45,8 +45,11 @@ void launch_bgzf_inflate_v4(const uint8_t* comp, const uint64_t* blk_coff, const
 constexpr uint32_t V3_PRE_DWORDS = 42;
 void launch_bgzf_headers(const uint8_t* comp, const uint64_t* blk_coff, uint32_t n_blocks, uint32_t* rec, hipStream_t st);
 // K2: CRC32 of each inflated block vs the BGZF trailer (validation mode).
+// nl_cnt != nullptr (FASTQ): also adds the newlines of every 16 KiB tile of the text buffer to nl_cnt[tile] (zeroed by the caller);
+// a member byte at inflated offset o lies at buffer position o + nl_bias, and the buffer starts on a 16-byte boundary.
 void launch_bgzf_crc32(const uint8_t* comp, const uint64_t* blk_coff, const uint64_t* blk_uoff,
-                       const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st);
+                       const uint8_t* out, uint32_t n_blocks, uint32_t* status, hipStream_t st, uint32_t* nl_cnt = nullptr,
+                       uint64_t nl_bias = 0);
 
 // ---- scans ------------------------------------------------------------------------------------
 // out[0..n] exclusive prefix sums of in[0..n) (out has n+1 entries); tmp must hold
@@ -216,7 +219,8 @@ void launch_fastq_sync(const uint8_t* u, uint64_t start, uint64_t ulen, const ui
                        const uint64_t* win_next, uint32_t n_win, uint64_t end_comp, int check_end, unsigned long long* result,
                        hipStream_t st);
 uint64_t nl_chunks(uint64_t lo, uint64_t hi);
-void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st);
+void launch_nl_count(const uint8_t* u, uint64_t lo, uint64_t hi, uint32_t* cnt, hipStream_t st, bool add = false);
+void launch_nl_lower_bound(const uint64_t* nl, uint64_t n, uint64_t x, unsigned long long* out, hipStream_t st);
 void launch_nl_write(const uint8_t* u, uint64_t lo, uint64_t hi, const uint64_t* base, uint64_t* nl, hipStream_t st);
 void launch_fastq_count_owned(const uint64_t* nl, uint64_t n_nl, uint64_t x0, uint64_t eof, uint64_t limit_off,
                               unsigned long long* result, hipStream_t st);
