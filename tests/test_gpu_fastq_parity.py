@@ -330,6 +330,31 @@ def test_chunked_stream_any_chunk_size(pkg, fo, tmp_path, chunk):
             assert pa.Table.from_batches(got).equals(pa.Table.from_batches(want).slice(0, 100))
 
 
+@pytest.mark.parametrize("chunk", [1, 2, 0])
+def test_long_reads_across_many_members(pkg, fo, tmp_path, chunk):
+    """Reads of 20 .. 90 kb (a nanopore-like file): a record spans several 64 KiB members, so a chunk of one member holds no
+    complete record and the bytes carried to the next chunk cover several 16 KiB tiles of the text buffer -- the tiles whose
+    newlines are counted partly by K2 (member bytes) and partly by the carry's own count (csrc/crc32.hip, fastq_kernels.hip)."""
+    import random
+    rng = random.Random(5 + chunk)
+    recs = []
+    for i in range(40):
+        ln = rng.choice([20000, 33000, 65536, 90000, rng.randint(1, 50)])
+        seq = "".join(rng.choice("ACGT") for _ in range(64)) * (ln // 64) + "A" * (ln % 64)
+        eol = rng.choice(["\n", "\r\n"])
+        recs.append(f"@long{i} ch={i % 5}{eol}{seq}{eol}+{eol}{'5' * len(seq)}{eol}")
+    text = "".join(recs).encode()
+    path = str(tmp_path / "long.fastq.bgz")
+    open(path, "wb").write(_bgzf([text[o:o + 65280] for o in range(0, len(text), 65280)]))
+    orc = fo.FastqOracle(path)
+    strat, parts = orc.scan(1)
+    _, want = orc.execute(strat, parts[0], batch_size=7)
+    prov = pkg.FastqTableProvider(path, chunk_members=chunk)
+    got = list(prov.scan().execute(0, 7))
+    _cmp(got, want, ("long reads", chunk))
+    assert sum(b.num_rows for b in got) == 40
+
+
 def test_differential_fuzz_of_whole_files(pkg):
     """tools/fuzz_fastq_parity.py, a fixed number of files: random record shapes, line ends and descriptions, plain / BGZF with GZI
     / BGZF without, members of 60 .. 65 280 bytes, one file in eight with a broken record -- partition plans and every batch against
