@@ -507,7 +507,9 @@ def main():
     if args.mode == "indexed":
         plan = prov.scan(projection=projection, target_partitions=8 * world)
         weights = [plan.partition_estimated_bytes(p) for p in range(plan.num_partitions())]
-        my_parts = pkg.shard_partitions_in_order(weights, world)[rank]
+        # contiguous runs in plan order whose heaviest run is as light as possible (sharding.py: the reference's in-order rule lets a
+        # one-byte difference in the estimates decide between 8 | 8 and 9 | 7 equal partitions, and the slowest rank is the bench's time)
+        my_parts = pkg.shard_partitions_balanced(weights, world)[rank]
         t0 = time.time()
         plan.make_resident(my_parts)   # only the compressed byte range this rank's partitions cover
         t_load += time.time() - t0

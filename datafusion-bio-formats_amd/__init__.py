@@ -9,4 +9,4 @@ opening a file without a HIP device) raises -- there is no CPU fallback.
 from .table_provider import FastqTableProvider, FastqExec  # noqa: F401
 from .table_provider import BamTableProvider, BamExec, BioscanError, load_library, bgzf_inflate, device_check, debug_balance_partitions, debug_plan_full_scan, debug_shard_partitions, debug_extract_regions, BamWriter, bgzf_deflate, bam_header_from_schema  # noqa: F401
 from .table_provider import VcfTableProvider, VcfExec, list_avg, list_gte, list_lte, list_and, vcf_set_gts, vcf_an, vcf_ac, vcf_af  # noqa: F401
-from .sharding import shard_partitions_in_order  # noqa: F401
+from .sharding import shard_partitions_in_order, shard_partitions_balanced  # noqa: F401

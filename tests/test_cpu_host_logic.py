@@ -237,3 +237,28 @@ def test_cpp_sharding_equals_python_restatement(pkg):
         world = rng.randrange(1, 12)
         want = [r for r in pkg.shard_partitions_in_order(weights, world) if r]
         assert _runs_from_c(pkg, weights, world) == want, (weights, world)
+
+
+def test_shard_partitions_balanced_is_the_contiguous_optimum(pkg):
+    """bench.py deals the partitions of a plan to its ranks with this rule: contiguous runs in plan order (so the ranks' outputs
+    concatenated are the single-GPU order, as with the reference's in-order rule) whose heaviest run is as light as any contiguous
+    split allows -- checked against every split of small random plans; on the bench's own shape (16 equal partitions + the empty
+    no-coor one) two ranks get 8 real partitions each, eight ranks of 128 + 1 get 16 each."""
+    import itertools
+    import random
+    f = pkg.shard_partitions_balanced
+    assert [len(r) for r in f([52] * 16 + [0], 2)] == [8, 9]
+    assert [len(r) for r in f([52] * 128 + [0], 8)] == [16] * 7 + [17]
+    assert f([], 3) == [[], [], []]
+    assert f([5, 5], 4) == [[0], [1], [], []]
+    rng = random.Random(1)
+    for _ in range(300):
+        n, k = rng.randint(1, 9), rng.randint(1, 6)
+        ws = [rng.choice([0, 1, 5, 7, 50, rng.randint(0, 100)]) for _ in range(n)]
+        runs = f(ws, k)
+        assert len(runs) == k and [i for r in runs for i in r] == list(range(n))
+        filled = [r for r in runs if r]
+        assert len(filled) == min(k, n)
+        best = min(max(sum(ws[a:b]) for a, b in zip((0,) + cuts, cuts + (n,)))
+                   for cuts in itertools.combinations(range(1, n), min(k, n) - 1))
+        assert max(sum(ws[i] for i in r) for r in filled) == best, (ws, k, runs)
